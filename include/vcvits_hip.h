@@ -1,0 +1,125 @@
+/*
+ * vcvits_hip.h -- C ABI of libvcvits_hip.so, the MI355X (gfx950) kernel library behind the
+ * vcvits hot path.
+ *
+ * The reference (vtuber-plan/vcvits) has no FFI: its hot path is plain PyTorch calls
+ * (F.conv1d / F.conv2d / F.conv_transpose1d / torch.stft / torch.matmul / softmax / layer_norm).
+ * Each entry point below replaces one of those call sites; the reference file:line it stands
+ * for is cited next to it.  The Python mirror of the reference modules (the vcvits_amd package) binds
+ * these symbols through ctypes (vcvits_amd/_lib.py) -- see INTEGRATION.md for the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator); the library
+ *     allocates nothing persistent and never synchronises;
+ *   - `stream` is the caller's HIP stream (hipStream_t passed as void*); all launches are
+ *     asynchronous on it;
+ *   - return value: 0 on success, negative VCV_E* otherwise (never aborts);
+ *   - tensors are dense fp32, layout [B, C, T] (or [B, C, H, P] for the period discriminators,
+ *     which the kernels address as rows of P contiguous columns).
+ */
+#ifndef VCVITS_HIP_H
+#define VCVITS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCV_OK 0
+#define VCV_EINVAL (-1)  /* bad shape / unsupported configuration */
+#define VCV_EHIP (-2)    /* a HIP runtime error was raised by the launch */
+#define VCV_ELDS (-3)    /* tile does not fit the 160 KiB LDS */
+
+/* activation / transform selectors */
+#define VCV_ACT_NONE 0
+#define VCV_ACT_LEAKY 1    /* x > 0 ? x : slope*x */
+#define VCV_ACT_RELU 2
+#define VCV_ACT_TANH 3
+#define VCV_ACT_LOGCLAMP 4 /* log(max(x, clamp)) with clamp passed in `slope` */
+
+#define VCV_TF_NONE 0
+#define VCV_TF_LEAKY 1     /* operand := leaky(operand) on load */
+#define VCV_TF_DLEAKY 2    /* operand := operand * leaky'(aux) on load (aux > 0 ? 1 : slope) */
+#define VCV_TF_DRELU 3     /* operand := operand * (aux > 0) */
+#define VCV_TF_DTANH 4     /* operand := operand * (1 - aux^2)   (aux = tanh output) */
+
+/*
+ * Generic implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *
+ *   y[b, g*Mg + m, q*os + oo, p]  (+)=  act( alpha * sum_{c<Cg, j<J} A(m, c, kw0 + j*kws) *
+ *                                   tf(x[b, g*Cg + c, q*s + j*dj + off, p]) + bias[g*Mg+m] ) ...
+ *
+ * with rows outside [0, Tin) read as zero and rows outside [0, Tout) not written.  One
+ * parametrisation covers (reference call sites):
+ *   - Conv1d forward, any stride / dilation / groups   (modules.py:126-143,190-201;
+ *     discriminator.py:53-61; relative_attention_transformer.py:121-124,283-284)
+ *   - Conv2d (k,1)/(s,1) of the period discriminators, P = period  (discriminator.py:18-25)
+ *   - ConvTranspose1d forward, one launch phase per output residue (HiFi-GAN `ups`,
+ *     synthesizer_svc.py:59 / synthesizer_tts.py:71-78)
+ *   - the data gradients of all of the above (torch autograd in the reference).
+ * Weight addressing: a_mode 0: A(m,c,k) = w[((g*Mg + m)*Cg + c)*K + k]   (Conv weight, forward)
+ *                    a_mode 1: A(m,c,k) = w[((g*Cg + c)*Mg + m)*K + k]   (transposed use)
+ * Epilogue order: v = alpha*acc + bias[m]; v = act(v); v *= dact(oaux) (out_tf); v += res;
+ *                 v *= mask[b, row]; if (accumulate) v += y;  y = v.
+ */
+typedef struct VcvConvArgs {
+  const float* x;     /* [B, G*Cg, Tin, P] */
+  const float* w;     /* see a_mode */
+  const float* bias;  /* [G*Mg] or NULL */
+  const float* res;   /* like y, or NULL */
+  const float* mask;  /* [B, Tout] or NULL */
+  const float* xaux;  /* like x, for in_tf == DLEAKY/DRELU, else NULL */
+  const float* oaux;  /* like y, for out_tf != NONE, else NULL */
+  float* y;           /* [B, G*Mg, Tout, P] */
+  int32_t B, G, Cg, Mg;
+  int32_t Tin, Tout, P;
+  int32_t K;          /* taps stored per (m,c) pair in w */
+  int32_t s, dj, off; /* input row = q*s + j*dj + off */
+  int32_t os, oo;     /* output row = q*os + oo (phase r adds r to oo when phases > 1) */
+  int32_t phases;     /* 1: J = K, kw0 = 0, kws = 1.  >1: phase r uses taps kw = r + j*phases */
+  int32_t Q;          /* number of q positions per phase */
+  int32_t a_mode, in_tf, out_act, out_tf, accumulate;
+  float alpha, slope;
+} VcvConvArgs;
+
+int vcv_conv_gemm(const VcvConvArgs* args, void* stream);
+
+/*
+ * Weight gradient of the same family (torch autograd of the call sites above):
+ *   dw[(g*Mg + m), c, k] (+)= alpha * sum_{b, q, p} tfa(dy[b, g*Mg+m, q, p]) *
+ *                                               tfb(x[b, g*Cg+c, q*s + k*dj + off, p])
+ * `a` is the un-shifted operand (dy for Conv, x for ConvTranspose), `b` the shifted one.
+ * dw is [G*Mg, Cg, K] in the `a`-major order; the reduction over (b, q) is split over
+ * workgroups and combined with fp32 atomics, so dw must be zeroed (or hold the value to
+ * accumulate onto) before the call.
+ */
+typedef struct VcvWgradArgs {
+  const float* a;     /* [B, G*Mg, Ta, P] */
+  const float* b;     /* [B, G*Cg, Tb, P] */
+  const float* aaux;  /* like a, for a_tf, or NULL */
+  const float* baux;  /* like b, for b_tf, or NULL */
+  float* dw;          /* [G*Mg, Cg, K] */
+  int32_t B, G, Cg, Mg;
+  int32_t Ta, Tb, P;
+  int32_t K;
+  int32_t s, dj, off;
+  int32_t a_tf, b_tf;
+  int32_t transpose_out; /* 1: write dw[(g*Cg + c), m, k] instead (Conv weight from ConvT roles) */
+  float alpha, slope;
+} VcvWgradArgs;
+
+int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
+
+/* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites).  dy: [B, C, T] (T = Tout*P) */
+int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T,
+                  int tf, float slope, void* stream);
+
+/* returns a static string describing the build (arch, kernel variants) */
+const char* vcv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCVITS_HIP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of libvcvits_hip.so (the C ABI declared in include/vcvits_hip.h).
+
+The library is the product path: there is NO CPU fallback.  `lib()` raises if the shared object
+is missing; every launcher raises RuntimeError on a non-zero status.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvcvits_hip.so")
+
+VCV_OK = 0
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 2, 3, 4
+TF_NONE, TF_LEAKY, TF_DLEAKY, TF_DRELU = 0, 1, 2, 3
+
+_f32p = ctypes.c_void_p
+_i32 = ctypes.c_int32
+
+
+class VcvConvArgs(ctypes.Structure):
+    _fields_ = [
+        ("x", _f32p), ("w", _f32p), ("bias", _f32p), ("res", _f32p), ("mask", _f32p),
+        ("xaux", _f32p), ("oaux", _f32p), ("y", _f32p),
+        ("B", _i32), ("G", _i32), ("Cg", _i32), ("Mg", _i32),
+        ("Tin", _i32), ("Tout", _i32), ("P", _i32),
+        ("K", _i32),
+        ("s", _i32), ("dj", _i32), ("off", _i32),
+        ("os", _i32), ("oo", _i32),
+        ("phases", _i32),
+        ("Q", _i32),
+        ("a_mode", _i32), ("in_tf", _i32), ("out_act", _i32), ("out_tf", _i32), ("accumulate", _i32),
+        ("alpha", ctypes.c_float), ("slope", ctypes.c_float),
+    ]
+
+
+class VcvWgradArgs(ctypes.Structure):
+    _fields_ = [
+        ("a", _f32p), ("b", _f32p), ("aaux", _f32p), ("baux", _f32p), ("dw", _f32p),
+        ("B", _i32), ("G", _i32), ("Cg", _i32), ("Mg", _i32),
+        ("Ta", _i32), ("Tb", _i32), ("P", _i32),
+        ("K", _i32),
+        ("s", _i32), ("dj", _i32), ("off", _i32),
+        ("a_tf", _i32), ("b_tf", _i32),
+        ("transpose_out", _i32),
+        ("alpha", ctypes.c_float), ("slope", ctypes.c_float),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvcvits_hip.so not found at %s -- run `python -m vcvits_amd.build_ext` "
+                "(there is no CPU fallback for the vcvits hot path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.vcv_version.restype = ctypes.c_char_p
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name != "vcv_version":
+                fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+# every symbol include/vcvits_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "vcv_version", "vcv_conv_gemm", "vcv_conv_wgrad", "vcv_bias_grad",
+]
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int, contiguous, on GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vcvits_amd: tensor is not on the GPU; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("vcvits_amd: non-contiguous tensor passed to a HIP launcher")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(status, what):
+    if status != VCV_OK:
+        raise RuntimeError("vcvits_hip: %s failed with status %d" % (what, status))

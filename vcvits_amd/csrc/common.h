@@ -1,0 +1,39 @@
+// common.h -- shared device helpers for the gfx950 kernels of libvcvits_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vcvits_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define VCV_LDS_LIMIT (160 * 1024)
+
+__device__ __forceinline__ float vcv_leaky(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float vcv_dleaky(float aux, float s) { return aux > 0.f ? 1.f : s; }
+
+// operand transform applied while staging global -> LDS
+__device__ __forceinline__ float vcv_tf(float v, int tf, const float* aux, size_t idx, float slope) {
+  if (tf == VCV_TF_LEAKY) return vcv_leaky(v, slope);
+  if (tf == VCV_TF_DLEAKY) return v * vcv_dleaky(aux[idx], slope);
+  if (tf == VCV_TF_DRELU) return aux[idx] > 0.f ? v : 0.f;
+  if (tf == VCV_TF_DTANH) { const float a = aux[idx]; return v * (1.f - a * a); }
+  return v;
+}
+
+__device__ __forceinline__ float vcv_act(float v, int act, float slope) {
+  switch (act) {
+    case VCV_ACT_LEAKY: return vcv_leaky(v, slope);
+    case VCV_ACT_RELU: return v > 0.f ? v : 0.f;
+    case VCV_ACT_TANH: return tanhf(v);
+    case VCV_ACT_LOGCLAMP: return logf(fmaxf(v, slope));
+    default: return v;
+  }
+}
+
+static inline int vcv_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VCV_OK : VCV_EHIP;
+}
+
+static inline int vcv_cdiv(int a, int b) { return (a + b - 1) / b; }
