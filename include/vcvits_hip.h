@@ -44,6 +44,8 @@ extern "C" {
 #define VCV_TF_DLEAKY 2    /* operand := operand * leaky'(aux) on load (aux > 0 ? 1 : slope) */
 #define VCV_TF_DRELU 3     /* operand := operand * (aux > 0) */
 #define VCV_TF_DTANH 4     /* operand := operand * (1 - aux^2)   (aux = tanh output) */
+#define VCV_TF_DLOGCLAMP 5 /* operand := aux > log(clamp) ? operand * exp(-aux) : 0  (aux = logclamp output,
+                              clamp passed in `slope`) */
 
 /*
  * Generic implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -115,6 +117,46 @@ int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
 /* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites).  dy: [B, C, T] (T = Tout*P) */
 int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T,
                   int tf, float slope, void* stream);
+
+/* ---- weight norm: torch.nn.utils.weight_norm(dim=0) at modules.py:126,132,143,190-201 and
+ * discriminator.py:16-25,52-61.  v,w: [R, C] rows; g, norm: [R] ---- */
+int vcv_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, int R, int C, void* stream);
+int vcv_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv,
+                        float* dg, int R, int C, void* stream);
+
+/* ---- streaming helpers ---- */
+/* y = (a + b + c) / 3 : mean of the three ResBlock1 branches of a HiFi-GAN stage */
+int vcv_avg3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);
+int vcv_scale(const float* x, float* y, float alpha, int64_t n, void* stream);
+/* y[b,c,t] = x[b,c,t] * mask[b,t]   (the `* x_mask` of modules.py / posterior_encoder.py) */
+int vcv_mask_mul(const float* x, const float* mask, float* y, int B, int C, int T, void* stream);
+/* F.pad(x, (0, Tp-T), "reflect") of discriminator.py:33-36 on rows [R, T] -> [R, Tp], and its adjoint */
+int vcv_reflect_pad_fwd(const float* x, float* y, int R, int T, int Tp, void* stream);
+int vcv_reflect_pad_bwd(const float* dy, float* dx, int R, int T, int Tp, void* stream);
+/* AvgPool1d(4, 2, padding=2) of multi_scale_discriminator.py:20-25: [R, T] -> [R, T/2+1], and adjoint */
+int vcv_avgpool4_fwd(const float* x, float* y, int R, int T, void* stream);
+int vcv_avgpool4_bwd(const float* dy, float* dx, int R, int T, void* stream);
+
+/* ---- loss reductions (losses.py:4-38, vcvits.py:115): out[0] += scale * sum f(a,b)
+ * mode 0: |a-b| ; mode 1: (a-target)^2.  grad: da (+)= scale * gout[0] * f'(a,b) ---- */
+int vcv_loss_sum(const float* a, const float* b, float target, int mode, float scale, float* out,
+                 int64_t n, void* stream);
+int vcv_loss_grad(const float* a, const float* b, float target, int mode, float scale, const float* gout,
+                  float* da, int accumulate, int64_t n, void* stream);
+
+/* ---- torch.optim.AdamW step over a flat buffer (vcvits.py:247-257) ---- */
+int vcv_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+              float eps, float wd, int step, void* stream);
+
+/* ---- STFT magnitude sqrt(re^2+im^2+eps), n_fft = 2048 (mel_processing.py:54-96).
+ * y: [B, T]; window: [2048]; twiddle: [1024] complex (cos, -sin)(2*pi*k/2048) interleaved;
+ * mag/dmag: [B, 1025, F], F = (T + 2*pad - 2048)/hop + 1; reflect: 0 zero pad (torchaudio
+ * spectrogram, :76-96), 1 reflect pad (:54-74).  bwd overwrites dy [B, T]. ---- */
+int vcv_stft_mag_fwd(const float* y, const float* window, const float* twiddle, float* mag, int B, int T,
+                     int n_fft, int hop, int pad, int reflect, float eps, void* stream);
+int vcv_stft_mag_bwd(const float* y, const float* window, const float* twiddle, const float* dmag,
+                     float* dy, int B, int T, int n_fft, int hop, int pad, int reflect, float eps,
+                     void* stream);
 
 /* returns a static string describing the build (arch, kernel variants) */
 const char* vcv_version(void);

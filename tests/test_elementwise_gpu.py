@@ -1,0 +1,149 @@
+"""GPU parity of the streaming kernels, STFT, mel and AdamW against torch CPU ops (fp32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(name, got, ref, tol=2e-5):
+    got = got.detach().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item() / scale
+    assert err <= tol, "%s: rel err %.3e" % (name, err)
+
+
+@pytest.mark.parametrize("shape", [(32, 1, 5, 1), (1024, 1024, 5), (16, 1, 15), (512, 256, 16), (1024, 4, 41)])
+def test_weight_norm(gpu, shape):
+    from vcvits_amd import ops
+    gen = torch.Generator().manual_seed(1)
+    v = torch.randn(shape, generator=gen)
+    g = torch.rand((shape[0],) + (1,) * (len(shape) - 1), generator=gen) + 0.5
+    vr, gr = v.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    wr = torch._weight_norm(vr, gr, 0)
+    gw = torch.randn(shape, generator=gen)
+    wr.backward(gw)
+    vg, gg = v.clone().to(gpu).requires_grad_(True), g.clone().to(gpu).requires_grad_(True)
+    wg = ops.weight_norm(vg, gg)
+    wg.backward(gw.to(gpu))
+    _cmp("w", wg, wr.detach())
+    _cmp("dv", vg.grad, vr.grad)
+    _cmp("dg", gg.grad, gr.grad)
+
+
+def test_avg3_pad_pool(gpu):
+    from vcvits_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    a, b, c = (torch.randn(2, 8, 100, generator=gen) for _ in range(3))
+    leaves = [t.clone().requires_grad_(True) for t in (a, b, c)]
+    ref = (leaves[0] + leaves[1] + leaves[2]) / 3
+    gy = torch.randn(ref.shape, generator=gen)
+    ref.backward(gy)
+    gl = [t.clone().to(gpu).requires_grad_(True) for t in (a, b, c)]
+    out = ops.avg3(*gl)
+    out.backward(gy.to(gpu))
+    _cmp("avg3", out, ref.detach())
+    _cmp("davg3", gl[1].grad, leaves[1].grad)
+
+    for T, period in [(16384, 3), (16384, 37), (8193, 7), (100, 23)]:
+        x = torch.randn(3, 1, T, generator=gen)
+        n_pad = period - T % period
+        xr = x.clone().requires_grad_(True)
+        yr = F.pad(xr, (0, n_pad), "reflect")
+        gy = torch.randn(yr.shape, generator=gen)
+        yr.backward(gy)
+        xg = x.clone().to(gpu).requires_grad_(True)
+        yg = ops.reflect_pad_right(xg, n_pad)
+        yg.backward(gy.to(gpu))
+        _cmp("pad", yg, yr.detach())
+        _cmp("dpad", xg.grad, xr.grad)
+
+    for T in [16384, 8193, 4097, 2049, 50]:
+        x = torch.randn(3, 1, T, generator=gen)
+        xr = x.clone().requires_grad_(True)
+        yr = F.avg_pool1d(xr, 4, 2, 2)
+        gy = torch.randn(yr.shape, generator=gen)
+        yr.backward(gy)
+        xg = x.clone().to(gpu).requires_grad_(True)
+        yg = ops.avgpool4(xg)
+        yg.backward(gy.to(gpu))
+        _cmp("pool", yg, yr.detach())
+        _cmp("dpool", xg.grad, xr.grad)
+
+
+def test_losses(gpu):
+    from vcvits_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    a_list = [torch.randn(2, 4, n, generator=gen) for n in (10, 333, 5000)]
+    b_list = [torch.randn(2, 4, n, generator=gen) for n in (10, 333, 5000)]
+    ar = [a.clone().requires_grad_(True) for a in a_list]
+    ref = sum(torch.mean(torch.abs(b - a)) for a, b in zip(ar, b_list)) * 2
+    ref2 = sum(torch.mean((1 - a) ** 2) for a in ar)
+    (ref * 3 + ref2).backward()
+    ag = [a.clone().to(gpu).requires_grad_(True) for a in a_list]
+    bg = [b.to(gpu) for b in b_list]
+    out = ops.l1_mean_sum(ag, bg, weight=2.0)
+    out2 = ops.sq_mean_sum(ag, 1.0)
+    (out * 3 + out2).backward()
+    _cmp("l1", out, ref.detach())
+    _cmp("sq", out2, ref2.detach())
+    for i in range(3):
+        _cmp("dl%d" % i, ag[i].grad, ar[i].grad)
+
+
+@pytest.mark.parametrize("reflect", [False, True])
+@pytest.mark.parametrize("T", [16384, 5120])
+def test_stft_mag(gpu, reflect, T):
+    from vcvits_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    y = torch.rand(3, T, generator=gen) * 1.8 - 0.9
+    yr = y.clone().requires_grad_(True)
+    win = torch.hann_window(2048)
+    yp = F.pad(yr.unsqueeze(1), (768, 768), mode="reflect" if reflect else "constant").squeeze(1)
+    spec = torch.stft(yp, 2048, hop_length=512, win_length=2048, window=win, center=False,
+                      normalized=False, onesided=True, return_complex=True)
+    mr = torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+    gm = torch.randn(mr.shape, generator=gen)
+    mr.backward(gm)
+    yg = y.clone().to(gpu).requires_grad_(True)
+    mg = ops.stft_mag(yg, 2048, 512, 768, reflect, 1e-6)
+    mg.backward(gm.to(gpu))
+    _cmp("mag", mg, mr.detach(), tol=1e-5)
+    _cmp("dy", yg.grad, yr.grad, tol=1e-4)
+
+
+def test_mel_log(gpu):
+    from vcvits_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    spec = torch.rand(2, 1025, 40, generator=gen) * 3
+    mel = torch.rand(256, 1025, generator=gen) * 0.01
+    mel[:3] = 0  # empty filters -> clamp branch
+    sr = spec.clone().requires_grad_(True)
+    ref = torch.log(torch.clamp(torch.matmul(mel.unsqueeze(0), sr), min=1e-5))
+    gy = torch.randn(ref.shape, generator=gen)
+    ref.backward(gy)
+    sg = spec.clone().to(gpu).requires_grad_(True)
+    out = ops.mel_log(sg, mel.to(gpu), 1e-5)
+    out.backward(gy.to(gpu))
+    _cmp("mel", out, ref.detach())
+    _cmp("dspec", sg.grad, sr.grad)
+
+
+def test_adamw(gpu):
+    from vcvits_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    p0 = torch.randn(10000, generator=gen)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], 2e-4, betas=(0.8, 0.99), eps=1e-9)
+    pg = p0.clone().to(gpu)
+    m = torch.zeros_like(pg)
+    v = torch.zeros_like(pg)
+    for step in range(1, 4):
+        g = torch.randn(10000, generator=gen)
+        pr.grad = g.clone()
+        opt.step()
+        ops.adamw_step(pg, g.to(gpu), m, v, 2e-4, (0.8, 0.99), 1e-9, 0.01, step)
+    _cmp("adamw", pg, pr.detach(), tol=1e-6)

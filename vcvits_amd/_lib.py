@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvcvits_hip.so")
 
 VCV_OK = 0
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 2, 3, 4
-TF_NONE, TF_LEAKY, TF_DLEAKY, TF_DRELU = 0, 1, 2, 3
+TF_NONE, TF_LEAKY, TF_DLEAKY, TF_DRELU, TF_DTANH, TF_DLOGCLAMP = 0, 1, 2, 3, 4, 5
 
 _f32p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -65,6 +65,7 @@ def lib():
             fn = getattr(L, name)
             if name != "vcv_version":
                 fn.restype = ctypes.c_int
+                fn.argtypes = _ARGTYPES[name]
         _lib = L
     return _lib
 
@@ -72,7 +73,32 @@ def lib():
 # every symbol include/vcvits_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "vcv_version", "vcv_conv_gemm", "vcv_conv_wgrad", "vcv_bias_grad",
+    "vcv_weight_norm_fwd", "vcv_weight_norm_bwd", "vcv_avg3", "vcv_scale", "vcv_mask_mul",
+    "vcv_reflect_pad_fwd", "vcv_reflect_pad_bwd", "vcv_avgpool4_fwd", "vcv_avgpool4_bwd",
+    "vcv_loss_sum", "vcv_loss_grad", "vcv_adamw", "vcv_stft_mag_fwd", "vcv_stft_mag_bwd",
 ]
+
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_ARGTYPES = {
+    "vcv_conv_gemm": [ctypes.POINTER(VcvConvArgs), _P],
+    "vcv_conv_wgrad": [ctypes.POINTER(VcvWgradArgs), _P],
+    "vcv_bias_grad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vcv_weight_norm_fwd": [_P, _P, _P, _P, _I, _I, _P],
+    "vcv_weight_norm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vcv_avg3": [_P, _P, _P, _P, _L, _P],
+    "vcv_scale": [_P, _P, _F, _L, _P],
+    "vcv_mask_mul": [_P, _P, _P, _I, _I, _I, _P],
+    "vcv_reflect_pad_fwd": [_P, _P, _I, _I, _I, _P],
+    "vcv_reflect_pad_bwd": [_P, _P, _I, _I, _I, _P],
+    "vcv_avgpool4_fwd": [_P, _P, _I, _I, _P],
+    "vcv_avgpool4_bwd": [_P, _P, _I, _I, _P],
+    "vcv_loss_sum": [_P, _P, _F, _I, _F, _P, _L, _P],
+    "vcv_loss_grad": [_P, _P, _F, _I, _F, _P, _P, _I, _L, _P],
+    "vcv_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
+    "vcv_stft_mag_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vcv_stft_mag_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+}
 
 
 def ptr(t):

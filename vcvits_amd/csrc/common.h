@@ -18,6 +18,7 @@ __device__ __forceinline__ float vcv_tf(float v, int tf, const float* aux, size_
   if (tf == VCV_TF_DLEAKY) return v * vcv_dleaky(aux[idx], slope);
   if (tf == VCV_TF_DRELU) return aux[idx] > 0.f ? v : 0.f;
   if (tf == VCV_TF_DTANH) { const float a = aux[idx]; return v * (1.f - a * a); }
+  if (tf == VCV_TF_DLOGCLAMP) { const float a = aux[idx]; return a > logf(slope) ? v * expf(-a) : 0.f; }
   return v;
 }
 

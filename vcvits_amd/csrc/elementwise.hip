@@ -1,0 +1,275 @@
+// elementwise.hip -- HBM-bound helpers of the vcvits hot path (weight-norm reparametrisation,
+// reflect pad / average pool of the discriminator inputs, loss reductions, AdamW).
+// All are streaming kernels: coalesced reads of [B, C, T] rows, one pass, wavefront (64-lane)
+// shuffles for the reductions.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  return s;
+}
+
+// block-wide sum for 256-thread blocks; result valid in every thread
+__device__ __forceinline__ float block_sum256(float s, float* red) {
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- weight norm (torch.nn.utils.weight_norm, dim=0): w = g * v / ||v||_row -----------------
+__global__ void __launch_bounds__(256)
+weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ w,
+                       float* __restrict__ norm, int C) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* vr = v + (size_t)r * C;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) { const float a = vr[i]; s += a * a; }
+  s = block_sum256(s, red);
+  const float nrm = sqrtf(s);
+  const float sc = g[r] / nrm;
+  float* wr = w + (size_t)r * C;
+  for (int i = threadIdx.x; i < C; i += 256) wr[i] = vr[i] * sc;
+  if (threadIdx.x == 0) norm[r] = nrm;
+}
+
+__global__ void __launch_bounds__(256)
+weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                       const float* __restrict__ g, const float* __restrict__ norm,
+                       float* __restrict__ dv, float* __restrict__ dg, int C) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* vr = v + (size_t)r * C;
+  const float* dwr = dw + (size_t)r * C;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) s += dwr[i] * vr[i];
+  s = block_sum256(s, red);
+  const float nrm = norm[r], gg = g[r];
+  const float a = gg / nrm, bcoef = gg * s / (nrm * nrm * nrm);
+  float* dvr = dv + (size_t)r * C;
+  for (int i = threadIdx.x; i < C; i += 256) dvr[i] = a * dwr[i] - bcoef * vr[i];
+  if (threadIdx.x == 0) dg[r] = s / nrm;
+}
+
+// ---- small streaming ops --------------------------------------------------------------------
+__global__ void avg3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                            const float* __restrict__ c, float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (a[i] + b[i] + c[i]) / 3.f;
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = alpha * x[i];
+}
+
+// y[b, c, t] = x[b, c, t] * mask[b, t]
+__global__ void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                float* __restrict__ y, int C, int T, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t bc = i / T;
+  const int t = (int)(i - bc * T);
+  const size_t b = bc / C;
+  y[i] = x[i] * mask[b * T + t];
+}
+
+// right reflect pad of each row: y[r, t] = x[r, t] (t < T), x[r, 2T-2-t] (t >= T)   (F.pad reflect)
+__global__ void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int Tp,
+                                       size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t r = i / Tp;
+  const int t = (int)(i - r * Tp);
+  y[i] = x[r * T + (t < T ? t : 2 * T - 2 - t)];
+}
+
+__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int T, int Tp,
+                                       size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t r = i / T;
+  const int t = (int)(i - r * T);
+  float v = dy[r * Tp + t];
+  const int m = 2 * T - 2 - t;  // padded position that mirrors t
+  if (m >= T && m < Tp) v += dy[r * Tp + m];
+  dx[i] = v;
+}
+
+// AvgPool1d(kernel 4, stride 2, padding 2), count_include_pad: To = T/2 + 1
+__global__ void avgpool4_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int To,
+                                    size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t r = i / To;
+  const int o = (int)(i - r * To);
+  const float* xr = x + r * T;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = 2 * o - 2 + k;
+    if (t >= 0 && t < T) s += xr[t];
+  }
+  y[i] = 0.25f * s;
+}
+
+__global__ void avgpool4_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int T, int To,
+                                    size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t r = i / T;
+  const int t = (int)(i - r * T);
+  const float* dr = dy + r * To;
+  // outputs o with 2o-2 <= t <= 2o+1  ->  o in {ceil((t-1)/2) .. floor((t+2)/2)}
+  float s = 0.f;
+  const int o0 = (t + 2) >> 1;
+  const int o1 = o0 - 1;
+  if (o0 < To) s += dr[o0];
+  if (o1 >= 0 && o1 < To) s += dr[o1];
+  dx[i] = 0.25f * s;
+}
+
+// ---- loss reductions: out[0] += scale * sum(f(a, b)) ------------------------------------------
+// mode 0: |a - b|   mode 1: (a - target)^2  (b unused)
+__global__ void __launch_bounds__(256)
+loss_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, float target, int mode,
+                float scale, float* __restrict__ out, size_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (mode == 0) s += fabsf(a[i] - b[i]);
+    else { const float d = a[i] - target; s += d * d; }
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, scale * s);
+}
+
+// da = scale * gout[0] * f'(a, b)      (accumulate != 0: da += ...)
+__global__ void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, float target,
+                                 int mode, float scale, const float* __restrict__ gout,
+                                 float* __restrict__ da, int accumulate, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = scale * gout[0];
+  float v;
+  if (mode == 0) { const float d = a[i] - b[i]; v = d > 0.f ? g : (d < 0.f ? -g : 0.f); }
+  else v = 2.f * (a[i] - target) * g;
+  da[i] = accumulate ? da[i] + v : v;
+}
+
+// ---- AdamW over a flat parameter buffer (torch.optim.AdamW semantics) -------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                             float wd, float bc1, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.f - lr * wd);
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int vcv_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, int R, int C,
+                                   void* stream) {
+  if (!v || !g || !w || !norm || R <= 0 || C <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(R), dim3(256), 0, ST, v, g, w, norm, C);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm,
+                                   float* dv, float* dg, int R, int C, void* stream) {
+  if (!dw || !v || !g || !norm || !dv || !dg || R <= 0 || C <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(R), dim3(256), 0, ST, dw, v, g, norm, dv, dg, C);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_avg3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream) {
+  if (n <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(avg3_kernel, grid1d(n), dim3(256), 0, ST, a, b, c, y, (size_t)n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_scale(const float* x, float* y, float alpha, int64_t n, void* stream) {
+  if (n <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(scale_kernel, grid1d(n), dim3(256), 0, ST, x, y, alpha, (size_t)n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_mask_mul(const float* x, const float* mask, float* y, int B, int C, int T, void* stream) {
+  const size_t n = (size_t)B * C * T;
+  if (n == 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(mask_mul_kernel, grid1d(n), dim3(256), 0, ST, x, mask, y, C, T, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_reflect_pad_fwd(const float* x, float* y, int R, int T, int Tp, void* stream) {
+  if (R <= 0 || T <= 1 || Tp < T || Tp - T > T - 1) return VCV_EINVAL;
+  const size_t n = (size_t)R * Tp;
+  hipLaunchKernelGGL(reflect_pad_fwd_kernel, grid1d(n), dim3(256), 0, ST, x, y, T, Tp, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_reflect_pad_bwd(const float* dy, float* dx, int R, int T, int Tp, void* stream) {
+  if (R <= 0 || T <= 1 || Tp < T || Tp - T > T - 1) return VCV_EINVAL;
+  const size_t n = (size_t)R * T;
+  hipLaunchKernelGGL(reflect_pad_bwd_kernel, grid1d(n), dim3(256), 0, ST, dy, dx, T, Tp, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_avgpool4_fwd(const float* x, float* y, int R, int T, void* stream) {
+  if (R <= 0 || T <= 0) return VCV_EINVAL;
+  const int To = T / 2 + 1;
+  const size_t n = (size_t)R * To;
+  hipLaunchKernelGGL(avgpool4_fwd_kernel, grid1d(n), dim3(256), 0, ST, x, y, T, To, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_avgpool4_bwd(const float* dy, float* dx, int R, int T, void* stream) {
+  if (R <= 0 || T <= 0) return VCV_EINVAL;
+  const int To = T / 2 + 1;
+  const size_t n = (size_t)R * T;
+  hipLaunchKernelGGL(avgpool4_bwd_kernel, grid1d(n), dim3(256), 0, ST, dy, dx, T, To, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_loss_sum(const float* a, const float* b, float target, int mode, float scale,
+                            float* out, int64_t n, void* stream) {
+  if (!a || !out || n <= 0 || (mode == 0 && !b)) return VCV_EINVAL;
+  size_t nb = ((size_t)n + 2047) / 2048;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(loss_sum_kernel, dim3((unsigned)nb), dim3(256), 0, ST, a, b, target, mode, scale,
+                     out, (size_t)n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_loss_grad(const float* a, const float* b, float target, int mode, float scale,
+                             const float* gout, float* da, int accumulate, int64_t n, void* stream) {
+  if (!a || !gout || !da || n <= 0 || (mode == 0 && !b)) return VCV_EINVAL;
+  hipLaunchKernelGGL(loss_grad_kernel, grid1d(n), dim3(256), 0, ST, a, b, target, mode, scale, gout, da,
+                     accumulate, (size_t)n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                         float b2, float eps, float wd, int step, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return VCV_EINVAL;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, grid1d(n), dim3(256), 0, ST, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd,
+                     (float)bc1, (float)sqrt(bc2));
+  return vcv_check_launch();
+}
