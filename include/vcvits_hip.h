@@ -158,6 +158,73 @@ int vcv_stft_mag_bwd(const float* y, const float* window, const float* twiddle, 
                      float* dy, int B, int T, int n_fft, int hop, int pad, int reflect, float eps,
                      void* stream);
 
+/* ---- WaveNet block glue (modules.py:147-175; gate = commons.py:99-106) ----
+ * xin [B,2H,T]; g = cond_layer output viewed [B, gstride] (NULL when no speaker conditioning),
+ * layer slice at goff; acts [B,H,T] = tanh(xin[:, :H]+g[:H]) * sigmoid(xin[:, H:]+g[H:]). */
+int vcv_wn_gate_fwd(const float* xin, const float* g, int gstride, int goff, float* acts, int B, int H, int T,
+                    void* stream);
+int vcv_wn_gate_bwd(const float* xin, const float* g, int gstride, int goff, const float* dacts, float* dxin,
+                    int B, int H, int T, void* stream);
+/* out[(r/inner)*ostride + ooff + r%inner] = sum_t x[r, t]  (dg of the gate: rows = B*2H, inner = 2H) */
+int vcv_row_sum(const float* x, float* out, int R, int T, int inner, int ostride, int ooff, void* stream);
+/* x_new = (x + rs[:, :H])*mask, out_new = out + rs[:, H:]  (last layer: out_new = out + rs); out may be NULL */
+int vcv_wn_res_skip_fwd(const float* x, const float* out, const float* rs, const float* mask, float* xn,
+                        float* on, int B, int H, int T, int last, void* stream);
+int vcv_wn_res_skip_bwd(const float* dxn, const float* don, const float* mask, float* drs, float* dx, int B,
+                        int H, int T, void* stream);
+
+/* ---- (m, logs) = split(stats * mask); z = (m + eps*exp(logs))*mask  (posterior_encoder.py:36-38,
+ * content_encoder.py:70-72).  eps/z may be NULL (split only). ---- */
+int vcv_split_sample_fwd(const float* stats, const float* eps, const float* mask, float* m, float* logs,
+                         float* z, int B, int C, int T, void* stream);
+int vcv_split_sample_bwd(const float* dm, const float* dlogs, const float* dz, const float* eps,
+                         const float* logs, const float* mask, float* dstats, int B, int C, int T, void* stream);
+
+/* ---- mean-only coupling (modules.py:327-336): y = m + x1*mask, or (x1 - m)*mask when reverse ---- */
+int vcv_coupling(const float* x1, const float* m, const float* mask, float* y, int B, int C, int T, int reverse,
+                 void* stream);
+
+/* ---- LayerNorm over the channel dim of [B,C,T] applied to (x + y) (modules.py:19-31 with the
+ * residual add of relative_attention_transformer.py:41,45 fused); y may be NULL ---- */
+int vcv_layernorm_c_fwd(const float* x, const float* y, const float* gamma, const float* beta, float* out,
+                        float* mean, float* rstd, int B, int C, int T, float eps, void* stream);
+int vcv_layernorm_c_bwd(const float* x, const float* y, const float* gamma, const float* mean,
+                        const float* rstd, const float* dout, float* dx, float* dgamma, float* dbeta, int B,
+                        int C, int T, void* stream);
+
+/* ---- banded relative-position softmax (relative_attention_transformer.py:157-180).
+ * S,P,Pt,dP,dSt: [B*H, T, T]; q,dO,dqband: [B, H*dk, T]; embk/embv: [2w+1, dk]; mask [B,T]. ---- */
+/* P = softmax probabilities; Pd = P after dropout(pdrop) (NULL / unused when pdrop == 0: Pd == P);
+ * Pt = transpose of Pd (the layout the P.V contraction consumes). */
+int vcv_rel_softmax_fwd(const float* S, const float* q, const float* embk, const float* mask, float* P,
+                        float* Pd, float* Pt, int B, int H, int dk, int T, int w, float qscale, float pdrop,
+                        uint64_t seed, void* stream);
+int vcv_rel_value_fwd(const float* P, const float* embv, float* out, int B, int H, int dk, int T, int w,
+                      void* stream);
+int vcv_rel_softmax_bwd(const float* P, const float* Pd, float* dP, const float* dO, const float* q,
+                        const float* embk, const float* embv, const float* mask, float* dSt, float* dqband,
+                        float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale,
+                        void* stream);
+/* nn.Dropout (relative_attention_transformer.py:40,44,292): y = x * mask(seed, index) / (1-p); the
+ * backward is the same call on dy with the same seed */
+int vcv_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+
+/* ---- KL loss (losses.py:40-55): out2[0] = sum(kl*mask), out2[1] = sum(mask) ---- */
+int vcv_kl_fwd(const float* zp, const float* lq, const float* mp, const float* lp, const float* mask,
+               float* out2, int B, int C, int T, void* stream);
+int vcv_kl_bwd(const float* zp, const float* mp, const float* lp, const float* mask, const float* gout,
+               const float* den, float* dzp, float* dlq, float* dmp, float* dlp, int B, int C, int T,
+               void* stream);
+
+/* ---- F.interpolate(mode="nearest") along T (synthesizer_svc.py:83-84) and slice_segments
+ * (commons.py:48-54): y[b,c,s] = x[b,c,ids[b]*mul + s] ---- */
+int vcv_nearest_fwd(const float* x, float* y, int R, int Tin, int Tout, void* stream);
+int vcv_nearest_bwd(const float* dy, float* dx, int R, int Tin, int Tout, void* stream);
+int vcv_slice_fwd(const float* x, const int64_t* ids, int mul, float* y, int B, int C, int T, int S,
+                  void* stream);
+int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float* dx, int B, int C, int T, int S,
+                  void* stream);
+
 /* returns a static string describing the build (arch, kernel variants) */
 const char* vcv_version(void);
 

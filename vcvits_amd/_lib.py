@@ -76,6 +76,11 @@ EXPORTS = [
     "vcv_weight_norm_fwd", "vcv_weight_norm_bwd", "vcv_avg3", "vcv_scale", "vcv_mask_mul",
     "vcv_reflect_pad_fwd", "vcv_reflect_pad_bwd", "vcv_avgpool4_fwd", "vcv_avgpool4_bwd",
     "vcv_loss_sum", "vcv_loss_grad", "vcv_adamw", "vcv_stft_mag_fwd", "vcv_stft_mag_bwd",
+    "vcv_wn_gate_fwd", "vcv_wn_gate_bwd", "vcv_row_sum", "vcv_wn_res_skip_fwd", "vcv_wn_res_skip_bwd",
+    "vcv_split_sample_fwd", "vcv_split_sample_bwd", "vcv_coupling", "vcv_layernorm_c_fwd",
+    "vcv_layernorm_c_bwd", "vcv_rel_softmax_fwd", "vcv_rel_value_fwd", "vcv_rel_softmax_bwd",
+    "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
+    "vcv_dropout",
 ]
 
 
@@ -98,6 +103,26 @@ _ARGTYPES = {
     "vcv_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "vcv_stft_mag_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "vcv_stft_mag_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vcv_wn_gate_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _P],
+    "vcv_wn_gate_bwd": [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P],
+    "vcv_row_sum": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "vcv_wn_res_skip_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vcv_wn_res_skip_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vcv_split_sample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vcv_split_sample_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vcv_coupling": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vcv_layernorm_c_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "vcv_layernorm_c_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vcv_rel_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, ctypes.c_uint64, _P],
+    "vcv_dropout": [_P, _P, _L, _F, ctypes.c_uint64, _P],
+    "vcv_rel_value_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vcv_rel_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vcv_kl_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vcv_kl_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vcv_nearest_fwd": [_P, _P, _I, _I, _I, _P],
+    "vcv_nearest_bwd": [_P, _P, _I, _I, _I, _P],
+    "vcv_slice_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "vcv_slice_bwd": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
 }
 
 

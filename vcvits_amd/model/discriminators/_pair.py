@@ -1,0 +1,21 @@
+"""Shared (y, y_hat) driver of the multi-period / multi-scale discriminators.
+
+The reference runs d(y) then d(y_hat) as two passes per discriminator
+(multi_period_discriminator.py:22-28).  When the discriminator weights take gradients (D step)
+both signals share every weight, so they are stacked into ONE batch of 2B: each conv, and each
+weight-gradient reduction, is a single launch over both.  When the weights are frozen (G step,
+Lightning-1.x toggle_optimizer semantics) the real branch needs no graph at all and is run under
+no_grad, so its data-gradient work is never issued."""
+import torch
+
+
+def run_pair(disc, y, y_hat):
+    wants_wgrad = torch.is_grad_enabled() and any(p.requires_grad for p in disc.parameters())
+    B = y.shape[0]
+    if wants_wgrad or not (y_hat.requires_grad and torch.is_grad_enabled()):
+        out, fmap = disc(torch.cat([y, y_hat], dim=0))
+        return out[:B], out[B:], [f[:B] for f in fmap], [f[B:] for f in fmap]
+    with torch.no_grad():
+        y_d_r, fmap_r = disc(y)
+    y_d_g, fmap_g = disc(y_hat)
+    return y_d_r, y_d_g, fmap_r, fmap_g

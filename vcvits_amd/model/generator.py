@@ -1,0 +1,49 @@
+"""HiFi-GAN generator -- the decoder the reference pulls from torch.hub
+("vtuber-plan/hifi-gan:v0.3.1", synthesizer_svc.py:59).  Not in the reference tree: built from the
+canonical VITS/HiFi-GAN definition with the in-tree ResBlock1
+(modules.py:186-222), ctor signature of synthesizer_tts.py:71-78, hyper-parameters of
+configs/base.json:55-63.  Parity with the hub weights is unpinned."""
+from torch import nn
+
+from .. import ops
+from .._lib import ACT_TANH
+from . import modules
+from .modules import Conv, ConvT, LRELU_SLOPE
+
+
+class Generator(nn.Module):
+    def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
+        super().__init__()
+        self.num_kernels = len(resblock_kernel_sizes)
+        self.num_upsamples = len(upsample_rates)
+        if self.num_kernels != 3:
+            raise NotImplementedError("stage mean is fused for 3 resblocks per stage (configs/base.json:57)")
+        self.conv_pre = Conv(initial_channel, upsample_initial_channel, 7, padding=3)
+        block = modules.ResBlock1 if str(resblock) == "1" else modules.ResBlock2
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            self.ups.append(ConvT(upsample_initial_channel // (2 ** i), upsample_initial_channel // (2 ** (i + 1)),
+                                  k, stride=u, padding=(k - u) // 2, weight_norm=True))
+        self.resblocks = nn.ModuleList()
+        ch = upsample_initial_channel
+        for i in range(len(self.ups)):
+            ch = upsample_initial_channel // (2 ** (i + 1))
+            for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes):
+                self.resblocks.append(block(ch, k, tuple(d)))
+        self.conv_post = Conv(ch, 1, 7, padding=3, bias=False)
+        if gin_channels != 0:
+            self.cond = Conv(gin_channels, upsample_initial_channel, 1)
+        for m in self.ups:
+            m.weight_v.data.normal_(0.0, 0.01)
+
+    def forward(self, x, g=None):
+        x = self.conv_pre(x)
+        if g is not None:
+            x = x + self.cond(g)
+        for i in range(self.num_upsamples):
+            x = self.ups[i](x, in_leaky=True, slope=LRELU_SLOPE)
+            r = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
+            x = ops.avg3(r[0], r[1], r[2])
+        # F.leaky_relu default slope 0.01 -> conv_post -> tanh, all in one launch
+        return self.conv_post(x, in_leaky=True, slope=0.01, out_act=ACT_TANH)

@@ -1,0 +1,212 @@
+"""Building blocks with the reference's names and state_dict keys (vits/model/modules.py), whose
+forward/backward run on the HIP kernels behind ops.py."""
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH
+
+LRELU_SLOPE = 0.1  # vits/model/modules.py:16
+
+
+def _default_conv_init(weight, bias):
+    """PyTorch's Conv default init (kaiming_uniform(a=sqrt(5)) + uniform bias), as the reference's
+    nn.Conv1d/Conv2d/ConvTranspose1d constructors do."""
+    nn.init.kaiming_uniform_(weight, a=5 ** 0.5)
+    if bias is not None:
+        fan_in = weight[0].numel() if weight.dim() > 1 else weight.numel()
+        bound = 1.0 / fan_in ** 0.5 if fan_in > 0 else 0.0
+        nn.init.uniform_(bias, -bound, bound)
+
+
+class Conv(nn.Module):
+    """Conv1d ([M, C/g, K]) or period Conv2d with a (K,1) kernel ([M, C/g, K, 1]).  With
+    ``weight_norm=True`` the parameters are the old-style ``weight_g`` / ``weight_v`` pair of
+    torch.nn.utils.weight_norm (same state_dict keys as the reference)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, weight_norm=False, two_d=False):
+        super().__init__()
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        shape = (out_channels, in_channels // groups, kernel_size) + ((1,) if two_d else ())
+        w = torch.empty(shape)
+        b = torch.empty(out_channels) if bias else None
+        _default_conv_init(w, b)
+        self.is_wn = weight_norm
+        # registration order follows torch: (weight, bias) for a plain conv, (bias, weight_g, weight_v)
+        # after torch.nn.utils.weight_norm
+        if weight_norm:
+            self.bias = nn.Parameter(b) if bias else None
+            gshape = (out_channels,) + (1,) * (len(shape) - 1)
+            self.weight_g = nn.Parameter(w.reshape(out_channels, -1).norm(dim=1).reshape(gshape))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+            self.bias = nn.Parameter(b) if bias else None
+
+    def effective_weight(self):
+        return ops.weight_norm(self.weight_v, self.weight_g) if self.is_wn else self.weight
+
+    def forward(self, x, in_leaky=False, out_act=ACT_NONE, slope=LRELU_SLOPE, res=None, weight=None):
+        w = self.effective_weight() if weight is None else weight
+        return ops.conv1d(x, w, self.bias, stride=self.stride, pad=self.padding, dil=self.dilation,
+                          groups=self.groups, in_leaky=in_leaky, out_act=out_act, slope=slope, res=res)
+
+
+class ConvT(nn.Module):
+    """ConvTranspose1d ([Cin, Cout, K]); weight norm is over dim 0 = Cin as torch does."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, weight_norm=True):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        w = torch.empty(in_channels, out_channels, kernel_size)
+        b = torch.empty(out_channels)
+        _default_conv_init(w, b)
+        self.bias = nn.Parameter(b)
+        self.is_wn = weight_norm
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.reshape(in_channels, -1).norm(dim=1).reshape(in_channels, 1, 1))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+
+    def effective_weight(self):
+        return ops.weight_norm(self.weight_v, self.weight_g) if self.is_wn else self.weight
+
+    def forward(self, x, in_leaky=False, slope=LRELU_SLOPE):
+        return ops.conv_transpose1d(x, self.effective_weight(), self.bias, stride=self.stride,
+                                    pad=self.padding, in_leaky=in_leaky, slope=slope)
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm over the channel dim of [B,C,T] (vits/model/modules.py:19-31); ``residual`` fuses
+    the ``x + y`` of the post-LN transformer."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x, residual=None):
+        return ops.layernorm_c(x, residual, self.gamma, self.beta, self.eps)
+
+
+class WN(nn.Module):
+    """WaveNet-style gated stack (vits/model/modules.py:109-175)."""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.hidden_channels, self.kernel_size = hidden_channels, kernel_size
+        self.dilation_rate, self.n_layers = dilation_rate, n_layers
+        self.gin_channels, self.p_dropout = gin_channels, p_dropout
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        if gin_channels != 0:
+            self.cond_layer = Conv(gin_channels, 2 * hidden_channels * n_layers, 1, weight_norm=True)
+        for i in range(n_layers):
+            dilation = dilation_rate ** i
+            padding = int((kernel_size * dilation - dilation) / 2)
+            self.in_layers.append(Conv(hidden_channels, 2 * hidden_channels, kernel_size, dilation=dilation,
+                                       padding=padding, weight_norm=True))
+            rs_ch = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(Conv(hidden_channels, rs_ch, 1, weight_norm=True))
+
+    def forward(self, x, x_mask, g=None, **kwargs):
+        mask2 = x_mask.reshape(x_mask.shape[0], x_mask.shape[-1])
+        if g is not None:
+            g = self.cond_layer(g)  # [B, 2H*L, 1]
+        output = None
+        H = self.hidden_channels
+        for i in range(self.n_layers):
+            x_in = self.in_layers[i](x)
+            acts = ops.wn_gate(x_in, g, i * 2 * H)
+            acts = ops.dropout(acts, self.p_dropout, self.training)
+            rs = self.res_skip_layers[i](acts)
+            if i < self.n_layers - 1:
+                x, output = ops.wn_res_skip(x, output, rs, mask2, False)
+            else:
+                output = ops.wn_res_skip(x, output, rs, mask2, True)
+        return ops.mask_mul(output, mask2)
+
+
+class ResBlock1(nn.Module):
+    """vits/model/modules.py:186-222; leaky-ReLU inputs and the residual add are fused into the
+    convs."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        pad = lambda d: int((kernel_size * d - d) / 2)
+        self.convs1 = nn.ModuleList([Conv(channels, channels, kernel_size, dilation=d, padding=pad(d),
+                                          weight_norm=True) for d in dilation])
+        self.convs2 = nn.ModuleList([Conv(channels, channels, kernel_size, dilation=1, padding=pad(1),
+                                          weight_norm=True) for _ in dilation])
+
+    def forward(self, x, x_mask=None):
+        if x_mask is not None:
+            raise NotImplementedError("ResBlock1 with x_mask is never used on the VC path")
+        for c1, c2 in zip(self.convs1, self.convs2):
+            xt = c1(x, in_leaky=True, slope=LRELU_SLOPE)
+            x = c2(xt, in_leaky=True, slope=LRELU_SLOPE, res=x)
+        return x
+
+
+class ResBlock2(nn.Module):
+    """vits/model/modules.py:225-247"""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        pad = lambda d: int((kernel_size * d - d) / 2)
+        self.convs = nn.ModuleList([Conv(channels, channels, kernel_size, dilation=d, padding=pad(d),
+                                         weight_norm=True) for d in dilation])
+
+    def forward(self, x, x_mask=None):
+        if x_mask is not None:
+            raise NotImplementedError("ResBlock2 with x_mask is never used on the VC path")
+        for c in self.convs:
+            x = c(x, in_leaky=True, slope=LRELU_SLOPE, res=x)
+        return x
+
+
+class Flip(nn.Module):
+    """vits/model/modules.py:261-268 (pure data movement)."""
+
+    def forward(self, x, *args, reverse=False, **kwargs):
+        x = torch.flip(x, [1])
+        if not reverse:
+            return x, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
+        return x
+
+
+class ResidualCouplingLayer(nn.Module):
+    """vits/model/modules.py:289-336."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0,
+                 gin_channels=0, mean_only=False):
+        assert channels % 2 == 0, "channels should be divisible by 2"
+        super().__init__()
+        if not mean_only:
+            raise NotImplementedError("the VC path only uses mean_only=True (flow.py:27)")
+        self.channels, self.hidden_channels = channels, hidden_channels
+        self.half_channels = channels // 2
+        self.mean_only = mean_only
+        self.pre = Conv(self.half_channels, hidden_channels, 1)
+        self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=p_dropout,
+                      gin_channels=gin_channels)
+        self.post = Conv(hidden_channels, self.half_channels, 1)
+        self.post.weight.data.zero_()
+        self.post.bias.data.zero_()
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        mask2 = x_mask.reshape(x_mask.shape[0], x_mask.shape[-1])
+        x0 = x[:, :self.half_channels].contiguous()
+        x1 = x[:, self.half_channels:].contiguous()
+        h = ops.mask_mul(self.pre(x0), mask2)
+        h = self.enc(h, x_mask, g=g)
+        m = ops.mask_mul(self.post(h), mask2)
+        x1 = ops.coupling(x1, m, mask2, reverse)
+        x = torch.cat([x0, x1], 1)
+        if not reverse:
+            return x, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)  # logs == 0 (mean_only)
+        return x

@@ -400,17 +400,19 @@ def avgpool4(x):
 # ---------------------------------------------------------------------------------------------
 # losses:  sum_i scale_i * sum f(a_i, b_i)   as ONE autograd node over many tensors
 # ---------------------------------------------------------------------------------------------
-class _LossSumFn(torch.autograd.Function):
-    """mode 0: |a-b| (b carries no grad), mode 1: (a-target)^2.  `scales[i]` multiplies term i."""
+class _LossTermsFn(torch.autograd.Function):
+    """terms[i] = scale_i * sum f(a_i, b_i) as ONE autograd node over many tensors.
+    mode 0: |a-b| (b carries no grad), mode 1: (a-target)^2."""
 
     @staticmethod
     def forward(ctx, mode, target, scales, n_a, *tensors):
         a_list = [_f32c(t) for t in tensors[:n_a]]
         b_list = [_f32c(t) for t in tensors[n_a:]] if mode == 0 else [None] * n_a
-        out = torch.zeros((), device=a_list[0].device, dtype=torch.float32)
-        for a, b, sc in zip(a_list, b_list, scales):
-            check(lib().vcv_loss_sum(ptr(a), ptr(b), target, mode, sc, ptr(out), a.numel(), stream()),
-                  "vcv_loss_sum")
+        out = torch.zeros((n_a,), device=a_list[0].device, dtype=torch.float32)
+        base = out.data_ptr()
+        for i, (a, b, sc) in enumerate(zip(a_list, b_list, scales)):
+            check(lib().vcv_loss_sum(ptr(a), ptr(b), target, mode, sc, ctypes.c_void_p(base + 4 * i),
+                                     a.numel(), stream()), "vcv_loss_sum")
         ctx.mode, ctx.target, ctx.scales, ctx.n_a = mode, target, scales, n_a
         ctx.save_for_backward(*a_list, *[b for b in b_list if b is not None])
         return out
@@ -422,29 +424,39 @@ class _LossSumFn(torch.autograd.Function):
         a_list = saved[:n_a]
         b_list = saved[n_a:] if ctx.mode == 0 else [None] * n_a
         gout = _f32c(gout)
+        gbase = gout.data_ptr()
         grads = []
         for i, (a, b, sc) in enumerate(zip(a_list, b_list, ctx.scales)):
             if not ctx.needs_input_grad[4 + i]:
                 grads.append(None)
                 continue
             da = torch.empty_like(a)
-            check(lib().vcv_loss_grad(ptr(a), ptr(b), ctx.target, ctx.mode, sc, ptr(gout), ptr(da), 0,
-                                      a.numel(), stream()), "vcv_loss_grad")
+            check(lib().vcv_loss_grad(ptr(a), ptr(b), ctx.target, ctx.mode, sc,
+                                      ctypes.c_void_p(gbase + 4 * i), ptr(da), 0, a.numel(), stream()),
+                  "vcv_loss_grad")
             grads.append(da)
         grads += [None] * (len(saved) - n_a)
         return (None, None, None, None, *grads)
 
 
-def l1_mean_sum(a_list, b_list, weight=1.0):
-    """weight * sum_i mean|a_i - b_i|  (feature_loss: weight 2; mel loss: weight c_mel)."""
+def l1_mean_terms(a_list, b_list, weight=1.0):
+    """[weight * mean|a_i - b_i|]_i as a vector (feature_loss: weight 2; mel loss: weight c_mel)."""
     scales = [weight / a.numel() for a in a_list]
-    return _LossSumFn.apply(0, 0.0, scales, len(a_list), *a_list, *b_list)
+    return _LossTermsFn.apply(0, 0.0, scales, len(a_list), *a_list, *b_list)
+
+
+def sq_mean_terms(a_list, target, weight=1.0):
+    """[weight * mean((a_i - target)^2)]_i   (LSGAN terms of losses.py:14-38)."""
+    scales = [weight / a.numel() for a in a_list]
+    return _LossTermsFn.apply(1, float(target), scales, len(a_list), *a_list)
+
+
+def l1_mean_sum(a_list, b_list, weight=1.0):
+    return l1_mean_terms(a_list, b_list, weight).sum()
 
 
 def sq_mean_sum(a_list, target, weight=1.0):
-    """weight * sum_i mean((a_i - target)^2)   (LSGAN terms of losses.py:14-38)."""
-    scales = [weight / a.numel() for a in a_list]
-    return _LossSumFn.apply(1, float(target), scales, len(a_list), *a_list)
+    return sq_mean_terms(a_list, target, weight).sum()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -529,3 +541,377 @@ def mel_log(spec, melmat, clamp=1e-5):
 def adamw_step(p, g, m, v, lr, betas, eps, weight_decay, step):
     check(lib().vcv_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps,
                           weight_decay, step, stream()), "vcv_adamw")
+
+
+# ---------------------------------------------------------------------------------------------
+# WaveNet block glue
+# ---------------------------------------------------------------------------------------------
+class _WnGateFn(torch.autograd.Function):
+    """acts = tanh(xin[:, :H] + g_l[:H]) * sigmoid(xin[:, H:] + g_l[H:]);  g: [B, 2H*L, 1] or None."""
+
+    @staticmethod
+    def forward(ctx, xin, g, goff):
+        xin, g = _f32c(xin), _f32c(g)
+        B, H2, T = xin.shape
+        H = H2 // 2
+        gstride = g.shape[1] if g is not None else 0
+        acts = torch.empty((B, H, T), device=xin.device, dtype=torch.float32)
+        check(lib().vcv_wn_gate_fwd(ptr(xin), ptr(g), gstride, goff, ptr(acts), B, H, T, stream()),
+              "vcv_wn_gate_fwd")
+        ctx.goff = goff
+        ctx.save_for_backward(xin, g)
+        return acts
+
+    @staticmethod
+    def backward(ctx, dacts):
+        xin, g = ctx.saved_tensors
+        dacts = _f32c(dacts)
+        B, H2, T = xin.shape
+        H = H2 // 2
+        gstride = g.shape[1] if g is not None else 0
+        dxin = torch.empty_like(xin)
+        check(lib().vcv_wn_gate_bwd(ptr(xin), ptr(g), gstride, ctx.goff, ptr(dacts), ptr(dxin), B, H, T,
+                                    stream()), "vcv_wn_gate_bwd")
+        dg = None
+        if g is not None and ctx.needs_input_grad[1]:
+            dg = torch.zeros_like(g)
+            check(lib().vcv_row_sum(ptr(dxin), ptr(dg), B * H2, T, H2, gstride, ctx.goff, stream()),
+                  "vcv_row_sum")
+        return dxin, dg, None
+
+
+def wn_gate(xin, g, goff):
+    return _WnGateFn.apply(xin, g, goff)
+
+
+class _WnResSkipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out, rs, mask, last):
+        x, out, rs, mask = _f32c(x), _f32c(out), _f32c(rs), _f32c(mask)
+        B, H, T = x.shape
+        on = torch.empty_like(x)
+        xn = x if last else torch.empty_like(x)
+        check(lib().vcv_wn_res_skip_fwd(ptr(x), ptr(out), ptr(rs), ptr(mask), ptr(xn), ptr(on), B, H, T,
+                                        1 if last else 0, stream()), "vcv_wn_res_skip_fwd")
+        ctx.last, ctx.has_out = last, out is not None
+        ctx.save_for_backward(mask)
+        if last:
+            return on
+        return xn, on
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (mask,) = ctx.saved_tensors
+        if ctx.last:
+            don = _f32c(grads[0])
+            return None, (don if ctx.has_out else None), don, None, None
+        dxn, don = _f32c(grads[0]), _f32c(grads[1])
+        ref = dxn if dxn is not None else don
+        B, H, T = ref.shape
+        drs = torch.empty((B, 2 * H, T), device=ref.device, dtype=torch.float32)
+        dx = torch.empty_like(ref)
+        check(lib().vcv_wn_res_skip_bwd(ptr(dxn), ptr(don), ptr(mask), ptr(drs), ptr(dx), B, H, T, stream()),
+              "vcv_wn_res_skip_bwd")
+        return dx, (don if ctx.has_out else None), drs, None, None
+
+
+def wn_res_skip(x, out, rs, mask, last):
+    """(x_new, out_new) for a middle layer, out_new for the last one (modules.py:168-174)."""
+    return _WnResSkipFn.apply(x, out, rs, mask, last)
+
+
+class _SplitSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stats, eps, mask):
+        stats, eps, mask = _f32c(stats), _f32c(eps), _f32c(mask)
+        B, C2, T = stats.shape
+        C = C2 // 2
+        m = torch.empty((B, C, T), device=stats.device, dtype=torch.float32)
+        logs = torch.empty_like(m)
+        z = torch.empty_like(m) if eps is not None else None
+        check(lib().vcv_split_sample_fwd(ptr(stats), ptr(eps), ptr(mask), ptr(m), ptr(logs), ptr(z), B, C, T,
+                                         stream()), "vcv_split_sample_fwd")
+        ctx.save_for_backward(eps, logs, mask)
+        ctx.has_eps = eps is not None
+        if eps is None:
+            return m, logs
+        return z, m, logs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        eps, logs, mask = ctx.saved_tensors
+        if ctx.has_eps:
+            dz, dm, dlogs = (_f32c(g) for g in grads)
+        else:
+            dz = None
+            dm, dlogs = (_f32c(g) for g in grads)
+        B, C, T = logs.shape
+        dstats = torch.empty((B, 2 * C, T), device=logs.device, dtype=torch.float32)
+        check(lib().vcv_split_sample_bwd(ptr(dm), ptr(dlogs), ptr(dz), ptr(eps), ptr(logs), ptr(mask),
+                                         ptr(dstats), B, C, T, stream()), "vcv_split_sample_bwd")
+        return dstats, None, None
+
+
+def split_stats(stats, mask):
+    """m, logs = split(stats * mask)."""
+    return _SplitSampleFn.apply(stats, None, mask)
+
+
+def posterior_sample(stats, eps, mask):
+    """z, m, logs with z = (m + eps*exp(logs)) * mask."""
+    return _SplitSampleFn.apply(stats, eps, mask)
+
+
+class _CouplingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, m, mask, reverse):
+        x1, m, mask = _f32c(x1), _f32c(m), _f32c(mask)
+        B, C, T = x1.shape
+        y = torch.empty_like(x1)
+        check(lib().vcv_coupling(ptr(x1), ptr(m), ptr(mask), ptr(y), B, C, T, 1 if reverse else 0, stream()),
+              "vcv_coupling")
+        ctx.reverse = reverse
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dmasked = mask_mul(dy, mask.view(mask.shape[0], 1, -1))
+        if ctx.reverse:
+            return dmasked, scale(dmasked, -1.0), None, None
+        return dmasked, dy, None, None
+
+
+def coupling(x1, m, mask, reverse=False):
+    return _CouplingFn.apply(x1, m, mask, reverse)
+
+
+class _LayerNormCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, eps):
+        x, y, gamma, beta = _f32c(x), _f32c(y), _f32c(gamma), _f32c(beta)
+        B, C, T = x.shape
+        out = torch.empty_like(x)
+        mean = torch.empty((B, T), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(lib().vcv_layernorm_c_fwd(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(out), ptr(mean), ptr(rstd),
+                                        B, C, T, eps, stream()), "vcv_layernorm_c_fwd")
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.has_y = y is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        dout = _f32c(dout)
+        B, C, T = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        check(lib().vcv_layernorm_c_bwd(ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dout), ptr(dx),
+                                        ptr(dgamma), ptr(dbeta), B, C, T, stream()), "vcv_layernorm_c_bwd")
+        return dx, (dx if ctx.has_y else None), dgamma, dbeta, None
+
+
+def layernorm_c(x, y, gamma, beta, eps=1e-5):
+    """LayerNorm over channels of (x + y) for [B,C,T] tensors (y may be None)."""
+    return _LayerNormCFn.apply(x, y, gamma, beta, eps)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        check(lib().vcv_dropout(ptr(x), ptr(y), x.numel(), p, seed, stream()), "vcv_dropout")
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().vcv_dropout(ptr(dy), ptr(dx), dy.numel(), ctx.p, ctx.seed, stream()), "vcv_dropout")
+        return dx, None, None
+
+
+_seed_state = [0x1234ABCD]
+
+
+def next_seed():
+    """Host-side seed stream for the counter-based dropout masks (reseeded by manual_seed)."""
+    _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+    return _seed_state[0]
+
+
+def manual_seed(seed):
+    _seed_state[0] = (int(seed) * 2654435761 + 0x9E3779B97F4A7C15) % (1 << 64)
+
+
+def dropout(x, p, training=True):
+    if not training or p <= 0.0:
+        return x
+    return _DropoutFn.apply(x, float(p), next_seed())
+
+
+# ---------------------------------------------------------------------------------------------
+# relative-position attention: QK^T and P.V on the MFMA GEMM kernel, banded softmax in between
+# ---------------------------------------------------------------------------------------------
+def _bgemm(x, w, out, G, Cg, Mg, T, a_mode, alpha=1.0, res=None):
+    """out[g*Mg + m, t] = alpha * sum_c A_g(m, c) * x[g*Cg + c, t] (+ res): one grouped 1x1 'conv'
+    per (batch, head) pair on vcv_conv_gemm."""
+    a = VcvConvArgs()
+    a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
+    a.B, a.G, a.Cg, a.Mg = 1, G, Cg, Mg
+    a.Tin, a.Tout, a.P, a.K = T, T, 1, 1
+    a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = 1, 1, 0, 1, 0, 1, T, a_mode
+    _common(a, alpha=alpha, res=res)
+    _launch_conv(a)
+    return out
+
+
+class _RelAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, embk, embv, mask, n_heads, window, pdrop, seed):
+        q, k, v, embk, embv, mask = (_f32c(t) for t in (q, k, v, embk, embv, mask))
+        B, C, T = q.shape
+        H = n_heads
+        dk = C // H
+        G = B * H
+        qscale = 1.0 / (dk ** 0.5)
+        dev = q.device
+        S = torch.empty((G, T, T), device=dev, dtype=torch.float32)
+        _bgemm(k, q, S, G, dk, T, T, a_mode=1, alpha=qscale)
+        P = S  # softmax in place
+        Pd = torch.empty_like(S) if pdrop > 0 else None
+        Pt = torch.empty_like(S)
+        check(lib().vcv_rel_softmax_fwd(ptr(S), ptr(q), ptr(embk), ptr(mask), ptr(P), ptr(Pd), ptr(Pt), B, H,
+                                        dk, T, window, qscale, pdrop, seed, stream()), "vcv_rel_softmax_fwd")
+        if Pd is None:
+            Pd = P
+        out = torch.empty_like(q)
+        _bgemm(Pt, v, out, G, T, dk, T, a_mode=0)
+        check(lib().vcv_rel_value_fwd(ptr(Pd), ptr(embv), ptr(out), B, H, dk, T, window, stream()),
+              "vcv_rel_value_fwd")
+        ctx.cfg = (H, window, qscale)
+        ctx.save_for_backward(q, k, v, embk, embv, mask, P, Pd)
+        attn = Pd.view(B, H, T, T)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, _dattn):
+        q, k, v, embk, embv, mask, P, Pd = ctx.saved_tensors
+        H, window, qscale = ctx.cfg
+        dout = _f32c(dout)
+        B, C, T = q.shape
+        dk = C // H
+        G = B * H
+        dv = torch.empty_like(v)
+        _bgemm(Pd, dout, dv, G, T, dk, T, a_mode=0)
+        dP = torch.empty_like(P)
+        _bgemm(v, dout, dP, G, dk, T, T, a_mode=1)
+        dSt = torch.empty_like(P)
+        dqband = torch.empty_like(q)
+        dembk = torch.empty_like(embk)
+        dembv = torch.empty_like(embv)
+        check(lib().vcv_rel_softmax_bwd(ptr(P), ptr(Pd), ptr(dP), ptr(dout), ptr(q), ptr(embk), ptr(embv),
+                                        ptr(mask), ptr(dSt), ptr(dqband), ptr(dembk), ptr(dembv), B, H, dk, T,
+                                        window, qscale, stream()), "vcv_rel_softmax_bwd")
+        dS = dP
+        dq = torch.empty_like(q)
+        _bgemm(dSt, k, dq, G, T, dk, T, a_mode=0, alpha=qscale, res=dqband)
+        dkk = torch.empty_like(k)
+        _bgemm(dS, q, dkk, G, T, dk, T, a_mode=0, alpha=qscale)
+        return dq, dkk, dv, dembk, dembv, None, None, None, None, None
+
+
+def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, pdrop=0.0, training=False):
+    """Self-attention with shared-head windowed relative embeddings; mask [B,T] (key/query
+    validity).  Returns (out [B,C,T], attn [B,H,T,T])."""
+    p = float(pdrop) if training else 0.0
+    seed = next_seed() if p > 0 else 0
+    return _RelAttnFn.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, p, seed)
+
+
+# ---------------------------------------------------------------------------------------------
+# KL loss, nearest interpolation, segment slicing
+# ---------------------------------------------------------------------------------------------
+class _KlFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z_p, logs_q, m_p, logs_p, mask):
+        z_p, logs_q, m_p, logs_p, mask = (_f32c(t) for t in (z_p, logs_q, m_p, logs_p, mask))
+        B, C, T = z_p.shape
+        out2 = torch.empty((2,), device=z_p.device, dtype=torch.float32)
+        check(lib().vcv_kl_fwd(ptr(z_p), ptr(logs_q), ptr(m_p), ptr(logs_p), ptr(mask), ptr(out2), B, C, T,
+                               stream()), "vcv_kl_fwd")
+        ctx.save_for_backward(z_p, m_p, logs_p, mask, out2)
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        z_p, m_p, logs_p, mask, out2 = ctx.saved_tensors
+        B, C, T = z_p.shape
+        gout = _f32c(gout).reshape(1)
+        den = out2[1:2]
+        grads = [torch.empty_like(z_p) for _ in range(4)]
+        check(lib().vcv_kl_bwd(ptr(z_p), ptr(m_p), ptr(logs_p), ptr(mask), ptr(gout), ptr(den), ptr(grads[0]),
+                               ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), B, C, T, stream()), "vcv_kl_bwd")
+        return grads[0], grads[1], grads[2], grads[3], None
+
+
+def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
+    return _KlFn.apply(z_p, logs_q, m_p, logs_p, z_mask)
+
+
+class _NearestFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tout):
+        x = _f32c(x)
+        B, C, Tin = x.shape
+        y = torch.empty((B, C, tout), device=x.device, dtype=torch.float32)
+        check(lib().vcv_nearest_fwd(ptr(x), ptr(y), B * C, Tin, tout, stream()), "vcv_nearest_fwd")
+        ctx.tin = Tin
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        B, C, Tout = dy.shape
+        dx = torch.empty((B, C, ctx.tin), device=dy.device, dtype=torch.float32)
+        check(lib().vcv_nearest_bwd(ptr(dy), ptr(dx), B * C, ctx.tin, Tout, stream()), "vcv_nearest_bwd")
+        return dx, None
+
+
+def interpolate_nearest(x, size):
+    return _NearestFn.apply(x, int(size))
+
+
+class _SliceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ids, mul, seg):
+        x = _f32c(x)
+        ids = ids.to(torch.int64).contiguous()
+        B, C, T = x.shape
+        y = torch.empty((B, C, seg), device=x.device, dtype=torch.float32)
+        check(lib().vcv_slice_fwd(ptr(x), ptr(ids), mul, ptr(y), B, C, T, seg, stream()), "vcv_slice_fwd")
+        ctx.shape, ctx.mul, ctx.seg = (B, C, T), mul, seg
+        ctx.save_for_backward(ids)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C, T = ctx.shape
+        dx = torch.empty((B, C, T), device=dy.device, dtype=torch.float32)
+        check(lib().vcv_slice_bwd(ptr(dy), ptr(ids), ctx.mul, ptr(dx), B, C, T, ctx.seg, stream()),
+              "vcv_slice_bwd")
+        return dx, None, None, None
+
+
+def slice_segments(x, ids_str, segment_size=4, mul=1):
+    """x[b, :, ids[b]*mul : ids[b]*mul + segment_size] (commons.py:48-54)."""
+    return _SliceFn.apply(x, ids_str, int(mul), int(segment_size))
