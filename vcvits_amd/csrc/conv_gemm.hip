@@ -18,6 +18,7 @@
 //   Epilogue (bias, activation, activation-derivative, residual, mask, accumulate) is fused on
 //   the accumulator registers; rows of 32 consecutive positions are written per register.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -237,7 +238,10 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st) {
       return VCV_EHIP;
   }
   dim3 grid(a.B * tg.ntu, a.G * tg.nmt, phases), block(64 * WM * WN);
+  const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)(phases > 1 ? a.Tin : a.Q);
+  const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
+  vcv_prof_stop(slot, st);
   return vcv_check_launch();
 }
 

@@ -12,6 +12,7 @@
 //   tab[u]          the LDS offset of position u inside a staged span (handles P > 1 rows)
 // and feeds v_mfma_f32_32x32x2_f32 with lane half h taking position 2i+h.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -181,7 +182,10 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st) {
       return VCV_EHIP;
   }
   dim3 grid(tg.nnt, a.G * tg.nmt, tg.Z), block(64 * WM * WN);
+  const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
+  const int slot = vcv_prof_start(VCV_PROF_WGRAD, flops, st);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
+  vcv_prof_stop(slot, st);
   return vcv_check_launch();
 }
 

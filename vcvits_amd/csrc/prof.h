@@ -1,0 +1,12 @@
+// prof.h -- optional per-launch HIP-event timing of the MFMA kernels (used by bench.py for the
+// roofline line: achieved FLOP/s of the dominant kernel measured on the launch stream itself).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define VCV_PROF_CONV 0
+#define VCV_PROF_WGRAD 1
+#define VCV_PROF_NCLS 2
+
+// returns a slot (>= 0) when profiling is on and an event pair was recorded before the launch
+int vcv_prof_start(int cls, double flops, hipStream_t st);
+void vcv_prof_stop(int slot, hipStream_t st);

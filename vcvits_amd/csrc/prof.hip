@@ -1,0 +1,67 @@
+// prof.hip -- event-pair pool behind vcv_prof_begin / vcv_prof_end
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+std::mutex g_mu;
+bool g_on = false;
+std::vector<hipEvent_t> g_start, g_stop;
+std::vector<int> g_cls;
+std::vector<double> g_flops;
+size_t g_used = 0;
+}  // namespace
+
+int vcv_prof_start(int cls, double flops, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on || g_used >= g_start.size()) return -1;
+  const int slot = (int)g_used++;
+  g_cls[slot] = cls;
+  g_flops[slot] = flops;
+  hipEventRecord(g_start[slot], st);
+  return slot;
+}
+
+void vcv_prof_stop(int slot, hipStream_t st) {
+  if (slot < 0) return;
+  hipEventRecord(g_stop[slot], st);
+}
+
+extern "C" int vcv_prof_begin(int max_launches) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (max_launches <= 0) return VCV_EINVAL;
+  while ((int)g_start.size() < max_launches) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return VCV_EHIP;
+    g_start.push_back(a);
+    g_stop.push_back(b);
+  }
+  g_cls.assign(g_start.size(), 0);
+  g_flops.assign(g_start.size(), 0.0);
+  g_used = 0;
+  g_on = true;
+  return VCV_OK;
+}
+
+// out[cls*3 + {0,1,2}] = {launch count, total milliseconds, total algorithmic flops}; returns the
+// number of launches that did not fit the pool (0 = all timed).  Synchronises on the events.
+extern "C" int vcv_prof_end(double* out, int ncls) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!out || ncls < VCV_PROF_NCLS) return VCV_EINVAL;
+  g_on = false;
+  for (int i = 0; i < ncls * 3; ++i) out[i] = 0.0;
+  for (size_t i = 0; i < g_used; ++i) {
+    if (hipEventSynchronize(g_stop[i]) != hipSuccess) return VCV_EHIP;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_start[i], g_stop[i]) != hipSuccess) return VCV_EHIP;
+    const int c = g_cls[i];
+    out[c * 3 + 0] += 1.0;
+    out[c * 3 + 1] += ms;
+    out[c * 3 + 2] += g_flops[i];
+  }
+  const int overflow = 0;
+  g_used = 0;
+  return overflow;
+}

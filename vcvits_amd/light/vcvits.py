@@ -1,0 +1,220 @@
+"""VCVITS training module -- the step semantics of vits/light/vcvits.py:28-283 of the reference
+without Lightning (not installed; its 1.x loop "for optimizer_idx in (0, 1): training_step ->
+backward -> step" is restated in `fit_batch`).
+
+Kept: attribute names (net_g, net_period_d, net_scale_d, hparams), `training_step(batch,
+batch_idx, optimizer_idx)`, `validation_step`, `configure_optimizers`, `on_load_checkpoint`, the
+batch-dict schema of vits/data/collate.py:177-187, the loss composition (:113-117) and the
+reference's quirks (zero-padded STFT for training targets, mel target = slice of the
+full-utterance mel, MPD default periods when the config omits them).
+Out of scope: SpeechConversionAudioPipeline and the fairseq HuBERT -- the
+batch carries content features `x_hubert_features_values` [B, hubert, T] instead of a waveform."""
+import itertools
+import logging
+from typing import Any, Dict
+
+import torch
+from torch import nn
+
+from .. import commons, ops
+from ..hparams import HParams
+from ..losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+from ..mel_processing import mel_spectrogram_torch, spec_to_mel_torch, spectrogram_torch_audio
+from ..model.discriminators.multi_period_discriminator import MultiPeriodDiscriminator
+from ..model.discriminators.multi_scale_discriminator import MultiScaleDiscriminator
+from ..model.generator import Generator
+from ..model.synthesizers.synthesizer_svc import SynthesizerSVC
+from .optim import FlatAdamW
+
+DEFAULT_PERIODS = [2, 3, 5, 7, 11, 17, 23, 37]  # multi_period_discriminator.py:10
+
+
+def _hp(v):
+    return HParams(**v) if isinstance(v, dict) else v
+
+
+class VCVITS(nn.Module):
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.hparams = HParams(**{k: (v.to_dict() if isinstance(v, HParams) else v) for k, v in kwargs.items()})
+        hp = self.hparams
+        self.net_g = self._build_generator()
+        periods = hp.model.get("multi_period_discriminator_periods", None) or DEFAULT_PERIODS
+        self.net_period_d = MultiPeriodDiscriminator(periods=list(periods),
+                                                     use_spectral_norm=hp.model.use_spectral_norm)
+        self.net_scale_d = MultiScaleDiscriminator(hp.model.use_spectral_norm)
+        self.audio_pipeline = nn.Identity()  # STFT->iSTFT augmentation of the HuBERT input: out of scope
+        self.current_epoch = 0
+        self.global_step = 0
+        self.logged = {}
+        self.optim_g = self.optim_d = None
+
+    def _build_generator(self):
+        hp = self.hparams
+        return SynthesizerSVC(hp.data.filter_length // 2 + 1, hp.train.segment_size // hp.data.hop_length,
+                              n_speakers=hp.data.n_speakers, **hp.model)
+
+    # ------------------------------------------------------------------------------------------
+    def _spec_mel(self, wav):
+        d = self.hparams.data
+        spec = spectrogram_torch_audio(wav, d.filter_length, d.target_sampling_rate, d.hop_length, d.win_length,
+                                       center=False)
+        mel = spec_to_mel_torch(spec, d.filter_length, d.n_mel_channels, d.target_sampling_rate, d.mel_fmin,
+                                d.mel_fmax)
+        return spec, mel
+
+    def _generator_pass(self, batch):
+        """vcvits.py:55-82: targets (no grad), net_g forward, waveform slice.  Returns
+        (y_hat, y, y_mel_slice, kl_args or None)."""
+        d, t = self.hparams.data, self.hparams.train
+        speakers = batch.get("sid", None)
+        x_feat, x_lengths = batch["x_hubert_features_values"], batch["x_hubert_features_lengths"]
+        x_pitch, x_pitch_lengths = batch["x_pitch_values"], batch["x_pitch_lengths"]
+        y_wav, y_wav_lengths = batch["y_wav_values"], batch["y_wav_lengths"]
+        with torch.no_grad():
+            y_spec, y_mel = self._spec_mel(y_wav.squeeze(1))
+            y_spec_lengths = (y_wav_lengths / d.hop_length).long()
+        y_hat, ids_slice, z_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \
+            self.net_g(x_feat, x_lengths, x_pitch, x_pitch_lengths, y_spec, y_spec_lengths, sid=speakers,
+                       noise=batch.get("noise", None), ids_slice=batch.get("ids_slice", None))
+        with torch.no_grad():
+            y = ops.slice_segments(y_wav, ids_slice, t.segment_size, d.hop_length)
+            y_mel_slice = commons.slice_segments(y_mel, ids_slice, t.segment_size // d.hop_length)
+        return y_hat, y, y_mel_slice, (z_p, logs_q, m_p, logs_p, z_mask)
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int, optimizer_idx: int):
+        t = self.hparams.train
+        if optimizer_idx == 0:
+            y_hat, y, y_mel_slice, kl_args = self._generator_pass(batch)
+            y_dp_hat_r, y_dp_hat_g, fmap_p_r, fmap_p_g = self.net_period_d(y, y_hat)
+            loss_p_fm = feature_loss(fmap_p_r, fmap_p_g)
+            loss_p_gen, _ = generator_loss(y_dp_hat_g)
+            y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = self.net_scale_d(y, y_hat)
+            loss_s_fm = feature_loss(fmap_s_r, fmap_s_g)
+            loss_s_gen, _ = generator_loss(y_ds_hat_g)
+            _, y_mel_hat = self._spec_mel(y_hat)  # [B,1,n_mel,32]
+            y_mel_hat = y_mel_hat.squeeze(1)
+            loss_mel = ops.l1_mean_sum([y_mel_hat], [y_mel_slice], weight=float(t.c_mel))
+            loss_gen_all = (loss_s_gen + loss_s_fm) + (loss_p_gen + loss_p_fm) + loss_mel
+            self.logged = {"loss/g/p_fm": loss_p_fm, "loss/g/s_fm": loss_s_fm, "loss/g/p_gen": loss_p_gen,
+                           "loss/g/s_gen": loss_s_gen, "loss/g/loss_mel": loss_mel}
+            if kl_args is not None:
+                loss_kl = kl_loss(*kl_args) * t.c_kl
+                loss_gen_all = loss_gen_all + loss_kl
+                self.logged["loss/g/loss_kl"] = loss_kl
+            self.logged["loss/g/total"] = loss_gen_all
+            return loss_gen_all
+        if optimizer_idx == 1:
+            with torch.no_grad():  # only y_hat.detach() is consumed (vcvits.py:153,157)
+                y_hat, y, _, _ = self._generator_pass(batch)
+            y_dp_hat_r, y_dp_hat_g, _, _ = self.net_period_d(y, y_hat.detach())
+            loss_disc_p, r_p, g_p = discriminator_loss(y_dp_hat_r, y_dp_hat_g)
+            y_ds_hat_r, y_ds_hat_g, _, _ = self.net_scale_d(y, y_hat.detach())
+            loss_disc_s, r_s, g_s = discriminator_loss(y_ds_hat_r, y_ds_hat_g)
+            loss_disc_all = loss_disc_p + loss_disc_s
+            self.logged = {"loss/d/total": loss_disc_all}
+            return loss_disc_all
+        raise ValueError("optimizer_idx must be 0 (generator) or 1 (discriminators)")
+
+    def validation_step(self, batch, batch_idx):
+        """vcvits.py:185-245 without the TensorBoard writes: returns (y_hat, y_hat_lengths, mel, y_hat_mel)."""
+        d = self.hparams.data
+        self.net_g.eval()
+        with torch.no_grad():
+            y_spec, mel = self._spec_mel(batch["y_wav_values"].squeeze(1)[:1])
+            len_scale = (d.target_sampling_rate / d.hop_length) / d.source_sampling_rate
+            y_hat, mask, _ = self.net_g.infer(batch["x_hubert_features_values"], batch["x_hubert_features_lengths"],
+                                              batch["x_pitch_values"], batch["x_pitch_lengths"],
+                                              sid=batch.get("sid", None), length_scale=len_scale, max_len=1000)
+            y_hat_lengths = mask.sum([1, 2]).long() * d.hop_length
+            y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1).float(), d.filter_length, d.n_mel_channels,
+                                              d.target_sampling_rate, d.hop_length, d.win_length, d.mel_fmin,
+                                              d.mel_fmax)
+        self.net_g.train()
+        return y_hat, y_hat_lengths, mel, y_hat_mel
+
+    # ------------------------------------------------------------------------------------------
+    def generator_parameters(self):
+        return self.net_g.parameters()
+
+    def configure_optimizers(self, process_group=None):
+        t = self.hparams.train
+        self.optim_g = FlatAdamW(self.generator_parameters(), t.learning_rate, betas=t.betas, eps=t.eps,
+                                 process_group=process_group)
+        self.optim_d = FlatAdamW(itertools.chain(self.net_period_d.parameters(), self.net_scale_d.parameters()),
+                                 t.learning_rate, betas=t.betas, eps=t.eps, process_group=process_group)
+        self.optim_g.set_epoch(max(self.current_epoch, 0), t.lr_decay)
+        self.optim_d.set_epoch(max(self.current_epoch, 0), t.lr_decay)
+        return [self.optim_g, self.optim_d], []
+
+    def _toggle(self, idx):
+        """Lightning-1.x toggle_optimizer: only the active optimizer's parameters take gradients."""
+        g_on = idx == 0
+        for p in self.optim_g.params:
+            p.requires_grad_(g_on)
+        for p in self.optim_d.params:
+            p.requires_grad_(not g_on)
+
+    def fit_batch(self, batch, batch_idx=0, after_backward=None):
+        """One batch of the reference's loop: generator step, then discriminator step.
+        `after_backward(optimizer_idx, optimizer)` is an optional probe called before each step."""
+        if self.optim_g is None:
+            self.configure_optimizers()
+        out = {}
+        for idx, opt in ((0, self.optim_g), (1, self.optim_d)):
+            self._toggle(idx)
+            opt.zero_grad()
+            loss = self.training_step(batch, batch_idx, idx)
+            loss.backward()
+            if after_backward is not None:
+                opt.finish_grad_sync()
+                after_backward(idx, opt)
+            opt.step()
+            out["g" if idx == 0 else "d"] = loss.detach()
+        for p in itertools.chain(self.optim_g.params, self.optim_d.params):
+            p.requires_grad_(True)
+        self.global_step += 1
+        return out
+
+    def on_epoch_end(self):
+        self.current_epoch += 1
+        t = self.hparams.train
+        self.optim_g.set_epoch(self.current_epoch, t.lr_decay)
+        self.optim_d.set_epoch(self.current_epoch, t.lr_decay)
+
+    def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        """vcvits.py:265-282: shape-mismatched tensors are replaced by the fresh ones, unknown keys
+        are dropped, and the optimizer state is discarded if anything changed."""
+        state_dict = checkpoint["state_dict"]
+        model_state_dict = self.state_dict()
+        is_changed = False
+        for k in list(state_dict):
+            if k in model_state_dict:
+                if state_dict[k].shape != model_state_dict[k].shape:
+                    logging.info(f"Skip loading parameter: {k}, required shape: {model_state_dict[k].shape}, "
+                                 f"loaded shape: {state_dict[k].shape}")
+                    state_dict[k] = model_state_dict[k]
+                    is_changed = True
+            else:
+                logging.info(f"Dropping parameter {k}")
+                is_changed = True
+        if is_changed:
+            checkpoint.pop("optimizer_states", None)
+
+
+class VocoderGAN(VCVITS):
+    """BASELINE.json configs[1]: "HiFi-GAN generator+discriminator step only" -- net_g is the
+    decoder alone; the batch feeds `z_slice` [B, inter_channels, 32] and the matching target
+    waveform segment `y_wav_values` [B, 1, segment_size] directly."""
+
+    def _build_generator(self):
+        m = self.hparams.model
+        return Generator(m.inter_channels, m.resblock, m.resblock_kernel_sizes, m.resblock_dilation_sizes,
+                         m.upsample_rates, m.upsample_initial_channel, m.upsample_kernel_sizes)
+
+    def _generator_pass(self, batch):
+        y = batch["y_wav_values"]
+        y_hat = self.net_g(batch["z_slice"])
+        with torch.no_grad():
+            _, y_mel = self._spec_mel(y.squeeze(1))
+        return y_hat, y, y_mel, None
