@@ -13,6 +13,9 @@
 //                     from LDS at a shifted offset, so each input element crosses HBM/L2 once per
 //                     workgroup instead of once per tap (zero padding, the fused leaky-ReLU /
 //                     activation-derivative transforms are applied here, once per element).
+//   Staging is software-pipelined through registers: the global loads of chunk c+1 are issued
+//   before the MFMA loop of chunk c and written to LDS after it, so HBM/L2 latency hides behind
+//   the matrix pipe.  All index decodes use power-of-two widths (shifts), fixed per thread.
 //   Each wave owns TM x TN tiles of v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD): lane
 //   half h feeds channel 2*c2+h, so one instruction consumes two channels of one tap.
 //   Epilogue (bias, activation, activation-derivative, residual, mask, accumulate) is fused on
@@ -22,19 +25,29 @@
 
 namespace {
 
+constexpr int VCV_ENOFIT = -100;  // internal: tile geometry exceeds the prefetch budget
+constexpr int APT = 16;  // max weight elements prefetched per thread per chunk
+constexpr int XPT = 12;  // max input elements prefetched per thread per chunk
+
 struct TileGeom {
-  int BKC;   // reduction channels per stage (even)
-  int JMAX;  // max taps per phase
-  int ROWP;  // LDS pitch of one staged input channel (floats)
-  int ntu;   // position tiles per batch element
-  int nmt;   // M tiles per group
+  int BKC;     // reduction channels per stage (even)
+  int JMAX;    // max taps per phase
+  int ROWP;    // LDS pitch of one staged input channel (floats)
+  int ntu;     // position tiles per batch element
+  int nmt;     // M tiles per group
+  int BMP;     // LDS pitch of one weight row (BM + pad)
+  int cw_log;  // a_mode 0: log2 of the padded (channel, tap) row width; a_mode 1: log2 of padded taps
+  int xw_log;  // log2 of the padded staged-span width
+  int napass;  // weight passes per thread (<= APT)
+  int nxpass;  // input passes per thread (<= XPT)
+  int xsync;   // 1: input spans exceed the prefetch registers -> staged synchronously
 };
 
-template <int TM, int TN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN)
+template <int TM, int TN, int WM, int WN, bool XAUX>
+__global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
-  constexpr int BMP = BM + 1;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
+  constexpr int BM_LOG = (BM == 128) ? 7 : (BM == 64 ? 6 : 5);
   extern __shared__ float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,7 +74,7 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   const int jmin = jspan < 0 ? jspan : 0, jmax = jspan > 0 ? jspan : 0;
   const int rlo = qa * p.s + p.off + jmin;
   const int rowlen = ((qb - qa) * p.s + (jmax - jmin) + 1) * P;
-  const int BKC = tg.BKC, ROWP = tg.ROWP;
+  const int BKC = tg.BKC, ROWP = tg.ROWP, BMP = tg.BMP;
   const int Cg = p.Cg, Mg = p.Mg, K = p.K;
 
   float* As = smem;
@@ -77,24 +90,26 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
     laneoff[tn] = ((q - qa) * p.s - jmin) * P + pc + h * ROWP;
   }
 
-  // a_mode 0: per-lane decode of the (channel, tap) columns of one weight row chunk
-  constexpr int NCOL = 4;
-  int acol_lds[NCOL], acol_c[NCOL];
-  const int ncols = BKC * K;
+  // ---- per-thread staging maps (chunk-invariant, power-of-two widths) ----
+  // a_mode 0: the thread owns column a_col of the (channel, tap) row chunk, rows a_row0 + i*a_rstep.
+  // a_mode 1: the thread owns tap slot a_col, flat (channel, m) pairs a_row0 + i*a_rstep.
+  const int cw = 1 << tg.cw_log;
+  const int a_col = tid & (cw - 1);
+  const int a_row0 = tid >> tg.cw_log;
+  const int a_rstep = NT >> tg.cw_log;
+  int a_lds_const = -1, a_cl = 0, a_kw = 0;
   if (p.a_mode == 0) {
-#pragma unroll
-    for (int i = 0; i < NCOL; ++i) {
-      const int col = lane + 64 * i;
-      acol_lds[i] = -1; acol_c[i] = 0;
-      if (col < ncols) {
-        const int cl = col / K, kw = col - cl * K;
-        const int d = kw - kw0;
-        if (d >= 0 && d % kws == 0 && d / kws < J) acol_lds[i] = (cl * J + d / kws) * BMP;
-        acol_c[i] = cl;
-      }
+    if (a_col < BKC * K) {
+      a_cl = a_col / K;
+      a_kw = a_col - a_cl * K;
+      const int d = a_kw - kw0;
+      if (d >= 0 && d % kws == 0 && d / kws < J) a_lds_const = (a_cl * J + d / kws) * BMP;
     }
+  } else {
+    if (a_col < J) a_lds_const = a_col * BMP;
+    a_kw = kw0 + a_col * kws;
   }
-  const unsigned jmagic = J > 0 ? (1u << 20) / (unsigned)J + 1u : 0u;
+  const int xw = 1 << tg.xw_log;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -108,69 +123,143 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   const float* __restrict__ x = p.x;
   const long long TinP = (long long)p.Tin * P;
   const long long f0 = (long long)rlo * P;
+  const size_t xbase_b = ((size_t)b * p.G * Cg + (size_t)g * Cg) * (size_t)TinP;
 
-  for (int c0 = 0; c0 < Cg && J > 0; c0 += BKC) {
-    __syncthreads();
-    // ---- stage weights ----
+  float areg[APT];
+  float xreg[XPT];
+  float xareg[XAUX ? XPT : 1];
+  int cur_c0 = 0;
+
+  // 32-bit element offsets relative to block-uniform bases keep one VGPR per in-flight address
+  const float* __restrict__ wblk0 = w + (size_t)(g * Mg + m0) * Cg * K;            // a_mode 0
+  const float* __restrict__ wblk1 = w + ((size_t)g * Cg * Mg + m0) * K;            // a_mode 1
+  const float* __restrict__ xblk = x + xbase_b;
+  const float* __restrict__ xablk = XAUX ? p.xaux + xbase_b : nullptr;
+  const unsigned a_rowpitch = (unsigned)(Cg * K);
+  const unsigned x_chpitch = (unsigned)TinP;  // host guarantees Cg*Tin*P < 2^31
+
+  auto load_chunk = [&](int c0) {
     if (p.a_mode == 0) {
-      for (int row = wave; row < BM; row += NW) {
-        const int m = m0 + row;
-        const float* wr = w + ((size_t)(g * Mg + m) * Cg + c0) * K;
+      const bool colok = a_lds_const >= 0 && (c0 + a_cl) < Cg;
+      const unsigned o0 = (unsigned)(c0 * K + a_col);
 #pragma unroll
-        for (int i = 0; i < NCOL; ++i) {
-          if (acol_lds[i] >= 0) {
-            float v = 0.f;
-            if (m < Mg && c0 + acol_c[i] < Cg) v = wr[lane + 64 * i];
-            As[acol_lds[i] + row] = v;
-          }
-        }
+      for (int i = 0; i < APT; ++i) {
+        const int row = a_row0 + i * a_rstep;
+        float v = 0.f;
+        if (i < tg.napass && colok && row < BM && m0 + row < Mg) v = wblk0[o0 + (unsigned)row * a_rowpitch];
+        areg[i] = v;
       }
     } else {
-      const int ne = BM * J;
-      for (int cl = wave; cl < BKC; cl += NW) {
-        const int c = c0 + cl;
-        const float* wc = w + ((size_t)(g * Cg + c) * Mg + m0) * K;
-        for (int e = lane; e < ne; e += 64) {
-          const int ml = (int)(((unsigned)e * jmagic) >> 20);
-          const int j = e - ml * J;
-          float v = 0.f;
-          if (c < Cg && m0 + ml < Mg) v = wc[ml * K + kw0 + j * kws];
-          As[(cl * J + j) * BMP + ml] = v;
-        }
-      }
-    }
-    // ---- stage input span ----
-    for (int cl = wave; cl < BKC; cl += NW) {
-      const int c = c0 + cl;
-      const size_t base = ((size_t)b * p.G * Cg + (size_t)g * Cg + c) * (size_t)TinP;
-      float* xs = Xs + cl * ROWP;
-      for (int i = lane; i < rowlen; i += 64) {
-        const long long f = f0 + i;
+#pragma unroll
+      for (int i = 0; i < APT; ++i) {
+        const int f = a_row0 + i * a_rstep;  // flat (cl, m)
+        const int cl = f >> BM_LOG, ml = f & (BM - 1);
         float v = 0.f;
-        if (c < Cg && f >= 0 && f < TinP) {
-          v = x[base + f];
-          v = vcv_tf(v, p.in_tf, p.xaux, base + f, p.slope);
-        }
-        xs[i] = v;
+        if (i < tg.napass && a_lds_const >= 0 && cl < BKC && c0 + cl < Cg && m0 + ml < Mg)
+          v = wblk1[((unsigned)(c0 + cl) * (unsigned)Mg + (unsigned)ml) * (unsigned)K + (unsigned)a_kw];
+        areg[i] = v;
       }
     }
+    cur_c0 = c0;
+    if (!tg.xsync)
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int f = tid + i * NT;
+      const int cl = f >> tg.xw_log, col = f & (xw - 1);
+      float v = 0.f, av = 0.f;
+      if (i < tg.nxpass && cl < BKC && col < rowlen && c0 + cl < Cg) {
+        const long long ff = f0 + col;
+        if (ff >= 0 && ff < TinP) {
+          const unsigned gi = (unsigned)(c0 + cl) * x_chpitch + (unsigned)ff;
+          v = xblk[gi];
+          if (XAUX) av = xablk[gi];
+        }
+      }
+      xreg[i] = v;
+      if (XAUX) xareg[i] = av;
+    }
+  };
+
+  auto store_chunk = [&]() {
+    if (a_lds_const >= 0) {
+      if (p.a_mode == 0) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+          const int row = a_row0 + i * a_rstep;
+          if (i < tg.napass && row < BM) As[a_lds_const + row] = areg[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+          const int f = a_row0 + i * a_rstep;
+          const int cl = f >> BM_LOG, ml = f & (BM - 1);
+          if (i < tg.napass && cl < BKC) As[cl * J * BMP + a_lds_const + ml] = areg[i];
+        }
+      }
+    }
+    if (tg.xsync) {
+      // generic path for very wide spans (large period x stride): load + transform + store in one loop
+      const int nel = BKC << tg.xw_log;
+      for (int f = tid; f < nel; f += NT) {
+        const int cl = f >> tg.xw_log, col = f & (xw - 1);
+        if (col >= rowlen) continue;
+        float v = 0.f;
+        const long long ff = f0 + col;
+        if (cur_c0 + cl < Cg && ff >= 0 && ff < TinP) {
+          const size_t gi = xbase_b + (size_t)(cur_c0 + cl) * (size_t)TinP + (size_t)ff;
+          v = vcv_tf(x[gi], p.in_tf, p.xaux, gi, p.slope);
+        }
+        Xs[cl * ROWP + col] = v;
+      }
+    } else
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int f = tid + i * NT;
+      const int cl = f >> tg.xw_log, col = f & (xw - 1);
+      if (i < tg.nxpass && cl < BKC && col < rowlen) {
+        float v = xreg[i];
+        if (p.in_tf == VCV_TF_LEAKY) v = vcv_leaky(v, p.slope);
+        if (XAUX) {
+          const float av = xareg[i];
+          if (p.in_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(av, p.slope);
+          else if (p.in_tf == VCV_TF_DRELU) v = av > 0.f ? v : 0.f;
+          else if (p.in_tf == VCV_TF_DTANH) v *= 1.f - av * av;
+          else if (p.in_tf == VCV_TF_DLOGCLAMP) v = av > logf(p.slope) ? v * expf(-av) : 0.f;
+        }
+        Xs[cl * ROWP + col] = v;
+      }
+    }
+  };
+
+  if (J > 0) {
+    load_chunk(0);
+    store_chunk();
     __syncthreads();
-    // ---- MFMA over (channel pair, tap) ----
-    for (int c2 = 0; c2 < BKC; c2 += 2) {
-      const float* Ab = As + (c2 + h) * J * BMP + wm * TM * 32 + l31;
-      const float* Xb = Xs + c2 * ROWP;
-      for (int j = 0; j < J; ++j) {
-        float a[TM], bb[TN];
+    for (int c0 = 0; c0 < Cg; c0 += BKC) {
+      const bool more = c0 + BKC < Cg;
+      if (more) load_chunk(c0 + BKC);
+      // ---- MFMA over (channel pair, tap) ----
+      for (int c2 = 0; c2 < BKC; c2 += 2) {
+        const float* Ab = As + (c2 + h) * J * BMP + wm * TM * 32 + l31;
+        const float* Xb = Xs + c2 * ROWP;
+        for (int j = 0; j < J; ++j) {
+          float a[TM], bb[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) a[tm] = Ab[j * BMP + tm * 32];
-        const int xo = j * p.dj * P;
+          for (int tm = 0; tm < TM; ++tm) a[tm] = Ab[j * BMP + tm * 32];
+          const int xo = j * p.dj * P;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bb[tn] = Xb[laneoff[tn] + xo];
+          for (int tn = 0; tn < TN; ++tn) bb[tn] = Xb[laneoff[tn] + xo];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+        }
+      }
+      if (more) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
       }
     }
   }
@@ -207,37 +296,72 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   }
 }
 
+inline int ilog2_ceil(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
 template <int TM, int TN, int WM, int WN>
-int launch_conv(const VcvConvArgs& a, hipStream_t st) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
   TileGeom tg;
   const int phases = a.phases > 1 ? a.phases : 1;
   tg.JMAX = phases > 1 ? vcv_cdiv(a.K, phases) : a.K;
-  // reduction channels per stage: ~32 (channel, tap) rows, even, at least 2
-  int bkc = 32 / tg.JMAX;
-  bkc &= ~1;
-  if (bkc < 2) bkc = 2;
-  if (bkc > 16) bkc = 16;
-  while (bkc > 2 && bkc * a.K > 256) bkc -= 2;
-  if (a.a_mode == 0 && bkc * a.K > 256) return VCV_EINVAL;
-  if (a.a_mode == 1 && BM * tg.JMAX > 4096) return VCV_EINVAL;
-  int cg_even = (a.Cg + 1) & ~1;
-  if (bkc > cg_even) bkc = cg_even;
-  tg.BKC = bkc;
   const int qspan = (BN - 1) / a.P + 1;
   const int adj = a.dj < 0 ? -a.dj : a.dj;
-  tg.ROWP = (qspan * a.s + (tg.JMAX - 1) * adj + 1) * a.P;
+  const int rowmax = (qspan * a.s + (tg.JMAX - 1) * adj + 1) * a.P;
+  tg.ROWP = rowmax;
+  tg.xw_log = ilog2_ceil(rowmax);
+  const int xw = 1 << tg.xw_log;
+  const int cg_even = (a.Cg + 1) & ~1;
+  // largest even channel chunk whose prefetch fits the per-thread register budget, <= ~64 (c,tap) rows
+  int best = 0;
+  for (int bkc = 2; bkc <= 64 && bkc <= cg_even; bkc += 2) {
+    if (bkc * tg.JMAX > 64 && bkc > 2) break;
+    int napass;
+    if (a.a_mode == 0) {
+      const int cwl = ilog2_ceil(bkc * a.K);
+      if ((1 << cwl) > NT) break;
+      napass = (BM << cwl) / NT;
+      if (napass < 1) napass = 1;
+    } else {
+      const int jl = ilog2_ceil(tg.JMAX);
+      if ((1 << jl) > NT) break;
+      napass = vcv_cdiv((bkc * BM) << jl, NT);
+    }
+    const int nxpass = vcv_cdiv(bkc * xw, NT);
+    if (napass > APT || (nxpass > XPT && !(allow_sync && bkc == 2))) break;
+    best = bkc;
+  }
+  if (best == 0) return VCV_ENOFIT;
+  tg.BKC = best;
+  if (a.a_mode == 0) {
+    tg.cw_log = ilog2_ceil(tg.BKC * a.K);
+    tg.napass = (BM << tg.cw_log) / NT;
+    if (tg.napass < 1) tg.napass = 1;
+    tg.BMP = BM + 1;
+  } else {
+    tg.cw_log = ilog2_ceil(tg.JMAX);
+    tg.napass = vcv_cdiv((tg.BKC * BM) << tg.cw_log, NT);
+    int pad = 32 >> tg.cw_log;
+    if (pad < 1) pad = 1;
+    tg.BMP = BM + pad;
+  }
+  tg.nxpass = vcv_cdiv(tg.BKC * xw, NT);
+  tg.xsync = tg.nxpass > XPT ? 1 : 0;
   const int U = a.Q * a.P;
   tg.ntu = vcv_cdiv(U, BN);
   tg.nmt = vcv_cdiv(a.Mg, BM);
-  const size_t lds = ((size_t)tg.BKC * tg.JMAX * (BM + 1) + (size_t)tg.BKC * tg.ROWP) * sizeof(float);
+  const size_t lds = ((size_t)tg.BKC * tg.JMAX * tg.BMP + (size_t)tg.BKC * tg.ROWP) * sizeof(float);
   if (lds > VCV_LDS_LIMIT) return VCV_ELDS;
-  auto kern = conv_gemm_kernel<TM, TN, WM, WN>;
+  const bool xaux = a.in_tf >= VCV_TF_DLEAKY;
+  auto kern = xaux ? conv_gemm_kernel<TM, TN, WM, WN, true> : conv_gemm_kernel<TM, TN, WM, WN, false>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return VCV_EHIP;
   }
-  dim3 grid(a.B * tg.ntu, a.G * tg.nmt, phases), block(64 * WM * WN);
+  dim3 grid(a.B * tg.ntu, a.G * tg.nmt, phases), block(NT);
   const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)(phases > 1 ? a.Tin : a.Q);
   const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
@@ -258,21 +382,30 @@ extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int U = a.Q * a.P;
   const int phases = a.phases > 1 ? a.phases : 1;
-  // tile choice: widest tile that still leaves >= ~2 workgroups per CU and is not mostly padding
+  // tile choice: widest tile that still leaves >= ~2 workgroups per CU and is not mostly padding;
+  // a tile whose staging does not fit the per-thread prefetch budget falls through to a narrower one
   auto ok = [&](int bm, int bn) {
     const int u32 = vcv_cdiv(U, 32) * 32;
     if (bn >= 2 * u32) return false;
     return (long long)a.B * vcv_cdiv(U, bn) * a.G * vcv_cdiv(a.Mg, bm) * phases >= 512;
   };
+  int rc = VCV_ENOFIT;
   if (a.Mg > 64) {
-    if (ok(128, 128)) return launch_conv<2, 2, 2, 2>(a, st);
-    if (ok(128, 64)) return launch_conv<2, 1, 2, 2>(a, st);
-    return launch_conv<1, 1, 2, 2>(a, st);
+    if (ok(128, 128)) rc = launch_conv<2, 2, 2, 2>(a, st);
+    if (rc == VCV_ENOFIT && ok(128, 64)) rc = launch_conv<2, 1, 2, 2>(a, st);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st, true);
+    return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
   }
   if (a.Mg > 32) {
-    if (ok(64, 128)) return launch_conv<1, 2, 2, 2>(a, st);
-    return launch_conv<1, 1, 2, 2>(a, st);
+    if (ok(64, 128)) rc = launch_conv<1, 2, 2, 2>(a, st);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st, true);
+    return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
   }
-  if (ok(32, 256)) return launch_conv<1, 2, 1, 4>(a, st);
-  return launch_conv<1, 1, 1, 4>(a, st);
+  if (ok(32, 256)) rc = launch_conv<1, 2, 1, 4>(a, st);
+  if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 4>(a, st);
+  if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 2>(a, st);
+  if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 2>(a, st, true);
+  return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
 }
