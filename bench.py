@@ -139,6 +139,8 @@ def main():
     if prof:
         out = (ctypes.c_double * 6)()
         _lib.check(L.vcv_prof_end(out, 2), "vcv_prof_end")
+        if os.environ.get("VCVITS_PROF_DUMP"):
+            L.vcv_prof_dump(os.environ["VCVITS_PROF_DUMP"].encode())
         n_conv, ms_conv, fl_conv = out[0], out[1], out[2]
         n_wg, ms_wg, fl_wg = out[3], out[4], out[5]
         if n_conv > 0 and ms_conv > 0:

@@ -232,6 +232,8 @@ int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float* dx, int B
  * 1 = conv_wgrad (ncls >= 2). ---- */
 int vcv_prof_begin(int max_launches);
 int vcv_prof_end(double* out, int ncls);
+/* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */
+int vcv_prof_dump(const char* path);
 
 /* returns a static string describing the build (arch, kernel variants) */
 const char* vcv_version(void);

@@ -29,25 +29,36 @@ constexpr int VCV_ENOFIT = -100;  // internal: tile geometry exceeds the prefetc
 constexpr int APT = 16;  // max weight elements prefetched per thread per chunk
 constexpr int XPT = 12;  // max input elements prefetched per thread per chunk
 
+// input-transform specialisations (template parameter INTF)
+constexpr int INTF_NONE = 0, INTF_LEAKY = 1, INTF_DLEAKY = 2, INTF_AUX = 3;
+
 struct TileGeom {
-  int BKC;     // reduction channels per stage (even)
-  int JMAX;    // max taps per phase
-  int ROWP;    // LDS pitch of one staged input channel (floats)
-  int ntu;     // position tiles per batch element
-  int nmt;     // M tiles per group
-  int BMP;     // LDS pitch of one weight row (BM + pad)
-  int cw_log;  // a_mode 0: log2 of the padded (channel, tap) row width; a_mode 1: log2 of padded taps
-  int xw_log;  // log2 of the padded staged-span width
-  int napass;  // weight passes per thread (<= APT)
-  int nxpass;  // input passes per thread (<= XPT)
-  int xsync;   // 1: input spans exceed the prefetch registers -> staged synchronously
+  int BKC;       // reduction channels per stage (even)
+  int JMAX;      // max taps per phase
+  int ntu;       // position tiles per batch element
+  int nmt;       // M tiles per group
+  int BMP;       // LDS pitch of one weight row (BM + pad)
+  int cw_log;    // a_mode 0: log2 of the padded (channel, tap) row width; a_mode 1: log2 of padded taps
+  int xw_log;    // log2 of the staged-span pitch (>= 6 so one wave-instruction stays inside one channel)
+  int napass;    // weight passes per thread (<= APT)
+  int nxpass;    // input passes per thread (<= XPT)
+  int a_floats;  // LDS floats reserved for the weight tile (incl. never-read overshoot rows)
+  int xsync;     // 1: spans too wide for the prefetch registers -> staged synchronously (rare: stride >= 8)
 };
 
-template <int TM, int TN, int WM, int WN, bool XAUX>
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+// Every global read of the staging path is a buffer load: the descriptor's range check returns 0
+// for rows / channels / time positions outside the tensor, so zero padding, ragged tiles and the
+// channel tail cost no predicate instructions.
+template <int TM, int TN, int WM, int WN, int INTF>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
   constexpr int BM_LOG = (BM == 128) ? 7 : (BM == 64 ? 6 : 5);
+  constexpr bool XAUX = INTF >= INTF_DLEAKY;
   extern __shared__ float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,17 +79,15 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   const int P = p.P, U = p.Q * P;
   const int u0 = ut * BN, m0 = mt * BM;
   const int qa = u0 / P;
-  int qb = (u0 + BN - 1) / P;
-  if (qb > p.Q - 1) qb = p.Q - 1;
   const int jspan = (J > 0 ? J - 1 : 0) * p.dj;
-  const int jmin = jspan < 0 ? jspan : 0, jmax = jspan > 0 ? jspan : 0;
+  const int jmin = jspan < 0 ? jspan : 0;
   const int rlo = qa * p.s + p.off + jmin;
-  const int rowlen = ((qb - qa) * p.s + (jmax - jmin) + 1) * P;
-  const int BKC = tg.BKC, ROWP = tg.ROWP, BMP = tg.BMP;
+  const int BKC = tg.BKC, BMP = tg.BMP;
   const int Cg = p.Cg, Mg = p.Mg, K = p.K;
+  const int XW = 1 << tg.xw_log;
 
   float* As = smem;
-  float* Xs = smem + BKC * tg.JMAX * BMP;
+  float* Xs = smem + tg.a_floats;
 
   // per-lane offsets of the B (input) fragment inside one staged channel row
   int laneoff[TN];
@@ -87,29 +96,35 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
     int u = u0 + (wn * TN + tn) * 32 + l31;
     if (u > U - 1) u = U - 1;
     const int q = u / P, pc = u - q * P;
-    laneoff[tn] = ((q - qa) * p.s - jmin) * P + pc + h * ROWP;
+    laneoff[tn] = ((q - qa) * p.s - jmin) * P + pc + h * XW;
   }
 
   // ---- per-thread staging maps (chunk-invariant, power-of-two widths) ----
-  // a_mode 0: the thread owns column a_col of the (channel, tap) row chunk, rows a_row0 + i*a_rstep.
-  // a_mode 1: the thread owns tap slot a_col, flat (channel, m) pairs a_row0 + i*a_rstep.
   const int cw = 1 << tg.cw_log;
   const int a_col = tid & (cw - 1);
   const int a_row0 = tid >> tg.cw_log;
   const int a_rstep = NT >> tg.cw_log;
-  int a_lds_const = -1, a_cl = 0, a_kw = 0;
+  const unsigned rowpitch = (unsigned)(Cg * K);
+  int a_lds = -1, a_cl = 0, a_kw = 0;
+  unsigned a_voff = 0xFFFFFFFFu;
   if (p.a_mode == 0) {
+    // thread owns column a_col of the (channel, tap) row chunk, rows a_row0 + i*a_rstep
     if (a_col < BKC * K) {
       a_cl = a_col / K;
       a_kw = a_col - a_cl * K;
       const int d = a_kw - kw0;
-      if (d >= 0 && d % kws == 0 && d / kws < J) a_lds_const = (a_cl * J + d / kws) * BMP;
+      if (d >= 0 && d % kws == 0 && d / kws < J) {
+        a_lds = (a_cl * J + d / kws) * BMP + a_row0;
+        a_voff = ((unsigned)a_row0 * rowpitch + (unsigned)a_col) * 4u;
+      }
     }
   } else {
-    if (a_col < J) a_lds_const = a_col * BMP;
+    // thread owns tap slot a_col, flat (channel, m) pairs a_row0 + i*a_rstep
+    if (a_col < J) a_lds = a_col * BMP;
     a_kw = kw0 + a_col * kws;
   }
-  const int xw = 1 << tg.xw_log;
+  const unsigned a_vstep = (unsigned)a_rstep * rowpitch * 4u;
+  const bool mtail = m0 + BM > Mg;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -119,116 +134,104 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
 
-  const float* __restrict__ w = p.w;
-  const float* __restrict__ x = p.x;
   const long long TinP = (long long)p.Tin * P;
-  const long long f0 = (long long)rlo * P;
+  const unsigned xrec = (unsigned)(TinP * 4);
   const size_t xbase_b = ((size_t)b * p.G * Cg + (size_t)g * Cg) * (size_t)TinP;
+  const int f0 = rlo * P;
+  const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
 
   float areg[APT];
   float xreg[XPT];
   float xareg[XAUX ? XPT : 1];
   int cur_c0 = 0;
 
-  // 32-bit element offsets relative to block-uniform bases keep one VGPR per in-flight address
-  const float* __restrict__ wblk0 = w + (size_t)(g * Mg + m0) * Cg * K;            // a_mode 0
-  const float* __restrict__ wblk1 = w + ((size_t)g * Cg * Mg + m0) * K;            // a_mode 1
-  const float* __restrict__ xblk = x + xbase_b;
-  const float* __restrict__ xablk = XAUX ? p.xaux + xbase_b : nullptr;
-  const unsigned a_rowpitch = (unsigned)(Cg * K);
-  const unsigned x_chpitch = (unsigned)TinP;  // host guarantees Cg*Tin*P < 2^31
-
   auto load_chunk = [&](int c0) {
     if (p.a_mode == 0) {
-      const bool colok = a_lds_const >= 0 && (c0 + a_cl) < Cg;
-      const unsigned o0 = (unsigned)(c0 * K + a_col);
+      const float* base = p.w + (size_t)(g * Mg + m0) * rowpitch + (size_t)c0 * K;
+      const long long rem = (long long)rows_valid * rowpitch - (long long)c0 * K;
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rem > 0 ? rem * 4 : 0), 0x00020000);
+      const unsigned v0 = (c0 + a_cl < Cg) ? a_voff : 0xFFFFFFFFu;
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        const int row = a_row0 + i * a_rstep;
-        float v = 0.f;
-        if (i < tg.napass && colok && row < BM && m0 + row < Mg) v = wblk0[o0 + (unsigned)row * a_rowpitch];
-        areg[i] = v;
-      }
+      for (int i = 0; i < APT; ++i)
+        if (i < tg.napass) areg[i] = ld_buf(ra, v0 == 0xFFFFFFFFu ? v0 : v0 + (unsigned)i * a_vstep);
     } else {
+      const float* base = p.w + ((size_t)(g * Cg + c0) * Mg + m0) * K;
+      const long long rem = ((long long)(Cg - c0) * Mg - m0) * K;
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rem > 0 ? rem * 4 : 0), 0x00020000);
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        const int f = a_row0 + i * a_rstep;  // flat (cl, m)
-        const int cl = f >> BM_LOG, ml = f & (BM - 1);
-        float v = 0.f;
-        if (i < tg.napass && a_lds_const >= 0 && cl < BKC && c0 + cl < Cg && m0 + ml < Mg)
-          v = wblk1[((unsigned)(c0 + cl) * (unsigned)Mg + (unsigned)ml) * (unsigned)K + (unsigned)a_kw];
-        areg[i] = v;
-      }
+      for (int i = 0; i < APT; ++i)
+        if (i < tg.napass) {
+          const int f = a_row0 + i * a_rstep;  // flat (cl, m)
+          const int cl = f >> BM_LOG, ml = f & (BM - 1);
+          unsigned v = ((unsigned)(cl * Mg + ml) * (unsigned)K + (unsigned)a_kw) * 4u;
+          if (a_lds < 0 || (mtail && ml >= rows_valid)) v = 0xFFFFFFFFu;
+          areg[i] = ld_buf(ra, v);
+        }
     }
     cur_c0 = c0;
     if (!tg.xsync)
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int f = tid + i * NT;
-      const int cl = f >> tg.xw_log, col = f & (xw - 1);
-      float v = 0.f, av = 0.f;
-      if (i < tg.nxpass && cl < BKC && col < rowlen && c0 + cl < Cg) {
-        const long long ff = f0 + col;
-        if (ff >= 0 && ff < TinP) {
-          const unsigned gi = (unsigned)(c0 + cl) * x_chpitch + (unsigned)ff;
-          v = xblk[gi];
-          if (XAUX) av = xablk[gi];
+    for (int i = 0; i < XPT; ++i)
+      if (i < tg.nxpass) {
+        const int f = tid + i * NT;
+        const int cl = __builtin_amdgcn_readfirstlane(f >> tg.xw_log);
+        const int col = f & (XW - 1);
+        const size_t rowbase = xbase_b + (size_t)(c0 + cl) * (size_t)TinP;
+        const unsigned rec = (c0 + cl < Cg) ? xrec : 0u;
+        const unsigned voff = (unsigned)(f0 + col) * 4u;  // negative positions wrap -> out of range -> 0
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + rowbase), 0, (int)rec, 0x00020000);
+        xreg[i] = ld_buf(rx, voff);
+        if (XAUX) {
+          __amdgpu_buffer_rsrc_t rxa = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xaux + rowbase), 0, (int)rec, 0x00020000);
+          xareg[i] = ld_buf(rxa, voff);
         }
       }
-      xreg[i] = v;
-      if (XAUX) xareg[i] = av;
-    }
   };
 
   auto store_chunk = [&]() {
-    if (a_lds_const >= 0) {
+    if (a_lds >= 0) {
       if (p.a_mode == 0) {
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
-          const int row = a_row0 + i * a_rstep;
-          if (i < tg.napass && row < BM) As[a_lds_const + row] = areg[i];
-        }
+        for (int i = 0; i < APT; ++i)
+          if (i < tg.napass) As[a_lds + i * a_rstep] = areg[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
-          const int f = a_row0 + i * a_rstep;
-          const int cl = f >> BM_LOG, ml = f & (BM - 1);
-          if (i < tg.napass && cl < BKC) As[cl * J * BMP + a_lds_const + ml] = areg[i];
-        }
+        for (int i = 0; i < APT; ++i)
+          if (i < tg.napass) {
+            const int f = a_row0 + i * a_rstep;
+            const int cl = f >> BM_LOG, ml = f & (BM - 1);
+            As[cl * J * BMP + a_lds + ml] = areg[i];
+          }
       }
     }
     if (tg.xsync) {
-      // generic path for very wide spans (large period x stride): load + transform + store in one loop
       const int nel = BKC << tg.xw_log;
       for (int f = tid; f < nel; f += NT) {
-        const int cl = f >> tg.xw_log, col = f & (xw - 1);
-        if (col >= rowlen) continue;
+        const int cl = f >> tg.xw_log, col = f & (XW - 1);
+        const long long ff = (long long)f0 + col;
         float v = 0.f;
-        const long long ff = f0 + col;
         if (cur_c0 + cl < Cg && ff >= 0 && ff < TinP) {
           const size_t gi = xbase_b + (size_t)(cur_c0 + cl) * (size_t)TinP + (size_t)ff;
-          v = vcv_tf(x[gi], p.in_tf, p.xaux, gi, p.slope);
+          v = vcv_tf(p.x[gi], p.in_tf, p.xaux, gi, p.slope);
         }
-        Xs[cl * ROWP + col] = v;
+        Xs[f] = v;
       }
     } else
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int f = tid + i * NT;
-      const int cl = f >> tg.xw_log, col = f & (xw - 1);
-      if (i < tg.nxpass && cl < BKC && col < rowlen) {
+    for (int i = 0; i < XPT; ++i)
+      if (i < tg.nxpass) {
         float v = xreg[i];
-        if (p.in_tf == VCV_TF_LEAKY) v = vcv_leaky(v, p.slope);
-        if (XAUX) {
+        if (INTF == INTF_LEAKY) v = vcv_leaky(v, p.slope);
+        if (INTF == INTF_DLEAKY) v *= vcv_dleaky(xareg[i], p.slope);
+        if (INTF == INTF_AUX) {
           const float av = xareg[i];
-          if (p.in_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(av, p.slope);
-          else if (p.in_tf == VCV_TF_DRELU) v = av > 0.f ? v : 0.f;
+          if (p.in_tf == VCV_TF_DRELU) v = av > 0.f ? v : 0.f;
           else if (p.in_tf == VCV_TF_DTANH) v *= 1.f - av * av;
           else if (p.in_tf == VCV_TF_DLOGCLAMP) v = av > logf(p.slope) ? v * expf(-av) : 0.f;
+          else v *= vcv_dleaky(av, p.slope);
         }
-        Xs[cl * ROWP + col] = v;
+        Xs[tid + i * NT] = v;  // == Xs[cl * XW + col]
       }
-    }
   };
 
   if (J > 0) {
@@ -241,7 +244,7 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
       // ---- MFMA over (channel pair, tap) ----
       for (int c2 = 0; c2 < BKC; c2 += 2) {
         const float* Ab = As + (c2 + h) * J * BMP + wm * TM * 32 + l31;
-        const float* Xb = Xs + c2 * ROWP;
+        const float* Xb = Xs + c2 * XW;
         for (int j = 0; j < J; ++j) {
           float a[TM], bb[TN];
 #pragma unroll
@@ -265,6 +268,9 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   }
 
   // ---- epilogue ----
+  const unsigned rowstride = (unsigned)(p.Tout * P);
+  const size_t ybase = ((size_t)b * p.G * Mg + (size_t)g * Mg + m0) * rowstride;
+  const float* bias = p.bias ? p.bias + g * Mg + m0 : nullptr;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int u = u0 + (wn * TN + tn) * 32 + l31;
@@ -273,16 +279,16 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
     const int trow = q * p.os + oo;
     if (trow < 0 || trow >= p.Tout) continue;
     const float mk = p.mask ? p.mask[(size_t)b * p.Tout + trow] : 1.f;
+    const size_t colbase = ybase + (size_t)trow * P + pc;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int ml = m0 + (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (ml >= Mg) continue;
-        const int mg = g * Mg + ml;
-        const size_t idx = (((size_t)b * p.G * Mg + mg) * p.Tout + trow) * P + pc;
+        const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (mtail && ml >= rows_valid) continue;
+        const size_t idx = colbase + (size_t)((unsigned)ml * rowstride);
         float v = p.alpha * acc[tm][tn][e];
-        if (p.bias) v += p.bias[mg];
+        if (bias) v += bias[ml];
         v = vcv_act(v, p.out_act, p.slope);
         if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
         else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
@@ -311,20 +317,21 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   const int qspan = (BN - 1) / a.P + 1;
   const int adj = a.dj < 0 ? -a.dj : a.dj;
   const int rowmax = (qspan * a.s + (tg.JMAX - 1) * adj + 1) * a.P;
-  tg.ROWP = rowmax;
   tg.xw_log = ilog2_ceil(rowmax);
+  if (tg.xw_log < 6) tg.xw_log = 6;
   const int xw = 1 << tg.xw_log;
   const int cg_even = (a.Cg + 1) & ~1;
+  const int min_cwl = ilog2_ceil(NT / BM);  // at least NT/BM columns so one pass never overshoots BM rows
   // largest even channel chunk whose prefetch fits the per-thread register budget, <= ~64 (c,tap) rows
   int best = 0;
   for (int bkc = 2; bkc <= 64 && bkc <= cg_even; bkc += 2) {
     if (bkc * tg.JMAX > 64 && bkc > 2) break;
     int napass;
     if (a.a_mode == 0) {
-      const int cwl = ilog2_ceil(bkc * a.K);
+      int cwl = ilog2_ceil(bkc * a.K);
+      if (cwl < min_cwl) cwl = min_cwl;
       if ((1 << cwl) > NT) break;
       napass = (BM << cwl) / NT;
-      if (napass < 1) napass = 1;
     } else {
       const int jl = ilog2_ceil(tg.JMAX);
       if ((1 << jl) > NT) break;
@@ -338,32 +345,46 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   tg.BKC = best;
   if (a.a_mode == 0) {
     tg.cw_log = ilog2_ceil(tg.BKC * a.K);
+    if (tg.cw_log < min_cwl) tg.cw_log = min_cwl;
     tg.napass = (BM << tg.cw_log) / NT;
-    if (tg.napass < 1) tg.napass = 1;
     tg.BMP = BM + 1;
+    tg.a_floats = tg.BKC * tg.JMAX * tg.BMP;
   } else {
     tg.cw_log = ilog2_ceil(tg.JMAX);
     tg.napass = vcv_cdiv((tg.BKC * BM) << tg.cw_log, NT);
     int pad = 32 >> tg.cw_log;
     if (pad < 1) pad = 1;
     tg.BMP = BM + pad;
+    const int cl_alloc = vcv_cdiv(tg.napass * (NT >> tg.cw_log), BM);  // channels the passes touch
+    tg.a_floats = (cl_alloc > tg.BKC ? cl_alloc : tg.BKC) * tg.JMAX * tg.BMP;
   }
   tg.nxpass = vcv_cdiv(tg.BKC * xw, NT);
   tg.xsync = tg.nxpass > XPT ? 1 : 0;
+  const int x_floats = tg.nxpass * NT > tg.BKC * xw ? tg.nxpass * NT : tg.BKC * xw;
   const int U = a.Q * a.P;
   tg.ntu = vcv_cdiv(U, BN);
   tg.nmt = vcv_cdiv(a.Mg, BM);
-  const size_t lds = ((size_t)tg.BKC * tg.JMAX * tg.BMP + (size_t)tg.BKC * tg.ROWP) * sizeof(float);
-  if (lds > VCV_LDS_LIMIT) return VCV_ELDS;
-  const bool xaux = a.in_tf >= VCV_TF_DLEAKY;
-  auto kern = xaux ? conv_gemm_kernel<TM, TN, WM, WN, true> : conv_gemm_kernel<TM, TN, WM, WN, false>;
+  const size_t lds = ((size_t)tg.a_floats + (size_t)x_floats) * sizeof(float);
+  if (lds > VCV_LDS_LIMIT) return VCV_ENOFIT;
+  // 32-bit offset preconditions of the buffer-load staging
+  if ((long long)a.Tin * a.P * 4 >= (1ll << 31) || (long long)a.Mg * a.Cg * a.K * 4 >= (1ll << 31) ||
+      (long long)a.Mg * a.Tout * a.P >= (1ll << 31))
+    return VCV_EINVAL;
+  void (*kern)(const VcvConvArgs, const TileGeom);
+  switch (a.in_tf) {
+    case VCV_TF_NONE: kern = conv_gemm_kernel<TM, TN, WM, WN, INTF_NONE>; break;
+    case VCV_TF_LEAKY: kern = conv_gemm_kernel<TM, TN, WM, WN, INTF_LEAKY>; break;
+    case VCV_TF_DLEAKY: kern = conv_gemm_kernel<TM, TN, WM, WN, INTF_DLEAKY>; break;
+    default: kern = conv_gemm_kernel<TM, TN, WM, WN, INTF_AUX>; break;
+  }
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return VCV_EHIP;
   }
   dim3 grid(a.B * tg.ntu, a.G * tg.nmt, phases), block(NT);
   const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)(phases > 1 ? a.Tin : a.Q);
-  const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st);
+  const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, phases, a.a_mode, BM * 1000 + BN, tg.BKC};
+  const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st, tag, 12);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
   vcv_prof_stop(slot, st);
   return vcv_check_launch();

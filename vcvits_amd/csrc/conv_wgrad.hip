@@ -287,7 +287,8 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   }
   dim3 grid(tg.nnt, a.G * tg.nmt, tg.Z), block(NT);
   const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
-  const int slot = vcv_prof_start(VCV_PROF_WGRAD, flops, st);
+  const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, tg.Z, tg.xsync, BM * 1000 + BN, tg.NCH};
+  const int slot = vcv_prof_start(VCV_PROF_WGRAD, flops, st, tag, 12);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
   vcv_prof_stop(slot, st);
   return vcv_check_launch();

@@ -8,5 +8,5 @@
 #define VCV_PROF_NCLS 2
 
 // returns a slot (>= 0) when profiling is on and an event pair was recorded before the launch
-int vcv_prof_start(int cls, double flops, hipStream_t st);
+int vcv_prof_start(int cls, double flops, hipStream_t st, const int* tag = nullptr, int ntag = 0);
 void vcv_prof_stop(int slot, hipStream_t st);

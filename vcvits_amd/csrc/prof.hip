@@ -1,4 +1,5 @@
 // prof.hip -- event-pair pool behind vcv_prof_begin / vcv_prof_end
+#include <cstdio>
 #include <mutex>
 #include <vector>
 
@@ -11,15 +12,19 @@ bool g_on = false;
 std::vector<hipEvent_t> g_start, g_stop;
 std::vector<int> g_cls;
 std::vector<double> g_flops;
-size_t g_used = 0;
+std::vector<int> g_tags;  // 12 ints per slot
+constexpr int NTAG = 12;
+size_t g_used = 0, g_last_used = 0;
+std::vector<float> g_ms;
 }  // namespace
 
-int vcv_prof_start(int cls, double flops, hipStream_t st) {
+int vcv_prof_start(int cls, double flops, hipStream_t st, const int* tag, int ntag) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_on || g_used >= g_start.size()) return -1;
   const int slot = (int)g_used++;
   g_cls[slot] = cls;
   g_flops[slot] = flops;
+  for (int i = 0; i < NTAG; ++i) g_tags[slot * NTAG + i] = (tag && i < ntag) ? tag[i] : 0;
   hipEventRecord(g_start[slot], st);
   return slot;
 }
@@ -40,6 +45,7 @@ extern "C" int vcv_prof_begin(int max_launches) {
   }
   g_cls.assign(g_start.size(), 0);
   g_flops.assign(g_start.size(), 0.0);
+  g_tags.assign(g_start.size() * NTAG, 0);
   g_used = 0;
   g_on = true;
   return VCV_OK;
@@ -61,7 +67,24 @@ extern "C" int vcv_prof_end(double* out, int ncls) {
     out[c * 3 + 1] += ms;
     out[c * 3 + 2] += g_flops[i];
   }
-  const int overflow = 0;
+  g_last_used = g_used;
+  g_ms.assign(g_used, 0.f);
+  for (size_t i = 0; i < g_used; ++i) hipEventElapsedTime(&g_ms[i], g_start[i], g_stop[i]);
   g_used = 0;
-  return overflow;
+  return 0;
+}
+
+// debugging aid: per-launch records of the last vcv_prof_begin/end window as CSV
+// (cls, ms, gflop, then the 12 shape tags the launcher attached)
+extern "C" int vcv_prof_dump(const char* path) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  FILE* f = fopen(path, "w");
+  if (!f) return VCV_EINVAL;
+  for (size_t i = 0; i < g_last_used; ++i) {
+    fprintf(f, "%d,%.6f,%.6f", g_cls[i], g_ms[i], g_flops[i] / 1e9);
+    for (int t = 0; t < NTAG; ++t) fprintf(f, ",%d", g_tags[i * NTAG + t]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+  return VCV_OK;
 }
