@@ -22,10 +22,25 @@ constexpr int WAPT = 16;  // un-shifted operand elements prefetched per thread p
 constexpr int WXPT = 16;  // shifted operand elements prefetched per thread per stage
 
 struct WgradGeom {
-  int NCH, ROWP, nmt, nnt, Z, nchunk_u, xw_log, napass, nxpass;
-  int xsync;  // 1: the shifted-operand spans exceed the prefetch registers -> staged synchronously
+  int NCH, nmt, nnt, Z, nchunk_u, xw_log, napass, nxpass, a_floats, x_floats;
+  int xsync;  // 1: shifted-operand spans exceed the prefetch registers -> staged synchronously
 };
 
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+__device__ __forceinline__ float apply_tf(float v, float av, int tf, float slope) {
+  if (tf == VCV_TF_LEAKY) return vcv_leaky(v, slope);
+  if (tf == VCV_TF_DLEAKY) return v * vcv_dleaky(av, slope);
+  if (tf == VCV_TF_DRELU) return av > 0.f ? v : 0.f;
+  if (tf == VCV_TF_DTANH) return v * (1.f - av * av);
+  if (tf == VCV_TF_DLOGCLAMP) return av > logf(slope) ? v * expf(-av) : 0.f;
+  return v;
+}
+
+// Staging reads are buffer loads whose descriptor range check zero-fills rows past the channel
+// count, positions past the sequence end and the convolution's zero padding.
 template <int TM, int TN, int WM, int WN, bool AAUX, bool BAUX>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
@@ -44,11 +59,11 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
   const int N = Cg * K;
   const int n0 = nt * BN, m0 = mt * BM;
   const int cfirst = n0 / K;
-  const int ROWP = tg.ROWP, NCH = tg.NCH;
+  const int XW = 1 << tg.xw_log;
 
-  float* As = smem;                    // [BU][BMP]
-  float* Xs = As + BU * BMP;           // [NCH][ROWP]
-  int* tab = (int*)(Xs + NCH * ROWP);  // [BU]
+  float* As = smem;                  // [BU][BMP] (+ overshoot rows)
+  float* Xs = As + tg.a_floats;      // [NCH][XW]
+  int* tab = (int*)(Xs + tg.x_floats);  // [BU]
 
   int nofs[TN];
 #pragma unroll
@@ -56,16 +71,18 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
     int n = n0 + (wn * TN + tn) * 32 + l31;
     if (n > N - 1) n = N - 1;
     const int c = n / K, kw = n - c * K;
-    nofs[tn] = (c - cfirst) * ROWP + kw * p.dj * P;
+    nofs[tn] = (c - cfirst) * XW + kw * p.dj * P;
   }
 
   const int jspan = (K - 1) * p.dj;
-  const int jmin = jspan < 0 ? jspan : 0, jmax = jspan > 0 ? jspan : 0;
+  const int jmin = jspan < 0 ? jspan : 0;
   const long long U = (long long)p.Ta * P;
   const long long TbP = (long long)p.Tb * P;
+  const unsigned urec = (unsigned)(U * 4), xrec = (unsigned)(TbP * 4);
   const int total = p.B * tg.nchunk_u;
-  const int xw = 1 << tg.xw_log;
   const int a_ul = tid & (BU - 1), a_row0 = tid / BU;
+  const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
+  const int nch_valid = Cg - cfirst;  // channels of this tile that exist
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -77,57 +94,50 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
 
   float areg[WAPT], aareg[AAUX ? WAPT : 1];
   float xreg[WXPT], xareg[BAUX ? WXPT : 1];
-  int cur_rowlen = 0, cur_tab = 0;
-  long long cur_f0 = 0;
-  size_t cur_xoff = 0;
+  int cur_tab = 0, cur_f0 = 0;
+  size_t cur_xbase = 0;
 
   auto load_chunk = [&](int ch) {
     const int b = ch / tg.nchunk_u;
     const int uc0 = (ch - b * tg.nchunk_u) * BU;
     const int qa = uc0 / P;
-    int qb = (uc0 + BU - 1) / P;
-    if (qb > p.Ta - 1) qb = p.Ta - 1;
     const int rlo = qa * p.s + p.off + jmin;
-    cur_rowlen = ((qb - qa) * p.s + (jmax - jmin) + 1) * P;
-    const long long f0 = (long long)rlo * P;
-    // un-shifted operand: rows m, positions uc0 + a_ul
+    const int f0 = rlo * P;
+    // un-shifted operand: one descriptor per row pass would cost SALU; rows are U floats apart, so a
+    // single descriptor over the rows_valid rows of this batch element + a position check suffices
+    const size_t abase = ((size_t)b * p.G * Mg + (size_t)g * Mg + m0) * (size_t)U;
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + abase), 0, (int)((unsigned)rows_valid * urec), 0x00020000);
+    __amdgpu_buffer_rsrc_t raa = ra;
+    if (AAUX) raa = __builtin_amdgcn_make_buffer_rsrc((void*)(p.aaux + abase), 0, (int)((unsigned)rows_valid * urec), 0x00020000);
     const long long u = (long long)uc0 + a_ul;
-    const float* ab = p.a + ((size_t)b * p.G * Mg + (size_t)g * Mg + m0) * (size_t)U;
-    const float* aab = AAUX ? p.aaux + ((size_t)b * p.G * Mg + (size_t)g * Mg + m0) * (size_t)U : nullptr;
+    const unsigned av0 = u < U ? ((unsigned)a_row0 * (unsigned)U + (unsigned)u) * 4u : 0xFFFFFFFFu;
+    const unsigned avstep = (unsigned)ARSTEP * (unsigned)U * 4u;
 #pragma unroll
-    for (int i = 0; i < WAPT; ++i) {
-      const int row = a_row0 + i * ARSTEP;
-      float v = 0.f, av = 0.f;
-      if (i < tg.napass && row < BM && m0 + row < Mg && u < U) {
-        const size_t gi = (size_t)row * (size_t)U + (size_t)u;
-        v = ab[gi];
-        if (AAUX) av = aab[gi];
+    for (int i = 0; i < WAPT; ++i)
+      if (i < tg.napass) {
+        const unsigned v = av0 == 0xFFFFFFFFu ? av0 : av0 + (unsigned)i * avstep;
+        areg[i] = ld_buf(ra, v);
+        if (AAUX) aareg[i] = ld_buf(raa, v);
       }
-      areg[i] = v;
-      if (AAUX) aareg[i] = av;
-    }
+    const size_t xbase = ((size_t)b * p.G * Cg + (size_t)g * Cg + cfirst) * (size_t)TbP;
     cur_f0 = f0;
-    cur_xoff = ((size_t)b * p.G * Cg + (size_t)g * Cg + cfirst) * (size_t)TbP;
-    const float* xb = p.b + cur_xoff;
-    const float* xab = BAUX ? p.baux + cur_xoff : nullptr;
-    if (!tg.xsync) {
+    cur_xbase = xbase;
+    if (!tg.xsync)
 #pragma unroll
-    for (int i = 0; i < WXPT; ++i) {
-      const int f = tid + i * NT;
-      const int cl = f >> tg.xw_log, col = f & (xw - 1);
-      float v = 0.f, av = 0.f;
-      if (i < tg.nxpass && cl < NCH && col < cur_rowlen && cfirst + cl < Cg) {
-        const long long ff = f0 + col;
-        if (ff >= 0 && ff < TbP) {
-          const size_t gi = (size_t)cl * (size_t)TbP + (size_t)ff;
-          v = xb[gi];
-          if (BAUX) av = xab[gi];
+    for (int i = 0; i < WXPT; ++i)
+      if (i < tg.nxpass) {
+        const int f = tid + i * NT;
+        const int cl = __builtin_amdgcn_readfirstlane(f >> tg.xw_log);
+        const int col = f & (XW - 1);
+        const unsigned rec = cl < nch_valid ? xrec : 0u;
+        const unsigned voff = (unsigned)(f0 + col) * 4u;
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + xbase + (size_t)cl * (size_t)TbP), 0, (int)rec, 0x00020000);
+        xreg[i] = ld_buf(rx, voff);
+        if (BAUX) {
+          __amdgpu_buffer_rsrc_t rxa = __builtin_amdgcn_make_buffer_rsrc((void*)(p.baux + xbase + (size_t)cl * (size_t)TbP), 0, (int)rec, 0x00020000);
+          xareg[i] = ld_buf(rxa, voff);
         }
       }
-      xreg[i] = v;
-      if (BAUX) xareg[i] = av;
-    }
-    }
     // LDS offset of this thread's position inside a staged span (threads < BU fill the table)
     int t = 0;
     const long long ut = (long long)uc0 + tid;
@@ -140,54 +150,25 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
 
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int i = 0; i < WAPT; ++i) {
-      const int row = a_row0 + i * ARSTEP;
-      if (i < tg.napass && row < BM) {
-        float v = areg[i];
-        if (p.a_tf == VCV_TF_LEAKY) v = vcv_leaky(v, p.slope);
-        if (AAUX) {
-          const float av = aareg[i];
-          if (p.a_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(av, p.slope);
-          else if (p.a_tf == VCV_TF_DRELU) v = av > 0.f ? v : 0.f;
-          else if (p.a_tf == VCV_TF_DTANH) v *= 1.f - av * av;
-          else if (p.a_tf == VCV_TF_DLOGCLAMP) v = av > logf(p.slope) ? v * expf(-av) : 0.f;
-        }
-        As[a_ul * BMP + row] = v;
-      }
-    }
+    for (int i = 0; i < WAPT; ++i)
+      if (i < tg.napass)
+        As[a_ul * BMP + a_row0 + i * ARSTEP] = apply_tf(areg[i], AAUX ? aareg[i] : 0.f, p.a_tf, p.slope);
     if (tg.xsync) {
-      // generic path for very wide spans (large period x stride): load + transform + store in one loop
-      const int nel = NCH << tg.xw_log;
+      const int nel = tg.NCH << tg.xw_log;
       for (int f = tid; f < nel; f += NT) {
-        const int cl = f >> tg.xw_log, col = f & (xw - 1);
-        if (col >= cur_rowlen) continue;
+        const int cl = f >> tg.xw_log, col = f & (XW - 1);
+        const long long ff = (long long)cur_f0 + col;
         float v = 0.f;
-        const long long ff = cur_f0 + col;
-        if (cfirst + cl < Cg && ff >= 0 && ff < TbP) {
-          const size_t gi = cur_xoff + (size_t)cl * (size_t)TbP + (size_t)ff;
+        if (cl < nch_valid && ff >= 0 && ff < TbP) {
+          const size_t gi = cur_xbase + (size_t)cl * (size_t)TbP + (size_t)ff;
           v = vcv_tf(p.b[gi], p.b_tf, p.baux, gi, p.slope);
         }
-        Xs[cl * ROWP + col] = v;
+        Xs[f] = v;
       }
-    } else {
+    } else
 #pragma unroll
-    for (int i = 0; i < WXPT; ++i) {
-      const int f = tid + i * NT;
-      const int cl = f >> tg.xw_log, col = f & (xw - 1);
-      if (i < tg.nxpass && cl < NCH && col < cur_rowlen) {
-        float v = xreg[i];
-        if (p.b_tf == VCV_TF_LEAKY) v = vcv_leaky(v, p.slope);
-        if (BAUX) {
-          const float av = xareg[i];
-          if (p.b_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(av, p.slope);
-          else if (p.b_tf == VCV_TF_DRELU) v = av > 0.f ? v : 0.f;
-          else if (p.b_tf == VCV_TF_DTANH) v *= 1.f - av * av;
-          else if (p.b_tf == VCV_TF_DLOGCLAMP) v = av > logf(p.slope) ? v * expf(-av) : 0.f;
-        }
-        Xs[cl * ROWP + col] = v;
-      }
-    }
-    }
+    for (int i = 0; i < WXPT; ++i)
+      if (i < tg.nxpass) Xs[tid + i * NT] = apply_tf(xreg[i], BAUX ? xareg[i] : 0.f, p.b_tf, p.slope);
     if (tid < BU) tab[tid] = cur_tab;
   };
 
@@ -260,13 +241,20 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   const int adj = a.dj < 0 ? -a.dj : a.dj;
   const int rowmax = (qspan * a.s + (a.K - 1) * adj + 1) * a.P;
   tg.xw_log = ilog2_ceil(rowmax);
-  tg.ROWP = rowmax | 1;  // odd pitch spreads the (channel, tap) columns of a B fragment over the banks
+  if (tg.xw_log < 6) tg.xw_log = 6;
+  // a power-of-two pitch would put the (channel, tap) columns of a B fragment on few LDS banks when
+  // K is a multiple of the bank period; the pitch stays 2^k (needed by the shift decode) and the
+  // conflicts that remain are paid in the LDS pipe, which has slack next to the 64-cycle MFMAs
   tg.napass = vcv_cdiv(BM * BU, NT);
   tg.nxpass = vcv_cdiv(tg.NCH << tg.xw_log, NT);
   if (tg.napass > WAPT) return VCV_ENOFIT;
   tg.xsync = tg.nxpass > WXPT ? 1 : 0;
   if (tg.xsync && !allow_sync) return VCV_ENOFIT;
+  const int arows = tg.napass * (NT / BU);  // rows the passes touch (>= BM)
+  tg.a_floats = BU * (BM + 1) + (arows > BM ? arows - BM : 0);
+  tg.x_floats = tg.nxpass * NT > (tg.NCH << tg.xw_log) ? tg.nxpass * NT : (tg.NCH << tg.xw_log);
   const long long U = (long long)a.Ta * a.P;
+  if (U * a.Mg * 4 >= (1ll << 31) || (long long)a.Tb * a.P * 4 >= (1ll << 31)) return VCV_EINVAL;
   tg.nchunk_u = (int)((U + BU - 1) / BU);
   const long long total = (long long)a.B * tg.nchunk_u;
   long long tiles = (long long)tg.nnt * tg.nmt * a.G;
@@ -274,7 +262,7 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   if (Z < 1) Z = 1;
   if (Z > total) Z = total;
   tg.Z = (int)Z;
-  const size_t lds = ((size_t)BU * (BM + 1) + (size_t)tg.NCH * tg.ROWP + BU) * sizeof(float);
+  const size_t lds = ((size_t)tg.a_floats + (size_t)tg.x_floats + BU) * sizeof(float);
   if (lds > VCV_LDS_LIMIT) return VCV_ENOFIT;
   const bool aaux = a.a_tf >= VCV_TF_DLEAKY, baux = a.b_tf >= VCV_TF_DLEAKY;
   if (aaux && baux) return VCV_EINVAL;
@@ -287,7 +275,7 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   }
   dim3 grid(tg.nnt, a.G * tg.nmt, tg.Z), block(NT);
   const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
-  const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, tg.Z, tg.xsync, BM * 1000 + BN, tg.NCH};
+  const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, tg.Z, 0, BM * 1000 + BN, tg.NCH};
   const int slot = vcv_prof_start(VCV_PROF_WGRAD, flops, st, tag, 12);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
   vcv_prof_stop(slot, st);
