@@ -1,0 +1,91 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vcvits_hip.h declares; the
+host-side mirror keeps the reference's import paths / names; there is no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vcvits_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vcv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vcvits_amd import _lib, build_ext
+    if not os.path.exists(_lib.LIB_PATH):
+        build_ext.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(L, name), "libvcvits_hip.so does not export %s" % name
+    assert sorted(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ set(declared)
+    assert b"gfx950" in _lib.lib().vcv_version()
+
+
+def test_no_cpu_fallback():
+    from vcvits_amd import ops
+    x = torch.randn(1, 4, 16)
+    w = torch.randn(4, 4, 3)
+    with pytest.raises(RuntimeError, match="not on the GPU"):
+        ops.conv1d(x, w, None, pad=1)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vcvits_amd")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dirpath, f)).read(), re.M):
+                bad.append(f)
+    assert not bad, bad
+
+
+def test_reference_import_paths():
+    import vits  # noqa: F401
+    from vits.hparams import HParams
+    from vits.light.vcvits import VCVITS
+    from vits.model.discriminators.multi_period_discriminator import MultiPeriodDiscriminator
+    from vits.model.synthesizers.synthesizer_svc import SynthesizerSVC, SynthesizerTrn
+    import vits.commons as commons
+    import vcvits_amd.commons
+    assert commons is vcvits_amd.commons
+    assert SynthesizerTrn is SynthesizerSVC
+    hp = HParams(a=1, b={"c": 2})
+    assert hp.b.c == 2 and dict(**hp.b) == {"c": 2} and "a" in hp
+    assert MultiPeriodDiscriminator().periods == [2, 3, 5, 7, 11, 17, 23, 37]
+    assert callable(VCVITS.training_step) and callable(VCVITS.on_load_checkpoint)
+
+
+def test_state_dict_surface_of_the_full_module():
+    from vcvits_amd import configs
+    from vcvits_amd.light.vcvits import VCVITS
+    cfg = configs.base()
+    cfg["model"].update({"inter_channels": 16, "hidden_channels": 16, "filter_channels": 32, "n_heads": 2,
+                         "upsample_initial_channel": 32, "hubert_channels": 24})
+    m = VCVITS(**cfg)
+    keys = set(m.state_dict().keys())
+    for k in ("net_g.enc_q.pre.weight", "net_g.enc_q.enc.in_layers.15.weight_v", "net_g.enc_q.enc.cond_layer.weight_g",
+              "net_g.flow.flows.6.post.bias", "net_g.enc_p.encoder.attn_layers.2.emb_rel_k",
+              "net_g.enc_p.encoder.norm_layers_2.0.gamma", "net_g.enc_p.hubert_proj.weight", "net_g.emb_g.weight",
+              "net_g.dec.ups.3.weight_g", "net_g.dec.resblocks.11.convs1.2.weight_v", "net_g.dec.conv_post.weight",
+              "net_period_d.discriminators.8.convs.4.weight_v", "net_scale_d.discriminators.4.conv_post.bias"):
+        assert k in keys, k
+    assert not any(".flows.1." in k or ".flows.3." in k for k in keys)  # odd flow indices are Flip
+    # base.json has no multi_period_discriminator_periods -> class default
+    assert len(m.net_period_d.discriminators) == 9
+    # zero-initialised flow `post` (modules.py:314-315)
+    assert float(m.net_g.flow.flows[0].post.weight.abs().sum()) == 0.0
+    # on_load_checkpoint: shape-mismatched tensors are replaced, unknown keys flagged, optimizer state dropped
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["net_g.emb_g.weight"] = torch.zeros(3, 3)
+    sd["extra.key"] = torch.zeros(1)
+    ck = {"state_dict": sd, "optimizer_states": [1]}
+    m.on_load_checkpoint(ck)
+    assert ck["state_dict"]["net_g.emb_g.weight"].shape == m.net_g.emb_g.weight.shape
+    assert "optimizer_states" not in ck
