@@ -114,6 +114,18 @@ typedef struct VcvWgradArgs {
 
 int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
 
+/* Thin convolutions (HBM-bound, no MFMA): a conv with ONE output channel (discriminator conv_post
+ * 1024->1, discriminator.py:25,61; generator conv_post 32->1 + tanh) and the weight gradient of a
+ * conv with one output or one input channel (conv_post / first layers, discriminator.py:18,53).
+ * x [B,C,Tin,P], w [1,C,K], y [B,1,Tout,P]; in_leaky / out_act as in vcv_conv_gemm.
+ * vcv_thin_wgrad: dw[m,c,k] += alpha * sum tf(a[b,m,q,p]) * tf(bsh[b,c,q*s+k*d+off,p]), K <= 16. */
+int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int Tin,
+                    int Tout, int P, int K, int stride, int dil, int pad, int in_leaky, int out_act,
+                    float slope, void* stream);
+int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const float* baux, float* dw, int B,
+                   int M, int C, int Ta, int Tb, int P, int K, int s, int d, int off, int a_tf, int b_tf,
+                   float slope, float alpha, void* stream);
+
 /* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites).  dy: [B, C, T] (T = Tout*P) */
 int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T,
                   int tf, float slope, void* stream);

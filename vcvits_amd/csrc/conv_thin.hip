@@ -1,0 +1,149 @@
+// conv_thin.hip -- convolutions with ONE output channel or ONE input channel per group.
+//
+// The discriminators end in Conv(1024 -> 1, k3) and start with Conv(1 -> 16/32) (reference:
+// discriminator.py:18,25,53,61), the generator ends in Conv(32 -> 1, k7) + tanh.
+// These are matrix-vector shaped and HBM-bound: padding them into 32-row MFMA tiles wastes the
+// matrix pipe and, worse, serialises a 3072-deep reduction inside a handful of workgroups.  Here:
+//   conv_m1_fwd   y[b,t,p] = act(bias + sum_{c,k} w[c,k] * tf(x[b,c,t*s+k*d-pad,p])): lanes along the
+//                 contiguous positions (coalesced row reads), the channel range split over the grid
+//                 and combined with fp32 atomics when it is deep;
+//   thin_wgrad    dw[m,c,k] for min(M,C) == 1: one workgroup per (m,c) weight row, lanes along the
+//                 positions, K accumulators per lane, wavefront-shuffle reduction.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wsum(float s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  return s;
+}
+
+constexpr int KMAX = 16;
+
+// grid: (position tiles of 256, B, channel splits)
+__global__ void __launch_bounds__(256)
+conv_m1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int C, int Tin, int Tout, int P, int K, int s, int d, int pad,
+                   int in_leaky, int out_act, float slope, int cper, int atomic) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const int c_lo = blockIdx.z * cper;
+  int c_hi = c_lo + cper;
+  if (c_hi > C) c_hi = C;
+  const int U = Tout * P;
+  if (u >= U) return;
+  const int t = u / P, pc = u - t * P;
+  const long long TinP = (long long)Tin * P;
+  const float* xb = x + (size_t)b * C * TinP;
+  float acc = 0.f;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const float* xr = xb + (size_t)c * TinP;
+    const float* wr = w + (size_t)c * K;
+    for (int k = 0; k < K; ++k) {
+      const int r = t * s + k * d - pad;
+      if (r >= 0 && r < Tin) {
+        float v = xr[(size_t)r * P + pc];
+        if (in_leaky) v = vcv_leaky(v, slope);
+        acc += wr[k] * v;
+      }
+    }
+  }
+  const size_t oi = (size_t)b * U + u;
+  if (atomic) {
+    unsafeAtomicAdd(y + oi, acc);
+  } else {
+    if (bias) acc += bias[0];
+    y[oi] = vcv_act(acc, out_act, slope);
+  }
+}
+
+__global__ void fill_bias_kernel(float* __restrict__ y, const float* __restrict__ bias, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = bias ? bias[0] : 0.f;
+}
+
+// one workgroup per weight row (m, c); a: [B, M, Ta, P] (un-shifted), bsh: [B, C, Tb, P] (shifted)
+__global__ void __launch_bounds__(256)
+thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, const float* __restrict__ aaux,
+                  const float* __restrict__ baux, float* __restrict__ dw, int B, int M, int C, int Ta, int Tb,
+                  int P, int K, int s, int d, int off, int a_tf, int b_tf, float slope, float alpha, int bper) {
+  __shared__ float red[4][KMAX];
+  const int m = blockIdx.x / C, c = blockIdx.x % C;
+  const long long U = (long long)Ta * P;
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  const int b_lo = blockIdx.y * bper;
+  int b_hi = b_lo + bper;
+  if (b_hi > B) b_hi = B;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const size_t abase = ((size_t)b * M + m) * (size_t)U;
+    const size_t bbase = ((size_t)b * C + c) * (size_t)Tb * P;
+    for (long long u = threadIdx.x; u < U; u += 256) {
+      float av = a[abase + u];
+      av = vcv_tf(av, a_tf, aaux, abase + u, slope);
+      const int q = (int)(u / P), pc = (int)(u - (long long)q * P);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const int r = q * s + k * d + off;
+          if (r >= 0 && r < Tb) {
+            const size_t bi = bbase + (size_t)r * P + pc;
+            acc[k] += av * vcv_tf(bsh[bi], b_tf, baux, bi, slope);
+          }
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const float v = wsum(acc[k]);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    unsafeAtomicAdd(dw + ((size_t)m * C + c) * K + k, alpha * (red[0][k] + red[1][k] + red[2][k] + red[3][k]));
+  }
+}
+
+}  // namespace
+
+extern "C" int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
+                               int Tin, int Tout, int P, int K, int stride, int dil, int pad, int in_leaky,
+                               int out_act, float slope, void* stream) {
+  if (!x || !w || !y || B <= 0 || C <= 0 || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || stride <= 0) return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int U = Tout * P;
+  const int nt = vcv_cdiv(U, 256);
+  // split the channel range until the grid has ~1000 workgroups
+  int splits = 1;
+  if (out_act == VCV_ACT_NONE) {
+    while (splits < 64 && (long long)nt * B * splits < 1024 && C / (splits * 2) >= 8) splits *= 2;
+  }
+  const int cper = vcv_cdiv(C, splits);
+  if (splits > 1) {
+    const size_t n = (size_t)B * U;
+    hipLaunchKernelGGL(fill_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, bias, n);
+  }
+  hipLaunchKernelGGL(conv_m1_fwd_kernel, dim3(nt, B, splits), dim3(256), 0, st, x, w, bias, y, C, Tin, Tout, P, K,
+                     stride, dil, pad, in_leaky, out_act, slope, cper, splits > 1 ? 1 : 0);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const float* baux, float* dw,
+                              int B, int M, int C, int Ta, int Tb, int P, int K, int s, int d, int off, int a_tf,
+                              int b_tf, float slope, float alpha, void* stream) {
+  if (!a || !bsh || !dw || B <= 0 || M <= 0 || C <= 0 || Ta <= 0 || Tb <= 0 || P <= 0 || K <= 0 || K > KMAX)
+    return VCV_EINVAL;
+  if ((a_tf >= VCV_TF_DLEAKY && !aaux) || (b_tf >= VCV_TF_DLEAKY && !baux)) return VCV_EINVAL;
+  int splits = 1;
+  while (splits < B && (long long)M * C * splits < 1024) splits *= 2;
+  if (splits > B) splits = B;
+  const int bper = vcv_cdiv(B, splits);
+  hipLaunchKernelGGL(thin_wgrad_kernel, dim3(M * C, vcv_cdiv(B, bper)), dim3(256), 0, (hipStream_t)stream, a, bsh, aaux,
+                     baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha, bper);
+  return vcv_check_launch();
+}

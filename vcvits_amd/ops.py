@@ -69,6 +69,16 @@ def conv_forward(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, out=None, **
     if out is None:
         shape = (B, M, Tout) if x.dim() == 3 else (B, M, Tout, P)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    plain = (all(kw.get(k) is None for k in ("res", "mask", "xaux", "oaux")) and not kw.get("accumulate", False)
+             and kw.get("out_tf", TF_NONE) == TF_NONE and kw.get("alpha", 1.0) == 1.0)
+    if (M == 1 and groups == 1 and C >= 16 and plain
+            and kw.get("in_tf", TF_NONE) in (TF_NONE, TF_LEAKY)
+            and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_TANH)):
+        # one output channel: HBM-bound matrix-vector kernel instead of a 32-row MFMA tile
+        check(lib().vcv_conv_m1_fwd(ptr(x), ptr(w), ptr(bias), ptr(out), B, C, Tin, Tout, P, K, stride, dil, pad,
+                                    1 if kw.get("in_tf", TF_NONE) == TF_LEAKY else 0, kw.get("out_act", ACT_NONE),
+                                    kw.get("slope", 0.1), stream()), "vcv_conv_m1_fwd")
+        return out
     a = VcvConvArgs()
     a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, groups, Cg, M // groups
@@ -111,6 +121,10 @@ def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=
     Cg, K = w_shape[1], w_shape[2]
     if out is None:
         out = torch.zeros(tuple(w_shape), device=dy.device, dtype=torch.float32)
+    if groups == 1 and min(M, C) == 1 and K <= 16:
+        check(lib().vcv_thin_wgrad(ptr(dy), ptr(x), ptr(aaux), ptr(baux), ptr(out), B, M, C, Tout, Tin, P, K, stride,
+                                   dil, -pad, a_tf, b_tf, slope, alpha, stream()), "vcv_thin_wgrad")
+        return out
     a = VcvWgradArgs()
     a.a, a.b, a.aaux, a.baux, a.dw = ptr(dy), ptr(x), ptr(aaux), ptr(baux), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, groups, Cg, M // groups
