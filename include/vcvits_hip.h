@@ -136,6 +136,9 @@ int vcv_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, i
 int vcv_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv,
                         float* dg, int R, int C, void* stream);
 
+/* wt[c, m, K-1-k] = w[m, c, k]: lets the stride-1 data gradient of a conv run as a forward conv */
+int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, void* stream);
+
 /* ---- streaming helpers ---- */
 /* y = (a + b + c) / 3 : mean of the three ResBlock1 branches of a HiFi-GAN stage */
 int vcv_avg3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);

@@ -177,6 +177,18 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
+// wt[c, m, K-1-k] = w[m, c, k]: the stride-1 data gradient of a conv is a forward conv with these weights
+__global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C,
+                                             int K, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = (int)(i % K);
+  const size_t cm = i / K;
+  const int m = (int)(cm % M);
+  const int c = (int)(cm / M);
+  wt[i] = w[((size_t)m * C + c) * K + (K - 1 - k)];
+}
+
 inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 }  // namespace
@@ -194,6 +206,13 @@ extern "C" int vcv_weight_norm_bwd(const float* dw, const float* v, const float*
                                    float* dv, float* dg, int R, int C, void* stream) {
   if (!dw || !v || !g || !norm || !dv || !dg || R <= 0 || C <= 0) return VCV_EINVAL;
   hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(R), dim3(256), 0, ST, dw, v, g, norm, dv, dg, C);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, void* stream) {
+  if (!w || !wt || M <= 0 || C <= 0 || K <= 0) return VCV_EINVAL;
+  const size_t n = (size_t)M * C * K;
+  hipLaunchKernelGGL(weight_flip_transpose_kernel, grid1d(n), dim3(256), 0, ST, w, wt, M, C, K, n);
   return vcv_check_launch();
 }
 

@@ -96,6 +96,19 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
     Cg, K = w.shape[1], w.shape[2]
     if out is None:
         out = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    if stride == 1 and groups == 1 and M >= 32 and C >= 32:
+        # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
+        # staging path (row-major weight rows) is the faster one
+        wt = torch.empty((C, M, K), device=dy.device, dtype=torch.float32)
+        check(lib().vcv_weight_flip_transpose(ptr(w), ptr(wt), M, C, K, stream()), "vcv_weight_flip_transpose")
+        a = VcvConvArgs()
+        a.x, a.w, a.y = ptr(dy), ptr(wt), ptr(out)
+        a.B, a.G, a.Cg, a.Mg = B, 1, M, C
+        a.Tin, a.Tout, a.P, a.K = Tout, Tin, P, K
+        a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = 1, dil, pad - (K - 1) * dil, 1, 0, 1, Tin, 0
+        _common(a, **kw)
+        _launch_conv(a)
+        return out
     a = VcvConvArgs()
     a.x, a.w, a.y = ptr(dy), ptr(w), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, groups, M // groups, Cg
