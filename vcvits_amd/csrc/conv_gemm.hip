@@ -26,7 +26,7 @@
 namespace {
 
 constexpr int VCV_ENOFIT = -100;  // internal: tile geometry exceeds the prefetch budget
-constexpr int APT = 16;  // max weight elements prefetched per thread per chunk
+constexpr int APT = 20;  // max weight elements prefetched per thread per chunk
 constexpr int XPT = 12;  // max input elements prefetched per thread per chunk
 
 // input-transform specialisations (template parameter INTF)
@@ -321,7 +321,7 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   if (tg.xw_log < 6) tg.xw_log = 6;
   const int xw = 1 << tg.xw_log;
   const int cg_even = (a.Cg + 1) & ~1;
-  const int min_cwl = ilog2_ceil(NT / BM);  // at least NT/BM columns so one pass never overshoots BM rows
+  const int min_cwl = ilog2_ceil(vcv_cdiv(NT, BM));  // at least NT/BM columns so one pass never overshoots BM rows
   // largest even channel chunk whose prefetch fits the per-thread register budget, <= ~64 (c,tap) rows
   int best = 0;
   for (int bkc = 2; bkc <= 64 && bkc <= cg_even; bkc += 2) {
@@ -330,11 +330,11 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
     if (a.a_mode == 0) {
       int cwl = ilog2_ceil(bkc * a.K);
       if (cwl < min_cwl) cwl = min_cwl;
-      if ((1 << cwl) > NT) break;
-      napass = (BM << cwl) / NT;
+      if ((1 << cwl) > NT || (NT % (1 << cwl)) != 0) break;
+      napass = vcv_cdiv(BM << cwl, NT);
     } else {
       const int jl = ilog2_ceil(tg.JMAX);
-      if ((1 << jl) > NT) break;
+      if ((1 << jl) > NT || (NT % (1 << jl)) != 0) break;
       napass = vcv_cdiv((bkc * BM) << jl, NT);
     }
     const int nxpass = vcv_cdiv(bkc * xw, NT);
@@ -346,8 +346,11 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   if (a.a_mode == 0) {
     tg.cw_log = ilog2_ceil(tg.BKC * a.K);
     if (tg.cw_log < min_cwl) tg.cw_log = min_cwl;
-    tg.napass = (BM << tg.cw_log) / NT;
-    tg.BMP = BM + 1;
+    tg.napass = vcv_cdiv(BM << tg.cw_log, NT);
+    // a pass may overshoot BM rows when NT is not a power of two: the pitch absorbs the overshoot
+    const int rows_touched = tg.napass * (NT >> tg.cw_log);
+    tg.BMP = (rows_touched > BM ? rows_touched : BM) + 1;
+    if ((tg.BMP & 1) == 0) tg.BMP += 1;
     tg.a_floats = tg.BKC * tg.JMAX * tg.BMP;
   } else {
     tg.cw_log = ilog2_ceil(tg.JMAX);
@@ -411,6 +414,13 @@ extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
     return (long long)a.B * vcv_cdiv(U, bn) * a.G * vcv_cdiv(a.Mg, bm) * phases >= 512;
   };
   int rc = VCV_ENOFIT;
+  // period-discriminator rows (160 < H*P <= 224 positions per batch element): one 7-wave tile covers a
+  // whole row (no second, mostly empty 128-wide tile) and amortises the weight staging over 224 columns
+  if (U > 160 && U <= 224 && a.Mg >= 64) {
+    if (a.Mg >= 128 && (long long)a.B * a.G * vcv_cdiv(a.Mg, 128) * phases >= 224) rc = launch_conv<4, 1, 1, 7>(a, st);
+    if (rc == VCV_ENOFIT) rc = launch_conv<2, 1, 1, 7>(a, st);
+    if (rc != VCV_ENOFIT) return rc;
+  }
   if (a.Mg > 64) {
     if (ok(128, 128)) rc = launch_conv<2, 2, 2, 2>(a, st);
     if (rc == VCV_ENOFIT && ok(128, 64)) rc = launch_conv<2, 1, 2, 2>(a, st);
