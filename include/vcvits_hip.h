@@ -126,6 +126,17 @@ int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const fl
                    int M, int C, int Ta, int Tb, int P, int K, int s, int d, int off, int a_tf, int b_tf,
                    float slope, float alpha, void* stream);
 
+/* Grouped k=41, stride 4, padding 20 convolutions with 4 input channels per group (DiscriminatorS
+ * layers 2-5, discriminator.py:55-58): direct fp32 FMA kernels (an MFMA tile would be mostly padding).
+ * x [B, G*4, Tin], w [G*Mg, 4, 41], y/dy [B, G*Mg, Tout], Mg in {4, 16}.  dtf / yaux: activation
+ * derivative applied to dy while staging (VCV_TF_DLEAKY with yaux = y).  wgrad accumulates into dw. */
+int vcv_grouped41_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg, int Tin,
+                      int Tout, int out_act, float slope, void* stream);
+int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg, int Tin,
+                        int Tout, int dtf, float slope, void* stream);
+int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg, int Tin,
+                        int Tout, int dtf, float slope, void* stream);
+
 /* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites).  dy: [B, C, T] (T = Tout*P) */
 int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T,
                   int tf, float slope, void* stream);

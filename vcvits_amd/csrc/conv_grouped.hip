@@ -1,0 +1,234 @@
+// conv_grouped.hip -- the grouped k=41 stride-4 convolutions of DiscriminatorS
+// (discriminator.py:55-58: 16->64 g4, 64->256 g16, 256->1024 g64, 1024->1024 g256; 4 input
+// channels per group, 16 or 4 output channels per group).
+//
+// With 4x(4|16) channels per group a 32x32 MFMA tile would be 75-88 % padding, so these run as
+// direct fp32 FMA kernels: a workgroup owns one (batch element, group, time tile); the group's
+// input span and its (tiny) weight block sit in LDS; each lane computes a few output times for
+// ALL channels of the group from 16-byte LDS reads (conflict-free x windows, broadcast weights).
+//   forward   y[b,g*Mg+m,t]   = act(bias + sum_{ci,k} w[g*Mg+m,ci,k] * x[b,g*4+ci,4t+k-20])
+//   dgrad     dx[b,g*4+ci,u]  = sum_{m,k == (u+20) mod 4} w[g*Mg+m,ci,k] * dye[b,g*Mg+m,(u+20-k)/4]
+//   wgrad     dw[g*Mg+m,ci,k] += sum_{b,t} dye[b,g*Mg+m,t] * x[b,g*4+ci,4t+k-20]
+// with dye = dy * leaky'(y) (the activation derivative is applied while staging).
+#include "common.h"
+
+namespace {
+
+constexpr int CG = 4, K = 41, S = 4, PAD = 20, KP = 44;  // taps padded to a multiple of 4
+
+// ---- forward: block = 256 lanes, TT = 256 output times, lane = one output time, all Mg outputs ----
+template <int MG>
+__global__ void __launch_bounds__(256)
+grouped_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int G, int Tin, int Tout, int act, float slope) {
+  constexpr int TT = 256;
+  constexpr int SPAN = S * TT + KP;  // input samples per channel needed by the tile
+  __shared__ __attribute__((aligned(16))) float xs[CG][SPAN];
+  __shared__ __attribute__((aligned(16))) float ws[CG][KP][MG];  // [ci][k][m]: m contiguous -> b128 broadcast reads
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
+  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+  const int in0 = t0 * S - PAD;
+  for (int i = tid; i < CG * SPAN; i += 256) {
+    const int ci = i / SPAN, j = i - ci * SPAN;
+    const int ti = in0 + j;
+    xs[ci][j] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+  }
+  for (int i = tid; i < CG * KP * MG; i += 256) {
+    const int m = i % MG, k = (i / MG) % KP, ci = i / (MG * KP);
+    ws[ci][k][m] = k < K ? w[((size_t)(g * MG + m) * CG + ci) * K + k] : 0.f;
+  }
+  __syncthreads();
+  float acc[MG];
+#pragma unroll
+  for (int m = 0; m < MG; ++m) acc[m] = 0.f;
+#pragma unroll 1
+  for (int ci = 0; ci < CG; ++ci) {
+#pragma unroll 1
+    for (int k4 = 0; k4 < KP; k4 += 4) {
+      const f32x4 xv = *(const f32x4*)&xs[ci][S * tid + k4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float xk = xv[kk];
+#pragma unroll
+        for (int m4 = 0; m4 < MG; m4 += 4) {
+          const f32x4 wv = *(const f32x4*)&ws[ci][k4 + kk][m4];
+          acc[m4 + 0] += wv[0] * xk; acc[m4 + 1] += wv[1] * xk;
+          acc[m4 + 2] += wv[2] * xk; acc[m4 + 3] += wv[3] * xk;
+        }
+      }
+    }
+  }
+  const int t = t0 + tid;
+  if (t < Tout) {
+#pragma unroll
+    for (int m = 0; m < MG; ++m) {
+      const int mg = g * MG + m;
+      float v = acc[m] + (bias ? bias[mg] : 0.f);
+      y[((size_t)b * G * MG + mg) * Tout + t] = vcv_act(v, act, slope);
+    }
+  }
+}
+
+// ---- dgrad: lane = one quad of input times u = 4q..4q+3 (the 4 residues), all 4 input channels ----
+// dx[ci][4q+r] = sum_m sum_j w[m][ci][r + 4j] * dye[m][q + 5 - j]   (j = 0..10; k = r+4j <= 40)
+template <int MG>
+__global__ void __launch_bounds__(256)
+grouped_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ w,
+                     float* __restrict__ dx, int G, int Tin, int Tout, int dtf, float slope) {
+  constexpr int QT = 256;        // quads per block -> 1024 input times
+  constexpr int DSPAN = QT + 12; // dy positions q-5 .. q+QT-1+5 (+ pad)
+  __shared__ float ds[MG][DSPAN];
+  __shared__ __attribute__((aligned(16))) float ws[MG][KP][CG];  // [m][k][ci]
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.x * QT, g = blockIdx.y, b = blockIdx.z;
+  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
+  for (int i = tid; i < MG * DSPAN; i += 256) {
+    const int m = i / DSPAN, j = i - m * DSPAN;
+    const int t = q0 - 5 + j;
+    float v = 0.f;
+    if (t >= 0 && t < Tout) {
+      const size_t gi = ybase + (size_t)m * Tout + t;
+      v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
+    }
+    ds[m][j] = v;
+  }
+  for (int i = tid; i < MG * KP * CG; i += 256) {
+    const int ci = i % CG, k = (i / CG) % KP, m = i / (CG * KP);
+    ws[m][k][ci] = k < K ? w[((size_t)(g * MG + m) * CG + ci) * K + k] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][CG];  // [r][ci]
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int ci = 0; ci < CG; ++ci) acc[r][ci] = 0.f;
+  // dy index for (q, j): t = q + 5 - j  -> ds column (q - q0) + 10 - j
+#pragma unroll 2
+  for (int m = 0; m < MG; ++m) {
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const float dv = ds[m][tid + 10 - j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 wv = *(const f32x4*)&ws[m][r + 4 * j][0];  // k = r + 4j (k > 40 rows are zero)
+        acc[r][0] += wv[0] * dv; acc[r][1] += wv[1] * dv; acc[r][2] += wv[2] * dv; acc[r][3] += wv[3] * dv;
+      }
+    }
+  }
+  // u + 20 = 4q' + r with q' = q + 5  ->  u = 4(q + 5) + r - 20 = 4q + r
+  const int q = q0 + tid;
+  float* dxb = dx + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+#pragma unroll
+  for (int ci = 0; ci < CG; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * q + r;
+      if (u < Tin) dxb[(size_t)ci * Tin + u] = acc[r][ci];
+    }
+}
+
+// ---- wgrad: block = (group, batch element, time chunk); lane = (m, ci, k4) owning 4 taps ----
+template <int MG>
+__global__ void __launch_bounds__(256)
+grouped_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ x,
+                     float* __restrict__ dw, int G, int Tin, int Tout, int dtf, float slope, int tchunk) {
+  constexpr int TT = 128;  // output times per stage
+  constexpr int SPAN = S * TT + KP;
+  constexpr int NOUT = MG * CG * (KP / 4);  // lanes with work: MG*4*11
+  __shared__ __attribute__((aligned(16))) float xs[CG][SPAN];
+  __shared__ float ds[MG][TT];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x, b = blockIdx.z;
+  const int tlo = blockIdx.y * tchunk;
+  int thi = tlo + tchunk;
+  if (thi > Tout) thi = Tout;
+  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
+  // each thread may own up to ceil(NOUT/256) (m, ci, k4) triples
+  constexpr int NOWN = (NOUT + 255) / 256;
+  float acc[NOWN][4];
+#pragma unroll
+  for (int o = 0; o < NOWN; ++o)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
+  for (int t0 = tlo; t0 < thi; t0 += TT) {
+    __syncthreads();
+    const int in0 = t0 * S - PAD;
+    for (int i = tid; i < CG * SPAN; i += 256) {
+      const int ci = i / SPAN, j = i - ci * SPAN;
+      const int ti = in0 + j;
+      xs[ci][j] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+    }
+    for (int i = tid; i < MG * TT; i += 256) {
+      const int m = i / TT, j = i - m * TT;
+      const int t = t0 + j;
+      float v = 0.f;
+      if (t < thi) {
+        const size_t gi = ybase + (size_t)m * Tout + t;
+        v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
+      }
+      ds[m][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+      const int id = tid + o * 256;
+      if (id < NOUT) {
+        const int k4 = (id % (KP / 4)) * 4, ci = (id / (KP / 4)) % CG, m = id / (CG * (KP / 4));
+#pragma unroll 4
+        for (int j = 0; j < TT; ++j) {
+          const float dv = ds[m][j];
+          const f32x4 xv = *(const f32x4*)&xs[ci][S * j + k4];
+          acc[o][0] += dv * xv[0]; acc[o][1] += dv * xv[1]; acc[o][2] += dv * xv[2]; acc[o][3] += dv * xv[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NOWN; ++o) {
+    const int id = tid + o * 256;
+    if (id < NOUT) {
+      const int k4 = (id % (KP / 4)) * 4, ci = (id / (KP / 4)) % CG, m = id / (CG * (KP / 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k4 + e < K) unsafeAtomicAdd(dw + ((size_t)(g * MG + m) * CG + ci) * K + k4 + e, acc[o][e]);
+    }
+  }
+}
+
+}  // namespace
+
+// x [B, G*4, Tin], w [G*Mg, 4, 41], y [B, G*Mg, Tout], Tout = (Tin + 40 - 41)/4 + 1; Mg in {4, 16}
+extern "C" int vcv_grouped41_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg,
+                                 int Tin, int Tout, int out_act, float slope, void* stream) {
+  if (!x || !w || !y || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
+  dim3 grid(vcv_cdiv(Tout, 256), G, B);
+  if (Mg == 16) hipLaunchKernelGGL(grouped_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
+  else hipLaunchKernelGGL(grouped_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg,
+                                   int Tin, int Tout, int dtf, float slope, void* stream) {
+  if (!dy || !w || !dx || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
+  if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
+  dim3 grid(vcv_cdiv(vcv_cdiv(Tin, 4), 256), G, B);
+  if (Mg == 16) hipLaunchKernelGGL(grouped_dgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
+  else hipLaunchKernelGGL(grouped_dgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
+                                   int Tin, int Tout, int dtf, float slope, void* stream) {
+  if (!dy || !x || !dw || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
+  if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
+  // time chunks so that the grid has >= ~1000 workgroups
+  int nchunk = 1;
+  while ((long long)G * B * nchunk < 1024 && Tout / (nchunk * 2) >= 128) nchunk *= 2;
+  const int tchunk = vcv_cdiv(vcv_cdiv(Tout, nchunk), 128) * 128;
+  dim3 grid(G, vcv_cdiv(Tout, tchunk), B);
+  if (Mg == 16) hipLaunchKernelGGL(grouped_wgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk);
+  else hipLaunchKernelGGL(grouped_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk);
+  return vcv_check_launch();
+}

@@ -71,6 +71,12 @@ def conv_forward(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, out=None, **
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     plain = (all(kw.get(k) is None for k in ("res", "mask", "xaux", "oaux")) and not kw.get("accumulate", False)
              and kw.get("out_tf", TF_NONE) == TF_NONE and kw.get("alpha", 1.0) == 1.0)
+    if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
+            and M // groups in (4, 16) and plain and kw.get("in_tf", TF_NONE) == TF_NONE
+            and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_LEAKY)):
+        check(lib().vcv_grouped41_fwd(ptr(x), ptr(w), ptr(bias), ptr(out), B, groups, M // groups, Tin, Tout,
+                                      kw.get("out_act", ACT_NONE), kw.get("slope", 0.1), stream()), "vcv_grouped41_fwd")
+        return out
     if (M == 1 and groups == 1 and C >= 16 and plain
             and kw.get("in_tf", TF_NONE) in (TF_NONE, TF_LEAKY)
             and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_TANH)):
@@ -96,6 +102,13 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
     Cg, K = w.shape[1], w.shape[2]
     if out is None:
         out = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
+            and M // groups in (4, 16) and set(kw) <= {"in_tf", "xaux", "slope"}
+            and kw.get("in_tf", TF_NONE) in (TF_NONE, TF_DLEAKY)):
+        check(lib().vcv_grouped41_dgrad(ptr(dy), ptr(kw.get("xaux")), ptr(w), ptr(out), B, groups, M // groups, Tin,
+                                        Tout, kw.get("in_tf", TF_NONE), kw.get("slope", 0.1), stream()),
+              "vcv_grouped41_dgrad")
+        return out
     if stride == 1 and groups == 1 and M >= 32 and C >= 32:
         # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
         # staging path (row-major weight rows) is the faster one
@@ -134,6 +147,11 @@ def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=
     Cg, K = w_shape[1], w_shape[2]
     if out is None:
         out = torch.zeros(tuple(w_shape), device=dy.device, dtype=torch.float32)
+    if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
+            and M // groups in (4, 16) and b_tf == TF_NONE and a_tf in (TF_NONE, TF_DLEAKY) and alpha == 1.0):
+        check(lib().vcv_grouped41_wgrad(ptr(dy), ptr(aaux), ptr(x), ptr(out), B, groups, M // groups, Tin, Tout, a_tf,
+                                        slope, stream()), "vcv_grouped41_wgrad")
+        return out
     if groups == 1 and min(M, C) == 1 and K <= 16:
         check(lib().vcv_thin_wgrad(ptr(dy), ptr(x), ptr(aaux), ptr(baux), ptr(out), B, M, C, Tout, Tin, P, K, stride,
                                    dil, -pad, a_tf, b_tf, slope, alpha, stream()), "vcv_thin_wgrad")
