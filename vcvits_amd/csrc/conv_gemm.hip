@@ -27,7 +27,8 @@ namespace {
 
 constexpr int VCV_ENOFIT = -100;  // internal: tile geometry exceeds the prefetch budget
 constexpr int APT = 20;  // max weight elements prefetched per thread per chunk
-constexpr int XPT = 12;  // max input elements prefetched per thread per chunk
+constexpr int XPT_DEFAULT = 12;  // max input elements prefetched per thread per chunk
+constexpr int XPT_WIDE = 24;     // ... for the 7-wave tiles (small accumulator footprint, wide strided spans)
 
 // input-transform specialisations (template parameter INTF)
 constexpr int INTF_NONE = 0, INTF_LEAKY = 1, INTF_DLEAKY = 2, INTF_AUX = 3;
@@ -59,6 +60,7 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
   constexpr int BM_LOG = (BM == 128) ? 7 : (BM == 64 ? 6 : 5);
   constexpr bool XAUX = INTF >= INTF_DLEAKY;
+  constexpr int XPT = (WN == 7) ? XPT_WIDE : XPT_DEFAULT;
   extern __shared__ float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,6 +313,7 @@ inline int ilog2_ceil(int v) {
 template <int TM, int TN, int WM, int WN>
 int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+  constexpr int XPT = (WN == 7) ? XPT_WIDE : XPT_DEFAULT;
   TileGeom tg;
   const int phases = a.phases > 1 ? a.phases : 1;
   tg.JMAX = phases > 1 ? vcv_cdiv(a.K, phases) : a.K;

@@ -19,7 +19,7 @@ namespace {
 constexpr int VCV_ENOFIT = -100;
 constexpr int BU = 32;    // positions per stage (power of two)
 constexpr int WAPT = 16;  // un-shifted operand elements prefetched per thread per stage
-constexpr int WXPT = 16;  // shifted operand elements prefetched per thread per stage
+constexpr int WXPT = 28;  // shifted operand elements prefetched per thread per stage
 
 struct WgradGeom {
   int NCH, nmt, nnt, Z, nchunk_u, xw_log, napass, nxpass, a_floats, x_floats;
