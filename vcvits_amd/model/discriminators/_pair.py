@@ -4,8 +4,9 @@ The reference runs d(y) then d(y_hat) as two passes per discriminator
 (multi_period_discriminator.py:22-28).  When the discriminator weights take gradients (D step)
 both signals share every weight, so they are stacked into ONE batch of 2B: each conv, and each
 weight-gradient reduction, is a single launch over both.  When the weights are frozen (G step,
-Lightning-1.x toggle_optimizer semantics) the real branch needs no graph at all and is run under
-no_grad, so its data-gradient work is never issued."""
+Lightning-1.x toggle_optimizer semantics) the two signals are stacked as well, and the backward of
+every conv is restricted to the generated half (`ops.grad_batch_start`), so no data-gradient work is
+issued for the real branch."""
 import torch
 
 
@@ -15,7 +16,9 @@ def run_pair(disc, y, y_hat):
     if wants_wgrad or not (y_hat.requires_grad and torch.is_grad_enabled()):
         out, fmap = disc(torch.cat([y, y_hat], dim=0))
         return out[:B], out[B:], [f[:B] for f in fmap], [f[B:] for f in fmap]
-    with torch.no_grad():
-        y_d_r, fmap_r = disc(y)
-    y_d_g, fmap_g = disc(y_hat)
-    return y_d_r, y_d_g, fmap_r, fmap_g
+    # frozen weights, gradient wanted for y_hat only: still ONE stacked forward pass (wider GEMM tiles,
+    # half the launches, weight norm computed once); the backward is told to skip the real half
+    from ... import ops
+    with ops.grad_batch_start(B):
+        out, fmap = disc(torch.cat([y.detach(), y_hat], dim=0))
+    return out[:B].detach(), out[B:], [f[:B].detach() for f in fmap], [f[B:] for f in fmap]

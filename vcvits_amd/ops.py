@@ -240,6 +240,28 @@ def bias_grad(dy, aux=None, tf=TF_NONE, slope=0.1):
 # ---------------------------------------------------------------------------------------------
 # autograd
 # ---------------------------------------------------------------------------------------------
+_GRAD_B0 = [0]
+
+
+class grad_batch_start:
+    """Context: convolutions recorded inside only need data gradients for batch elements >= b0 (the
+    leading b0 elements are inputs without gradient, e.g. the real waveforms stacked in front of the
+    generated ones in the generator step).  Their backward then launches the data-gradient kernels
+    on the trailing sub-batch only; the leading part of the returned gradient is unspecified."""
+
+    def __init__(self, b0):
+        self.b0 = int(b0)
+
+    def __enter__(self):
+        self.prev = _GRAD_B0[0]
+        _GRAD_B0[0] = self.b0
+        return self
+
+    def __exit__(self, *exc):
+        _GRAD_B0[0] = self.prev
+        return False
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(in_act(x), w) + bias) + res      (act and res are mutually exclusive)."""
 
@@ -258,6 +280,7 @@ class _ConvFn(torch.autograd.Function):
             y = conv_forward(x, w3, stride=stride, pad=pad, dil=dil, groups=groups, **kw)
         ctx.cfg = (stride, pad, dil, groups, in_leaky, out_act, slope, transposed)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        ctx.b0 = _GRAD_B0[0] if not (w.requires_grad or (bias is not None and bias.requires_grad)) else 0
         ctx.save_for_backward(x, w, y if out_act != ACT_NONE else None)
         return y
 
@@ -270,13 +293,17 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = dres = None
         w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
         if ctx.needs_input_grad[0]:
-            kw = dict(in_tf=dtf, xaux=y, slope=slope)
+            b0 = ctx.b0 if 0 < ctx.b0 < x.shape[0] else 0
+            dys, ys, xs = (dy[b0:], (y[b0:] if y is not None else None), x[b0:]) if b0 else (dy, y, x)
+            kw = dict(in_tf=dtf, xaux=ys, slope=slope)
             if in_leaky:
-                kw.update(out_tf=TF_DLEAKY, oaux=x)
+                kw.update(out_tf=TF_DLEAKY, oaux=xs)
+            dx = torch.empty_like(x)
+            dxs = dx[b0:] if b0 else dx
             if transposed:
-                dx = convT_dgrad(dy, w3, x.shape, stride=stride, pad=pad, **kw)
+                convT_dgrad(dys, w3, xs.shape, stride=stride, pad=pad, out=dxs, **kw)
             else:
-                dx = conv_dgrad(dy, w3, x.shape, stride=stride, pad=pad, dil=dil, groups=groups, **kw)
+                conv_dgrad(dys, w3, xs.shape, stride=stride, pad=pad, dil=dil, groups=groups, out=dxs, **kw)
         if ctx.needs_input_grad[1]:
             b_tf = TF_LEAKY if in_leaky else TF_NONE
             if transposed:
