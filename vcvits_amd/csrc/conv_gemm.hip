@@ -47,24 +47,8 @@ struct TileGeom {
   int xsync;     // 1: spans too wide for the prefetch registers -> staged synchronously (rare: stride >= 8)
 };
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// buffer descriptor from wave-uniform values (word 3 = raw 32-bit data format, as T8 of the guide)
-__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)ptr;
-  i32x4 r;
-  r.x = (int)(a & 0xffffffffull);
-  r.y = (int)((a >> 32) & 0xffffull);
-  r.z = (int)bytes;
-  r.w = 0x00020000;
-  return r;
-}
-
-// Prefetch load hidden from hipcc's waitcnt bookkeeping: the compiler otherwise drains vmcnt(0) in
-// front of the MFMA loop and the global latency is no longer overlapped with the matrix pipe.  The
-// destination is valid only after wait_prefetch() (guide section 5.7, item 1, form (ii)).
-__device__ __forceinline__ void ld_async(float& dst, i32x4 rsrc, unsigned voff) {
-  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
 }
 
 // Every global read of the staging path is a buffer load: the descriptor's range check returns 0
@@ -167,15 +151,15 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
     if (p.a_mode == 0) {
       const float* base = p.w + (size_t)(g * Mg + m0) * rowpitch + (size_t)c0 * K;
       const long long rem = (long long)rows_valid * rowpitch - (long long)c0 * K;
-      const i32x4 ra = make_rsrc(base, (unsigned)(rem > 0 ? rem * 4 : 0));
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rem > 0 ? rem * 4 : 0), 0x00020000);
       const unsigned v0 = (c0 + a_cl < Cg) ? a_voff : 0xFFFFFFFFu;
 #pragma unroll
       for (int i = 0; i < APT; ++i)
-        if (i < tg.napass) ld_async(areg[i], ra, v0 == 0xFFFFFFFFu ? v0 : v0 + (unsigned)i * a_vstep);
+        if (i < tg.napass) areg[i] = ld_buf(ra, v0 == 0xFFFFFFFFu ? v0 : v0 + (unsigned)i * a_vstep);
     } else {
       const float* base = p.w + ((size_t)(g * Cg + c0) * Mg + m0) * K;
       const long long rem = ((long long)(Cg - c0) * Mg - m0) * K;
-      const i32x4 ra = make_rsrc(base, (unsigned)(rem > 0 ? rem * 4 : 0));
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rem > 0 ? rem * 4 : 0), 0x00020000);
 #pragma unroll
       for (int i = 0; i < APT; ++i)
         if (i < tg.napass) {
@@ -183,7 +167,7 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
           const int cl = f >> BM_LOG, ml = f & (BM - 1);
           unsigned v = ((unsigned)(cl * Mg + ml) * (unsigned)K + (unsigned)a_kw) * 4u;
           if (a_lds < 0 || (mtail && ml >= rows_valid)) v = 0xFFFFFFFFu;
-          ld_async(areg[i], ra, v);
+          areg[i] = ld_buf(ra, v);
         }
     }
     cur_c0 = c0;
@@ -197,26 +181,16 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
         const size_t rowbase = xbase_b + (size_t)(c0 + cl) * (size_t)TinP;
         const unsigned rec = (c0 + cl < Cg) ? xrec : 0u;
         const unsigned voff = (unsigned)(f0 + col) * 4u;  // negative positions wrap -> out of range -> 0
-        ld_async(xreg[i], make_rsrc(p.x + rowbase, rec), voff);
-        if (XAUX) ld_async(xareg[i], make_rsrc(p.xaux + rowbase, rec), voff);
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + rowbase), 0, (int)rec, 0x00020000);
+        xreg[i] = ld_buf(rx, voff);
+        if (XAUX) {
+          __amdgpu_buffer_rsrc_t rxa = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xaux + rowbase), 0, (int)rec, 0x00020000);
+          xareg[i] = ld_buf(rxa, voff);
+        }
       }
   };
 
-  // drain the hidden prefetch and make every destination opaque so no consumer is scheduled above it
-  auto wait_prefetch = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < APT; ++i) asm volatile("" : "+v"(areg[i]));
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) asm volatile("" : "+v"(xreg[i]));
-    if (XAUX) {
-#pragma unroll
-      for (int i = 0; i < XPT; ++i) asm volatile("" : "+v"(xareg[i]));
-    }
-  };
-
   auto store_chunk = [&]() {
-    wait_prefetch();
     if (a_lds >= 0) {
       if (p.a_mode == 0) {
 #pragma unroll

@@ -23,6 +23,8 @@ constexpr int WXPT = 28;  // shifted operand elements prefetched per thread per 
 
 struct WgradGeom {
   int NCH, nmt, nnt, Z, nchunk_u, xw_log, napass, nxpass, a_floats, x_floats;
+  int xpitch;  // LDS pitch of one staged channel span: 2^xw_log + skew, == K*dj*P (mod 32) so that the
+               // (channel, tap) columns of one B fragment fall on distinct banks
   int xsync;  // 1: shifted-operand spans exceed the prefetch registers -> staged synchronously
 };
 
@@ -71,7 +73,7 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
     int n = n0 + (wn * TN + tn) * 32 + l31;
     if (n > N - 1) n = N - 1;
     const int c = n / K, kw = n - c * K;
-    nofs[tn] = (c - cfirst) * XW + kw * p.dj * P;
+    nofs[tn] = (c - cfirst) * tg.xpitch + kw * p.dj * P;
   }
 
   const int jspan = (K - 1) * p.dj;
@@ -163,12 +165,15 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
           const size_t gi = cur_xbase + (size_t)cl * (size_t)TbP + (size_t)ff;
           v = vcv_tf(p.b[gi], p.b_tf, p.baux, gi, p.slope);
         }
-        Xs[f] = v;
+        Xs[cl * tg.xpitch + col] = v;
       }
     } else
 #pragma unroll
     for (int i = 0; i < WXPT; ++i)
-      if (i < tg.nxpass) Xs[tid + i * NT] = apply_tf(xreg[i], BAUX ? xareg[i] : 0.f, p.b_tf, p.slope);
+      if (i < tg.nxpass) {
+        const int f = tid + i * NT;
+        Xs[(f >> tg.xw_log) * tg.xpitch + (f & (XW - 1))] = apply_tf(xreg[i], BAUX ? xareg[i] : 0.f, p.b_tf, p.slope);
+      }
     if (tid < BU) tab[tid] = cur_tab;
   };
 
@@ -252,7 +257,12 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   if (tg.xsync && !allow_sync) return VCV_ENOFIT;
   const int arows = tg.napass * (NT / BU);  // rows the passes touch (>= BM)
   tg.a_floats = BU * (BM + 1) + (arows > BM ? arows - BM : 0);
-  tg.x_floats = tg.nxpass * NT > (tg.NCH << tg.xw_log) ? tg.nxpass * NT : (tg.NCH << tg.xw_log);
+  {
+    int skew = ((a.K * adj * a.P) % 32 + 32 - ((1 << tg.xw_log) % 32)) % 32;
+    tg.xpitch = (1 << tg.xw_log) + skew;
+  }
+  const int xrows = vcv_cdiv(tg.nxpass * NT, 1 << tg.xw_log) > tg.NCH ? vcv_cdiv(tg.nxpass * NT, 1 << tg.xw_log) : tg.NCH;
+  tg.x_floats = xrows * tg.xpitch;
   const long long U = (long long)a.Ta * a.P;
   if (U * a.Mg * 4 >= (1ll << 31) || (long long)a.Tb * a.P * 4 >= (1ll << 31)) return VCV_EINVAL;
   tg.nchunk_u = (int)((U + BU - 1) / BU);
