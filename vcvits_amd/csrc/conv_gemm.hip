@@ -60,7 +60,7 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
   constexpr int BM_LOG = (BM == 128) ? 7 : (BM == 64 ? 6 : 5);
   constexpr bool XAUX = INTF >= INTF_DLEAKY;
-  constexpr int XPT = (WN == 7) ? (XAUX ? 16 : XPT_WIDE) : XPT_DEFAULT;
+  constexpr int XPT = (WN == 7 || TN * WN >= 8) ? (XAUX ? 16 : XPT_WIDE) : XPT_DEFAULT;
   extern __shared__ float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -313,7 +313,7 @@ inline int ilog2_ceil(int v) {
 template <int TM, int TN, int WM, int WN>
 int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
-  const int XPT = (WN == 7) ? (a.in_tf >= VCV_TF_DLEAKY ? 16 : XPT_WIDE) : XPT_DEFAULT;
+  const int XPT = (WN == 7 || TN * WN >= 8) ? (a.in_tf >= VCV_TF_DLEAKY ? 16 : XPT_WIDE) : XPT_DEFAULT;
   TileGeom tg;
   const int phases = a.phases > 1 ? a.phases : 1;
   tg.JMAX = phases > 1 ? vcv_cdiv(a.K, phases) : a.K;
@@ -432,12 +432,15 @@ extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
     return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
   }
   if (a.Mg > 32) {
-    if (ok(64, 128)) rc = launch_conv<1, 2, 2, 2>(a, st);
+    // long sequences: 64 x 256 tile (2x2 accumulators per wave like the 128 x 128 tile)
+    if (ok(64, 256)) rc = launch_conv<2, 2, 1, 4>(a, st);
+    if (rc == VCV_ENOFIT && ok(64, 128)) rc = launch_conv<1, 2, 2, 2>(a, st);
     if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st);
     if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st, true);
     return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
   }
-  if (ok(32, 256)) rc = launch_conv<1, 2, 1, 4>(a, st);
+  if (ok(32, 512)) rc = launch_conv<1, 4, 1, 4>(a, st);
+  if (rc == VCV_ENOFIT && ok(32, 256)) rc = launch_conv<1, 2, 1, 4>(a, st);
   if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 4>(a, st);
   if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 2>(a, st);
   if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 2>(a, st, true);
