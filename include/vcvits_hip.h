@@ -150,6 +150,10 @@ int vcv_weight_norm_bwd(const float* dw, const float* v, const float* g, const f
 /* wt[c, m, K-1-k] = w[m, c, k]: lets the stride-1 data gradient of a conv run as a forward conv */
 int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, void* stream);
 
+/* out = dy * act'(y) for tf in {DLEAKY, DRELU, DTANH, DLOGCLAMP}: one pass that the data-, weight- and
+ * bias-gradient kernels of a fused conv+activation then share */
+int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream);
+
 /* ---- streaming helpers ---- */
 /* y = (a + b + c) / 3 : mean of the three ResBlock1 branches of a HiFi-GAN stage */
 int vcv_avg3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);

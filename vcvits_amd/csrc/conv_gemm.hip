@@ -411,10 +411,11 @@ extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
   const int phases = a.phases > 1 ? a.phases : 1;
   // tile choice: widest tile that still leaves >= ~2 workgroups per CU and is not mostly padding;
   // a tile whose staging does not fit the per-thread prefetch budget falls through to a narrower one
+  const long long min_blocks = 512;
   auto ok = [&](int bm, int bn) {
     const int u32 = vcv_cdiv(U, 32) * 32;
     if (bn >= 2 * u32) return false;
-    return (long long)a.B * vcv_cdiv(U, bn) * a.G * vcv_cdiv(a.Mg, bm) * phases >= 512;
+    return (long long)a.B * vcv_cdiv(U, bn) * a.G * vcv_cdiv(a.Mg, bm) * phases >= min_blocks;
   };
   int rc = VCV_ENOFIT;
   // period-discriminator rows (160 < H*P <= 224 positions per batch element): one 7-wave tile covers a

@@ -68,6 +68,14 @@ __global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y,
   if (i < n) y[i] = alpha * x[i];
 }
 
+// out = dy * act'(y): the activation-derivative mask of a fused conv+activation, applied once so the data
+// gradient, weight gradient and bias gradient kernels all stream the same pre-masked tensor
+__global__ void act_grad_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                                int tf, float slope, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vcv_tf(dy[i], tf, y, i, slope);
+}
+
 // y[b, c, t] = x[b, c, t] * mask[b, t]
 __global__ void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                 float* __restrict__ y, int C, int T, size_t n) {
@@ -213,6 +221,12 @@ extern "C" int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C
   if (!w || !wt || M <= 0 || C <= 0 || K <= 0) return VCV_EINVAL;
   const size_t n = (size_t)M * C * K;
   hipLaunchKernelGGL(weight_flip_transpose_kernel, grid1d(n), dim3(256), 0, ST, w, wt, M, C, K, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream) {
+  if (!dy || !y || !out || n <= 0 || tf < VCV_TF_DLEAKY) return VCV_EINVAL;
+  hipLaunchKernelGGL(act_grad_kernel, grid1d(n), dim3(256), 0, ST, dy, y, out, tf, slope, (size_t)n);
   return vcv_check_launch();
 }
 

@@ -292,6 +292,13 @@ class _ConvFn(torch.autograd.Function):
         dtf = _ACT_TO_DTF[out_act]
         dx = dw = db = dres = None
         w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
+        if dtf != TF_NONE:
+            # apply the activation-derivative mask once; dgrad / wgrad / bias-grad then stream dye
+            b0 = ctx.b0 if (0 < ctx.b0 < x.shape[0] and not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])) else 0
+            dye = torch.empty_like(dy)
+            check(lib().vcv_act_grad(ptr(dy[b0:]), ptr(y[b0:]), ptr(dye[b0:]), dtf, slope, dy[b0:].numel(), stream()),
+                  "vcv_act_grad")
+            dy, y, dtf = dye, None, TF_NONE
         if ctx.needs_input_grad[0]:
             b0 = ctx.b0 if 0 < ctx.b0 < x.shape[0] else 0
             dys, ys, xs = (dy[b0:], (y[b0:] if y is not None else None), x[b0:]) if b0 else (dy, y, x)
