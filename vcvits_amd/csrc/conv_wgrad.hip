@@ -17,8 +17,8 @@
 namespace {
 
 constexpr int VCV_ENOFIT = -100;
-constexpr int BU = 32;    // positions per stage (power of two)
-constexpr int WAPT = 16;  // un-shifted operand elements prefetched per thread per stage
+// positions per stage: 64 for plain sequences (P == 1), 32 for period layouts whose spans are row-wide
+constexpr int WAPT = 32;  // un-shifted operand elements prefetched per thread per stage
 constexpr int WXPT = 28;  // shifted operand elements prefetched per thread per stage
 
 struct WgradGeom {
@@ -43,12 +43,13 @@ __device__ __forceinline__ float apply_tf(float v, float av, int tf, float slope
 
 // Staging reads are buffer loads whose descriptor range check zero-fills rows past the channel
 // count, positions past the sequence end and the convolution's zero padding.
-template <int TM, int TN, int WM, int WN, bool AAUX, bool BAUX>
+template <int TM, int TN, int WM, int WN, bool AAUX, bool BAUX, int BU>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
   constexpr int BMP = BM + 1;
   constexpr int ARSTEP = NT / BU;
+  constexpr int NAP = (BM * BU) / NT;  // un-shifted operand elements per thread per stage (exact)
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -94,7 +95,7 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
 
-  float areg[WAPT], aareg[AAUX ? WAPT : 1];
+  float areg[NAP], aareg[AAUX ? NAP : 1];
   float xreg[WXPT], xareg[BAUX ? WXPT : 1];
   int cur_tab = 0, cur_f0 = 0;
   size_t cur_xbase = 0;
@@ -115,12 +116,11 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
     const unsigned av0 = u < U ? ((unsigned)a_row0 * (unsigned)U + (unsigned)u) * 4u : 0xFFFFFFFFu;
     const unsigned avstep = (unsigned)ARSTEP * (unsigned)U * 4u;
 #pragma unroll
-    for (int i = 0; i < WAPT; ++i)
-      if (i < tg.napass) {
-        const unsigned v = av0 == 0xFFFFFFFFu ? av0 : av0 + (unsigned)i * avstep;
-        areg[i] = ld_buf(ra, v);
-        if (AAUX) aareg[i] = ld_buf(raa, v);
-      }
+    for (int i = 0; i < NAP; ++i) {
+      const unsigned v = av0 == 0xFFFFFFFFu ? av0 : av0 + (unsigned)i * avstep;
+      areg[i] = ld_buf(ra, v);
+      if (AAUX) aareg[i] = ld_buf(raa, v);
+    }
     const size_t xbase = ((size_t)b * p.G * Cg + (size_t)g * Cg + cfirst) * (size_t)TbP;
     cur_f0 = f0;
     cur_xbase = xbase;
@@ -152,9 +152,8 @@ conv_wgrad_kernel(const VcvWgradArgs p, const WgradGeom tg) {
 
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int i = 0; i < WAPT; ++i)
-      if (i < tg.napass)
-        As[a_ul * BMP + a_row0 + i * ARSTEP] = apply_tf(areg[i], AAUX ? aareg[i] : 0.f, p.a_tf, p.slope);
+    for (int i = 0; i < NAP; ++i)
+      As[a_ul * BMP + a_row0 + i * ARSTEP] = apply_tf(areg[i], AAUX ? aareg[i] : 0.f, p.a_tf, p.slope);
     if (tg.xsync) {
       const int nel = tg.NCH << tg.xw_log;
       for (int f = tid; f < nel; f += NT) {
@@ -233,8 +232,8 @@ inline int ilog2_ceil(int v) {
   return l;
 }
 
-template <int TM, int TN, int WM, int WN>
-int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false) {
+template <int TM, int TN, int WM, int WN, int BU>
+int launch_wgrad_bu(const VcvWgradArgs& a, hipStream_t st, bool allow_sync) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
   WgradGeom tg;
   const int N = a.Cg * a.K;
@@ -276,9 +275,9 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   if (lds > VCV_LDS_LIMIT) return VCV_ENOFIT;
   const bool aaux = a.a_tf >= VCV_TF_DLEAKY, baux = a.b_tf >= VCV_TF_DLEAKY;
   if (aaux && baux) return VCV_EINVAL;
-  auto kern = aaux ? conv_wgrad_kernel<TM, TN, WM, WN, true, false>
-                   : (baux ? conv_wgrad_kernel<TM, TN, WM, WN, false, true>
-                           : conv_wgrad_kernel<TM, TN, WM, WN, false, false>);
+  auto kern = aaux ? conv_wgrad_kernel<TM, TN, WM, WN, true, false, BU>
+                   : (baux ? conv_wgrad_kernel<TM, TN, WM, WN, false, true, BU>
+                           : conv_wgrad_kernel<TM, TN, WM, WN, false, false, BU>);
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return VCV_EHIP;
@@ -290,6 +289,15 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
   vcv_prof_stop(slot, st);
   return vcv_check_launch();
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false) {
+  if (a.P == 1 && a.a_tf < VCV_TF_DLEAKY) {
+    const int rc = launch_wgrad_bu<TM, TN, WM, WN, 64>(a, st, false);
+    if (rc != VCV_ENOFIT) return rc;
+  }
+  return launch_wgrad_bu<TM, TN, WM, WN, 32>(a, st, allow_sync);
 }
 
 __global__ void __launch_bounds__(256)
