@@ -92,8 +92,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("VCVITS_FORCE_DDP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from vcvits_amd import _lib, configs, synthetic
     from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS, VocoderGAN
@@ -174,7 +175,7 @@ def main():
             periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
             line["cpu_baseline"] = cpu_baseline(cfg, a.workload, periods)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -54,7 +54,11 @@ class FlatAdamW:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self._works = []
         self._buckets = []
-        if self.world > 1:
+        # VCVITS_FORCE_DDP=1 keeps the bucket hooks / collectives active in a 1-rank group (used to exercise
+        # the RCCL path on a single-GPU box)
+        import os
+        self._ddp = self.world > 1 or (os.environ.get("VCVITS_FORCE_DDP") == "1" and dist.is_initialized())
+        if self._ddp:
             self._make_buckets(int(bucket_mb * 1024 * 1024 / 4))
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -94,7 +98,7 @@ class FlatAdamW:
     def finish_grad_sync(self):
         """Wait for the bucket all-reduces of this backward pass (buckets whose parameters got no
         gradient in this pass are reduced here so every rank stays in step)."""
-        if self.world <= 1:
+        if not self._ddp:
             return
         for b in self._buckets:
             if b["ready"] != b["n"]:
@@ -137,5 +141,5 @@ class FlatAdamW:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self._ddp:
             dist.broadcast(self.flat, src=src, group=self.pg)
