@@ -40,6 +40,10 @@ CONV_CASES = [
     (2, 1024, 1, 24, 3, 1, 1, 1, 1),
     (2, 32, 1, 700, 7, 1, 3, 1, 1),
     (1, 130, 70, 33, 3, 1, 1, 1, 1),
+    # short sequences: the batch is folded into the column dimension (pooled DiscriminatorS scales)
+    (4, 64, 96, 5, 5, 1, 2, 1, 1),
+    (3, 128, 64, 33, 5, 1, 2, 1, 1),
+    (2, 1024, 1024, 9, 5, 1, 2, 1, 1),
 ]
 
 

@@ -262,6 +262,16 @@ class grad_batch_start:
         return False
 
 
+def _to_bt(t):
+    """[B, C, T] -> [1, C, T, B] (batch as the innermost column; pure data movement)."""
+    return t.permute(1, 2, 0).contiguous().unsqueeze(0)
+
+
+def _from_bt(t):
+    """[1, C, T, B] -> [B, C, T]."""
+    return t[0].permute(2, 0, 1).contiguous()
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(in_act(x), w) + bias) + res      (act and res are mutually exclusive)."""
 
@@ -273,8 +283,17 @@ class _ConvFn(torch.autograd.Function):
             raise RuntimeError("conv: out_act and res cannot be combined")
         kw = dict(bias=bias, res=res, in_tf=TF_LEAKY if in_leaky else TF_NONE, out_act=out_act,
                   slope=slope)
+        # Short sequences (the pooled scales of DiscriminatorS: 5..33 frames): one batch element cannot fill
+        # a GEMM tile, so the batch is folded into the kernel's column dimension -- x[b,c,t] is viewed as one
+        # "image" [1,C,T,B] (P = B columns) and the tile's N runs over (t, b) pairs.
+        ctx.bt = (not transposed and x.dim() == 3 and groups == 1 and res is None and x.shape[0] > 1
+                  and x.shape[2] <= 40 and w.shape[0] >= 32 and w.shape[1] >= 32)
         if transposed:
             y = convT_forward(x, w, stride=stride, pad=pad, **kw)
+        elif ctx.bt:
+            w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
+            x = _to_bt(x)
+            y = _from_bt(conv_forward(x, w3, stride=stride, pad=pad, dil=dil, groups=groups, **kw))
         else:
             w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
             y = conv_forward(x, w3, stride=stride, pad=pad, dil=dil, groups=groups, **kw)
@@ -299,6 +318,20 @@ class _ConvFn(torch.autograd.Function):
             check(lib().vcv_act_grad(ptr(dy[b0:]), ptr(y[b0:]), ptr(dye[b0:]), dtf, slope, dy[b0:].numel(), stream()),
                   "vcv_act_grad")
             dy, y, dtf = dye, None, TF_NONE
+        if ctx.bt:
+            # x was saved in the folded layout; fold dy the same way, unfold dx
+            dyt = _to_bt(dy)
+            if ctx.needs_input_grad[0]:
+                kw = dict(in_tf=TF_NONE, slope=slope)
+                if in_leaky:
+                    kw.update(out_tf=TF_DLEAKY, oaux=x)
+                dx = _from_bt(conv_dgrad(dyt, w3, x.shape, stride=stride, pad=pad, dil=dil, groups=groups, **kw))
+            if ctx.needs_input_grad[1]:
+                dw = conv_wgrad(dyt, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
+                                b_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope).view(w.shape)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = bias_grad(dy, slope=slope)
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             b0 = ctx.b0 if 0 < ctx.b0 < x.shape[0] else 0
             dys, ys, xs = (dy[b0:], (y[b0:] if y is not None else None), x[b0:]) if b0 else (dy, y, x)
