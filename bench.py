@@ -31,6 +31,20 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 GFLOP_PER_UTT = {"vocoder": 400.0, "full": 488.0}  # SURVEY.md section 8d (4G + 9 D1, reference semantics)
 
 
+def profiled_traffic():
+    """HBM bytes per conv_gemm launch from the latest committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
+    produced by tools/profile_summary.py; PMC counters cannot be read from inside the benchmark process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"bytes_per_launch": round(d["hbm_bytes_per_launch"]), "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +162,7 @@ def main():
             ach = fl_conv / (ms_conv * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (fwd + dgrad + convT, all tile variants)",
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": profiled_traffic(),
                     "launches_per_step": n_conv / a.steps, "avg_launch_us": round(1e3 * ms_conv / n_conv, 2),
                     "gflop_per_launch": round(fl_conv / n_conv / 1e9, 3),
                     "share_of_step_time": round(ms_conv * 1e-3 / dt, 3),
