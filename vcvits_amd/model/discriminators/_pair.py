@@ -22,3 +22,36 @@ def run_pair(disc, y, y_hat):
     with ops.grad_batch_start(B):
         out, fmap = disc(torch.cat([y.detach(), y_hat], dim=0))
     return out[:B].detach(), out[B:], [f[:B].detach() for f in fmap], [f[B:] for f in fmap]
+
+
+_STREAMS = []
+
+
+def run_many(discs, inputs):
+    """Run independent discriminators on their (y, y_hat) pairs.  With VCVITS_STREAMS=N > 1 the chains
+    are spread over N HIP streams so the short, low-occupancy layers (first / last convs, pooled scales)
+    of one discriminator overlap the big GEMMs of another; autograd replays each chain's backward on
+    the stream it ran on."""
+    import os
+    n = int(os.environ.get("VCVITS_STREAMS", "1"))
+    if n <= 1 or not inputs[0][0].is_cuda:
+        return [run_pair(d, y, y_hat) for d, (y, y_hat) in zip(discs, inputs)]
+    while len(_STREAMS) < n:
+        _STREAMS.append(torch.cuda.Stream())
+    cur = torch.cuda.current_stream()
+    ready = cur.record_event()
+    outs, events = [], []
+    for i, (d, (y, y_hat)) in enumerate(zip(discs, inputs)):
+        s = _STREAMS[i % n]
+        s.wait_event(ready)
+        with torch.cuda.stream(s):
+            y.record_stream(s)
+            y_hat.record_stream(s)
+            o = run_pair(d, y, y_hat)
+            for t in [o[0], o[1]] + list(o[2]) + list(o[3]):
+                t.record_stream(cur)
+            events.append(s.record_event())
+        outs.append(o)
+    for e in events:
+        cur.wait_event(e)
+    return outs

@@ -4,7 +4,7 @@ from typing import List
 
 from torch import nn
 
-from ._pair import run_pair
+from ._pair import run_many
 from .discriminator import DiscriminatorP, DiscriminatorS
 
 
@@ -18,8 +18,7 @@ class MultiPeriodDiscriminator(nn.Module):
 
     def forward(self, y, y_hat, g=None):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for d in self.discriminators:
-            y_d_r, y_d_g, fmap_r, fmap_g = run_pair(d, y, y_hat)
+        for y_d_r, y_d_g, fmap_r, fmap_g in run_many(self.discriminators, [(y, y_hat)] * len(self.discriminators)):
             y_d_rs.append(y_d_r)
             y_d_gs.append(y_d_g)
             fmap_rs.append(fmap_r)

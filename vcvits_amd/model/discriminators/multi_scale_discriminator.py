@@ -3,7 +3,7 @@ pooled by cascaded AvgPool1d(4, 2, 2))."""
 from torch import nn
 
 from ... import ops
-from ._pair import run_pair
+from ._pair import run_many
 from .discriminator import DiscriminatorS
 
 
@@ -15,11 +15,13 @@ class MultiScaleDiscriminator(nn.Module):
 
     def forward(self, y, y_hat):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for i, d in enumerate(self.discriminators):
+        inputs = []
+        for i in range(len(self.discriminators)):
             if i != 0:
                 y = ops.avgpool4(y)
                 y_hat = ops.avgpool4(y_hat)
-            y_d_r, y_d_g, fmap_r, fmap_g = run_pair(d, y, y_hat)
+            inputs.append((y, y_hat))
+        for y_d_r, y_d_g, fmap_r, fmap_g in run_many(self.discriminators, inputs):
             y_d_rs.append(y_d_r)
             fmap_rs.append(fmap_r)
             y_d_gs.append(y_d_g)
