@@ -265,6 +265,15 @@ int vcv_prof_end(double* out, int ncls);
 /* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */
 int vcv_prof_dump(const char* path);
 
+/* ---- source-audio front end (vits/model/pipeline.py:24-28,59-70):
+ * complex STFT (torchaudio Spectrogram(power=None, pad, center=False)) and inverse STFT
+ * (torchaudio InverseSpectrogram = torch.istft, Hann window, center=True trims n_fft/2 per side).
+ * spec: complex64 [B, 1025, F] interleaved (re, im); ola: workspace [B, 2048 + hop*(F-1)] ---- */
+int vcv_stft_complex_fwd(const float* y, const float* window, const float* twiddle, float* out, int B, int T,
+                         int n_fft, int hop, int pad, int reflect, void* stream);
+int vcv_istft(const float* spec, const float* window, const float* twiddle, float* ola, float* out, int B, int F,
+              int n_fft, int hop, int center, void* stream);
+
 /* returns a static string describing the build (arch, kernel variants) */
 const char* vcv_version(void);
 

@@ -43,7 +43,13 @@ class VCVITS(nn.Module):
         self.net_period_d = MultiPeriodDiscriminator(periods=list(periods),
                                                      use_spectral_norm=hp.model.use_spectral_norm)
         self.net_scale_d = MultiScaleDiscriminator(hp.model.use_spectral_norm)
-        self.audio_pipeline = nn.Identity()  # STFT->iSTFT augmentation of the HuBERT input: out of scope
+        from ..model.pipeline import SpeechConversionAudioPipeline
+        # STFT -> iSTFT pass over the 16 kHz source waveform (vcvits.py:45-52,62).  Its output feeds HuBERT, which
+        # is out of scope: the module is built (same ctor call as the reference) and usable, but the training
+        # step consumes precomputed content features.
+        self.audio_pipeline = SpeechConversionAudioPipeline(sr=hp.data.source_sampling_rate, n_fft=hp.data.filter_length,
+                                                            n_mel=hp.data.n_mel_channels, win_length=hp.data.win_length,
+                                                            hop_length=hp.data.hop_length)
         self.current_epoch = 0
         self.global_step = 0
         self.logged = {}

@@ -622,6 +622,33 @@ def stft_mag(y, n_fft=2048, hop=512, pad=768, reflect=False, eps=1e-6):
     return _StftMagFn.apply(y, n_fft, hop, pad, reflect, eps)
 
 
+def stft_complex(y, n_fft=2048, hop=512, pad=768, reflect=False):
+    """Complex STFT of y [B, T] -> complex64 [B, n_fft/2+1, frames] (no autograd: the reference runs the
+    source pipeline under inference_mode, vcvits.py:61-62)."""
+    y = _f32c(y.detach())
+    B, T = y.shape
+    win, tw = _stft_consts(y.device, n_fft)
+    F_ = (T + 2 * pad - n_fft) // hop + 1
+    out = torch.empty((B, n_fft // 2 + 1, F_, 2), device=y.device, dtype=torch.float32)
+    check(lib().vcv_stft_complex_fwd(ptr(y), ptr(win), ptr(tw), ptr(out), B, T, n_fft, hop, pad, 1 if reflect else 0,
+                                     stream()), "vcv_stft_complex_fwd")
+    return torch.view_as_complex(out)
+
+
+def istft(spec, n_fft=2048, hop=512, center=True):
+    """Inverse STFT of complex64 [B, n_fft/2+1, F] -> [B, hop*(F-1)] (torch.istft, Hann window)."""
+    s = torch.view_as_real(spec.detach()).contiguous()
+    B, _, F_, _ = s.shape
+    win, tw = _stft_consts(s.device, n_fft)
+    L = n_fft + hop * (F_ - 1)
+    ola = torch.empty((B, L), device=s.device, dtype=torch.float32)
+    tout = hop * (F_ - 1) if center else L
+    out = torch.empty((B, tout), device=s.device, dtype=torch.float32)
+    check(lib().vcv_istft(ptr(s), ptr(win), ptr(tw), ptr(ola), ptr(out), B, F_, n_fft, hop, 1 if center else 0,
+                          stream()), "vcv_istft")
+    return out
+
+
 class _MelLogFn(torch.autograd.Function):
     """log(clamp(M @ spec, clamp)) as a 1x1 conv with the log-clamp fused in the epilogue."""
 
