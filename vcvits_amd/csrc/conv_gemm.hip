@@ -26,7 +26,8 @@
 namespace {
 
 constexpr int VCV_ENOFIT = -100;  // internal: tile geometry exceeds the prefetch budget
-constexpr int APT = 20;  // max weight elements prefetched per thread per chunk
+constexpr int APT_DEFAULT = 20;  // max weight elements prefetched per thread per chunk
+constexpr int APT_SMALL_TILE = 32;  // ... for single-accumulator-tile waves (room in the register file)
 constexpr int XPT_DEFAULT = 12;  // max input elements prefetched per thread per chunk
 constexpr int XPT_WIDE = 24;     // ... for the 7-wave tiles (small accumulator footprint, wide strided spans)
 
@@ -60,6 +61,7 @@ conv_gemm_kernel(const VcvConvArgs p, const TileGeom tg) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
   constexpr int BM_LOG = (BM == 128) ? 7 : (BM == 64 ? 6 : 5);
   constexpr bool XAUX = INTF >= INTF_DLEAKY;
+  constexpr int APT = (TM * TN == 1) ? APT_SMALL_TILE : APT_DEFAULT;
   constexpr int XPT = (WN == 7 || TN * WN >= 8) ? (XAUX ? 16 : XPT_WIDE) : XPT_DEFAULT;
   extern __shared__ float smem[];
 
@@ -313,6 +315,7 @@ inline int ilog2_ceil(int v) {
 template <int TM, int TN, int WM, int WN>
 int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+  constexpr int APT = (TM * TN == 1) ? APT_SMALL_TILE : APT_DEFAULT;
   const int XPT = (WN == 7 || TN * WN >= 8) ? (a.in_tf >= VCV_TF_DLEAKY ? 16 : XPT_WIDE) : XPT_DEFAULT;
   TileGeom tg;
   const int phases = a.phases > 1 ? a.phases : 1;
@@ -430,6 +433,8 @@ extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
     if (rc == VCV_ENOFIT && ok(128, 64)) rc = launch_conv<2, 1, 2, 2>(a, st);
     if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st);
     if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st, true);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 4>(a, st);  // very long taps: only 32-row tiles fit the prefetch
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 2>(a, st, true);
     return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
   }
   if (a.Mg > 32) {
@@ -438,6 +443,8 @@ extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
     if (rc == VCV_ENOFIT && ok(64, 128)) rc = launch_conv<1, 2, 2, 2>(a, st);
     if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st);
     if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 2, 2>(a, st, true);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 4>(a, st);
+    if (rc == VCV_ENOFIT) rc = launch_conv<1, 1, 1, 2>(a, st, true);
     return rc == VCV_ENOFIT ? VCV_EINVAL : rc;
   }
   if (ok(32, 512)) rc = launch_conv<1, 4, 1, 4>(a, st);
