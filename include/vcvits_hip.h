@@ -89,6 +89,17 @@ typedef struct VcvConvArgs {
 int vcv_conv_gemm(const VcvConvArgs* args, void* stream);
 
 /*
+ * LDS-DMA variant of vcv_conv_gemm for forward-type launches (a_mode 0, G == 1, phases <= 1, in_tf in
+ * {NONE, LEAKY}): weights are packed per launch into LDS-image order in `workspace`
+ * (vcv_conv_dma_workspace floats, 0 = launch not eligible -> use vcv_conv_gemm) and both operands are
+ * staged by global/buffer loads that write LDS directly (double-buffered).  flip = 1: `w` is the
+ * forward weight [C, M, K] of a conv whose stride-1 DATA GRADIENT this launch computes (the pack
+ * flips / transposes it).  Same epilogue semantics as vcv_conv_gemm.
+ */
+int64_t vcv_conv_dma_workspace(const VcvConvArgs* args);
+int vcv_conv_dma(const VcvConvArgs* args, float* workspace, int flip, void* stream);
+
+/*
  * Weight gradient of the same family (torch autograd of the call sites above):
  *   dw[(g*Mg + m), c, k] (+)= alpha * sum_{b, q, p} tfa(dy[b, g*Mg+m, q, p]) *
  *                                               tfb(x[b, g*Cg+c, q*s + k*dj + off, p])

@@ -1,0 +1,329 @@
+// conv_dma.hip -- LDS-DMA variant of the implicit-GEMM convolution (forward-type launches:
+// a_mode 0, one group, no output phases; stride / dilation / period columns as in conv_gemm.hip).
+//
+// Same GEMM mapping and epilogue as conv_gemm_kernel, different staging: nothing passes through
+// registers.
+//   * weights are pre-packed per launch into the exact LDS image order
+//       wp[m-tile][channel chunk][(c, j)][m]      (zero-padded tails)
+//     so one chunk of one tile is a contiguous slab that `global_load_lds_dwordx4` copies 1 KiB per
+//     wave-instruction straight into LDS;
+//   * the input spans are contiguous per channel and are copied by `buffer_load_dword ... lds`
+//     (64 floats per wave-instruction); the descriptor's range check writes zeros for the
+//     convolution's padding and for positions past the sequence end;
+//   * two LDS buffers: the DMA of chunk c+1 is issued right after the barrier that publishes chunk c
+//     and runs under the MFMA loop of chunk c -- one barrier per chunk, no staging VGPRs, no
+//     ds_write instructions;
+//   * the leaky-ReLU of the input (ResBlocks / generator stages) is applied to the B fragment as
+//     it is read from LDS (two VALU ops per fragment element).
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int ENOFIT = -100;
+
+struct DmaGeom {
+  int BKC;      // reduction channels per chunk (even)
+  int KKR;      // (channel, tap) rows per chunk = BKC * K
+  int nch;      // chunks
+  int ntu;      // position tiles per batch element
+  int nmt;      // M tiles
+  int xw_log;   // log2 of the staged span pitch (>= 6)
+  int a_floats; // KKR * BM
+  int buf_floats;  // a_floats + BKC * XW
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// ---- weight pack: w [M, C, K] -> wp [nmt][nch][KKR][BM] ------------------------------------------------
+// flip != 0 packs the data-gradient view instead: A(m, c, k) = w[c, m, K-1-k]  (w is then [C, M, K])
+template <int BM>
+__global__ void __launch_bounds__(256)
+pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int C, int K, int BKC, int KKR,
+                    int nch, int flip) {
+  extern __shared__ float t[];  // [KKR][BM + 1]
+  const int ch = blockIdx.x, mt = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = ch * BKC, m0 = mt * BM;
+  if (!flip) {
+    for (int ml = wave; ml < BM; ml += 4) {
+      const int m = m0 + ml;
+      const float* wr = w + ((size_t)m * C + c0) * K;
+      for (int kk = lane; kk < KKR; kk += 64) {
+        const int c = c0 + kk / K;
+        t[kk * (BM + 1) + ml] = (m < M && c < C) ? wr[kk] : 0.f;
+      }
+    }
+  } else {
+    // w[c, m, k]: for fixed c the (m, k) block is contiguous
+    for (int cl = wave; cl < BKC; cl += 4) {
+      const int c = c0 + cl;
+      const float* wc = w + ((size_t)c * M + m0) * K;
+      for (int e = lane; e < BM * K; e += 64) {
+        const int ml = e / K, k = e - ml * K;
+        t[(cl * K + (K - 1 - k)) * (BM + 1) + ml] = (c < C && m0 + ml < M) ? wc[e] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  float* out = wp + ((size_t)mt * nch + ch) * (size_t)KKR * BM;
+  for (int i = tid; i < KKR * BM; i += 256) {
+    const int kk = i / BM, ml = i - kk * BM;
+    out[i] = t[kk * (BM + 1) + ml];
+  }
+}
+
+template <int TM, int TN, int WM, int WN, bool LEAKY>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__ wp) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+  extern __shared__ float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int b = blockIdx.x / tg.ntu, ut = blockIdx.x % tg.ntu;
+  const int mt = blockIdx.y;
+  const int K = p.K, P = p.P, U = p.Q * P, Cg = p.Cg, Mg = p.Mg;
+  const int u0 = ut * BN, m0 = mt * BM;
+  const int qa = u0 / P;
+  const int jspan = (K - 1) * p.dj;
+  const int jmin = jspan < 0 ? jspan : 0;
+  const int f0 = (qa * p.s + p.off + jmin) * P;
+  const int BKC = tg.BKC, KKR = tg.KKR;
+  const int XW = 1 << tg.xw_log;
+
+  int laneoff[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    int u = u0 + (wn * TN + tn) * 32 + l31;
+    if (u > U - 1) u = U - 1;
+    const int q = u / P, pc = u - q * P;
+    laneoff[tn] = ((q - qa) * p.s - jmin) * P + pc + h * XW;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+
+  const long long TinP = (long long)p.Tin * P;
+  const float* xb = p.x + (size_t)b * Cg * (size_t)TinP;
+  const float* wtile = wp + (size_t)mt * tg.nch * (size_t)tg.a_floats;
+  const int nA = tg.a_floats >> 8;       // 1 KiB wave-instructions per weight slab
+  const int nXrow = XW >> 6;             // 256-B wave-instructions per channel span
+  const int nX = BKC * nXrow;
+
+  auto issue = [&](int ch, int buf) {
+    float* As = smem + buf * tg.buf_floats;
+    float* Xs = As + tg.a_floats;
+    const float* slab = wtile + (size_t)ch * tg.a_floats;
+    for (int i = wave; i < nA; i += NW)
+      __builtin_amdgcn_global_load_lds(slab + i * 256 + lane * 4, (lds_ptr)(As + i * 256), 16, 0, 0);
+    const int c0 = ch * BKC;
+    for (int i = wave; i < nX; i += NW) {
+      const int cl = i / nXrow, part = i - cl * nXrow;
+      const int c = c0 + cl;
+      const unsigned rec = c < Cg ? (unsigned)(TinP * 4) : 0u;
+      __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * (size_t)TinP), 0, (int)rec, 0x00020000);
+      const unsigned voff = (unsigned)(f0 + part * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(Xs + cl * XW + part * 64), 4, voff, 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  for (int ch = 0; ch < tg.nch; ++ch) {
+    // publish chunk ch (its DMA is the only traffic in flight here) and retire every wave's reads of the
+    // other buffer before it is overwritten
+    __syncthreads();
+    if (ch + 1 < tg.nch) issue(ch + 1, (ch + 1) & 1);
+    const float* As = smem + (ch & 1) * tg.buf_floats;
+    const float* Xs = As + tg.a_floats;
+    for (int c2 = 0; c2 < BKC; c2 += 2) {
+      const float* Ab = As + (c2 + h) * K * BM + wm * TM * 32 + l31;
+      const float* Xb = Xs + c2 * XW;
+      for (int j = 0; j < K; ++j) {
+        float a[TM], bb[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = Ab[j * BM + tm * 32];
+        const int xo = j * p.dj * P;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          float v = Xb[laneoff[tn] + xo];
+          if (LEAKY) v = fmaxf(v, v * p.slope);  // slope < 1
+          bb[tn] = v;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue (as conv_gemm_kernel) ----
+  const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
+  const bool mtail = m0 + BM > Mg;
+  const unsigned rowstride = (unsigned)(p.Tout * P);
+  const size_t ybase = ((size_t)b * Mg + m0) * rowstride;
+  const float* bias = p.bias ? p.bias + m0 : nullptr;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int u = u0 + (wn * TN + tn) * 32 + l31;
+    if (u >= U) continue;
+    const int q = u / P, pc = u - q * P;
+    const int trow = q * p.os + p.oo;
+    if (trow < 0 || trow >= p.Tout) continue;
+    const float mk = p.mask ? p.mask[(size_t)b * p.Tout + trow] : 1.f;
+    const size_t colbase = ybase + (size_t)trow * P + pc;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (mtail && ml >= rows_valid) continue;
+        const size_t idx = colbase + (size_t)((unsigned)ml * rowstride);
+        float v = p.alpha * acc[tm][tn][e];
+        if (bias) v += bias[ml];
+        v = vcv_act(v, p.out_act, p.slope);
+        if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
+        else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
+        else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
+        if (p.res) v += p.res[idx];
+        v *= mk;
+        if (p.accumulate) v += p.y[idx];
+        p.y[idx] = v;
+      }
+    }
+  }
+}
+
+inline int ilog2c(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+struct Plan {
+  int variant;  // 0: 128x128 (4 waves)  1: 128x256 (8 waves)  2: 128x224 (7 waves)  3: 64x224 (7 waves)
+                // 4: 64x256 (8 waves: 2x2 per wave, 1x4 waves... see launch)  5: 64x128
+  int BM, BN;
+  DmaGeom g;
+  size_t ws_floats, lds_bytes;
+};
+
+bool eligible(const VcvConvArgs& a) {
+  return a.a_mode == 0 && a.G == 1 && a.phases <= 1 && (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) &&
+         a.Mg >= 32 && a.Cg >= 16 && a.K <= 16 && a.s >= 1 && (long long)a.Tin * a.P * 4 < (1ll << 31) &&
+         (long long)a.Mg * a.Tout * a.P < (1ll << 31);
+}
+
+bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
+  pl.BM = BM; pl.BN = BN;
+  DmaGeom& g = pl.g;
+  const int qspan = (BN - 1) / a.P + 1;
+  const int adj = a.dj < 0 ? -a.dj : a.dj;
+  const int rowmax = (qspan * a.s + (a.K - 1) * adj + 1) * a.P;
+  g.xw_log = ilog2c(rowmax);
+  if (g.xw_log < 6) g.xw_log = 6;
+  const int xw = 1 << g.xw_log;
+  // chunk: ~64 (c, tap) rows, even channel count, KKR*BM a multiple of 256 floats, two buffers within ~120 KiB
+  int bkc = 64 / a.K;
+  bkc &= ~1;
+  if (bkc < 2) bkc = 2;
+  const int cg_even = (a.Cg + 1) & ~1;
+  if (bkc > cg_even) bkc = cg_even;
+  while (bkc > 2 && 2ull * ((size_t)bkc * a.K * BM + (size_t)bkc * xw) * 4 > 120 * 1024) bkc -= 2;
+  if ((bkc * a.K * BM) % 256 != 0) return false;
+  g.BKC = bkc;
+  g.KKR = bkc * a.K;
+  g.nch = vcv_cdiv(a.Cg, bkc);
+  g.ntu = vcv_cdiv(a.Q * a.P, BN);
+  g.nmt = vcv_cdiv(a.Mg, BM);
+  g.a_floats = g.KKR * BM;
+  g.buf_floats = g.a_floats + bkc * xw;
+  pl.lds_bytes = 2ull * g.buf_floats * 4;
+  if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
+  pl.ws_floats = (size_t)g.nmt * g.nch * g.a_floats;
+  return true;
+}
+
+bool choose(const VcvConvArgs& a, Plan& pl) {
+  const int U = a.Q * a.P;
+  auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm); };
+  if (U > 160 && U <= 224) {
+    if (a.Mg >= 128 && blocks(128, 224) >= 224 && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
+    if (a.Mg >= 64 && make_plan(a, 64, 224, pl)) { pl.variant = 3; return true; }
+  }
+  if (a.Mg >= 128) {
+    if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, pl)) { pl.variant = 1; return true; }
+    if (blocks(128, 128) >= 256 && make_plan(a, 128, 128, pl)) { pl.variant = 0; return true; }
+  }
+  if (a.Mg >= 64) {
+    if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
+    if (make_plan(a, 64, 128, pl) && blocks(64, 128) >= 128) { pl.variant = 5; return true; }
+  }
+  return false;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, NT = 64 * WM * WN;
+  const DmaGeom& g = pl.g;
+  // pack (forward orientation; the data-gradient orientation is packed by the caller through flip)
+  const size_t plds = (size_t)g.KKR * (BM + 1) * 4;
+  auto pk = pack_weights_kernel<BM>;
+  if (plds > 64 * 1024 && hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
+    return VCV_EHIP;
+  hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR, g.nch,
+                     a.accumulate >> 8);
+  void (*kern)(const VcvConvArgs, const DmaGeom, const float*) =
+      a.in_tf == VCV_TF_LEAKY ? conv_dma_kernel<TM, TN, WM, WN, true> : conv_dma_kernel<TM, TN, WM, WN, false>;
+  if (pl.lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
+    return VCV_EHIP;
+  VcvConvArgs aa = a;
+  aa.accumulate = a.accumulate & 1;
+  dim3 grid(a.B * g.ntu, g.nmt), block(NT);
+  const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Q;
+  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, 1, 0, BM * 1000 + pl.BN, g.BKC};
+  const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st, tag, 12);
+  hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws);
+  vcv_prof_stop(slot, st);
+  return vcv_check_launch();
+}
+
+}  // namespace
+
+// Workspace (floats) the DMA path needs for this launch, 0 if the launch is not eligible.
+extern "C" int64_t vcv_conv_dma_workspace(const VcvConvArgs* args) {
+  if (!args || !eligible(*args)) return 0;
+  Plan pl;
+  if (!choose(*args, pl)) return 0;
+  return (int64_t)pl.ws_floats;
+}
+
+// `flip`: 0 = w is [M, C, K] (forward); 1 = w is [C, M, K] and the launch is the stride-1 data gradient
+// (the pack applies the flip / transpose, so no separate vcv_weight_flip_transpose pass is needed).
+extern "C" int vcv_conv_dma(const VcvConvArgs* args, float* workspace, int flip, void* stream) {
+  if (!args || !workspace || !eligible(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose(*args, pl)) return VCV_EINVAL;
+  VcvConvArgs a = *args;
+  a.accumulate = (a.accumulate & 1) | (flip ? 256 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  switch (pl.variant) {
+    case 0: return launch<2, 2, 2, 2>(a, pl, workspace, st);
+    case 1: return launch<2, 2, 2, 4>(a, pl, workspace, st);
+    case 2: return launch<4, 1, 1, 7>(a, pl, workspace, st);
+    case 3: return launch<2, 1, 1, 7>(a, pl, workspace, st);
+    case 4: return launch<2, 2, 1, 4>(a, pl, workspace, st);
+    default: return launch<1, 2, 2, 2>(a, pl, workspace, st);
+  }
+}

@@ -38,7 +38,25 @@ def conv_out_len(tin, k, stride, pad, dil):
     return (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _launch_conv(a):
+_USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
+
+
+def _launch_conv(a, flip_w=None):
+    """Forward-type launches go to the LDS-DMA kernel when it is eligible (vcv_conv_dma_workspace > 0),
+    everything else to the register-staged kernel.  flip_w: original [C, M, K] weight of a stride-1 data
+    gradient (the DMA pack flips it; the register path needs the explicit flipped copy in a.w)."""
+    if _USE_DMA[0] and a.a_mode == 0:
+        L = lib()
+        if flip_w is not None:
+            saved = a.w
+            a.w = ptr(flip_w)
+        ws = L.vcv_conv_dma_workspace(ctypes.byref(a))
+        if ws > 0:
+            buf = torch.empty((ws,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+            check(L.vcv_conv_dma(ctypes.byref(a), ptr(buf), 1 if flip_w is not None else 0, stream()), "vcv_conv_dma")
+            return
+        if flip_w is not None:
+            a.w = saved
     check(lib().vcv_conv_gemm(ctypes.byref(a), stream()), "vcv_conv_gemm")
 
 
@@ -112,15 +130,20 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
     if stride == 1 and groups == 1 and M >= 32 and C >= 32:
         # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
         # staging path (row-major weight rows) is the faster one
-        wt = torch.empty((C, M, K), device=dy.device, dtype=torch.float32)
-        check(lib().vcv_weight_flip_transpose(ptr(w), ptr(wt), M, C, K, stream()), "vcv_weight_flip_transpose")
         a = VcvConvArgs()
-        a.x, a.w, a.y = ptr(dy), ptr(wt), ptr(out)
+        a.x, a.y = ptr(dy), ptr(out)
         a.B, a.G, a.Cg, a.Mg = B, 1, M, C
         a.Tin, a.Tout, a.P, a.K = Tout, Tin, P, K
         a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = 1, dil, pad - (K - 1) * dil, 1, 0, 1, Tin, 0
         _common(a, **kw)
-        _launch_conv(a)
+        a.w = ptr(w)
+        if _USE_DMA[0] and lib().vcv_conv_dma_workspace(ctypes.byref(a)) > 0:
+            _launch_conv(a, flip_w=w)
+            return out
+        wt = torch.empty((C, M, K), device=dy.device, dtype=torch.float32)
+        check(lib().vcv_weight_flip_transpose(ptr(w), ptr(wt), M, C, K, stream()), "vcv_weight_flip_transpose")
+        a.w = ptr(wt)
+        check(lib().vcv_conv_gemm(ctypes.byref(a), stream()), "vcv_conv_gemm")
         return out
     a = VcvConvArgs()
     a.x, a.w, a.y = ptr(dy), ptr(w), ptr(out)
