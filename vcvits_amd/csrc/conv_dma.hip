@@ -15,6 +15,8 @@
 //     ds_write instructions;
 //   * the leaky-ReLU of the input (ResBlocks / generator stages) is applied to the B fragment as
 //     it is read from LDS (two VALU ops per fragment element).
+#include <cstdlib>
+
 #include "common.h"
 #include "prof.h"
 
@@ -239,7 +241,8 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   if (bkc < 2) bkc = 2;
   const int cg_even = (a.Cg + 1) & ~1;
   if (bkc > cg_even) bkc = cg_even;
-  while (bkc > 2 && 2ull * ((size_t)bkc * a.K * BM + (size_t)bkc * xw) * 4 > 120 * 1024) bkc -= 2;
+  const size_t lds_cap = (size_t)(getenv("VCV_DMA_LDS_KB") ? atoi(getenv("VCV_DMA_LDS_KB")) : 78) * 1024;
+  while (bkc > 2 && 2ull * ((size_t)bkc * a.K * BM + (size_t)bkc * xw) * 4 > lds_cap) bkc -= 2;
   if ((bkc * a.K * BM) % 256 != 0) return false;
   g.BKC = bkc;
   g.KKR = bkc * a.K;
@@ -256,6 +259,10 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
 
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
+  // measured on the bench step: the packed / DMA path wins for deep reductions over long rows (k >= 5,
+  // >= 160 positions per batch element); short rows and k = 3 stay on the register-staged kernel, whose
+  // smaller tiles and missing pack pass serve them better
+  if (a.K < 5 || U < 160) return false;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm); };
   if (U > 160 && U <= 224) {
     if (a.Mg >= 128 && blocks(128, 224) >= 224 && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
@@ -267,7 +274,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   }
   if (a.Mg >= 64) {
     if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
-    if (make_plan(a, 64, 128, pl) && blocks(64, 128) >= 128) { pl.variant = 5; return true; }
+    if (make_plan(a, 64, 128, pl) && blocks(64, 128) >= 256) { pl.variant = 5; return true; }
   }
   return false;
 }
