@@ -33,6 +33,8 @@ struct DmaGeom {
   int xw_log;   // log2 of the staged span pitch (>= 6)
   int a_floats; // KKR * BM
   int buf_floats;  // a_floats + BKC * XW
+  int JA;          // taps per channel stored in a weight slab (K, or ceil(K/phases) for a phased launch)
+  int phases;      // > 1: transposed / strided-data-gradient launch, one residue per blockIdx.z
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -56,7 +58,7 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
         t[kk * (BM + 1) + ml] = (m < M && c < C) ? wr[kk] : 0.f;
       }
     }
-  } else {
+  } else if (flip == 1) {
     // w[c, m, k]: for fixed c the (m, k) block is contiguous
     for (int cl = wave; cl < BKC; cl += 4) {
       const int c = c0 + cl;
@@ -66,9 +68,23 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
         t[(cl * K + (K - 1 - k)) * (BM + 1) + ml] = (c < C && m0 + ml < M) ? wc[e] : 0.f;
       }
     }
+  } else {
+    // phased (transposed) launch: residue r = blockIdx.z keeps taps k = r + j*phases of w[c, m, k]; here the
+    // argument K is the weight's tap count and KKR = BKC * JA
+    const int phases = flip >> 8, r = blockIdx.z, JA = KKR / BKC;
+    for (int i = tid; i < KKR * (BM + 1); i += 256) t[i] = 0.f;
+    __syncthreads();
+    for (int cl = wave; cl < BKC; cl += 4) {
+      const int c = c0 + cl;
+      const float* wc = w + ((size_t)c * M + m0) * K;
+      for (int e = lane; e < BM * K; e += 64) {
+        const int ml = e / K, k = e - ml * K;
+        if (k % phases == r && c < C && m0 + ml < M) t[(cl * JA + k / phases) * (BM + 1) + ml] = wc[e];
+      }
+    }
   }
   __syncthreads();
-  float* out = wp + ((size_t)mt * nch + ch) * (size_t)KKR * BM;
+  float* out = wp + (((size_t)blockIdx.z * gridDim.y + mt) * nch + ch) * (size_t)KKR * BM;
   for (int i = tid; i < KKR * BM; i += 256) {
     const int kk = i / BM, ml = i - kk * BM;
     out[i] = t[kk * (BM + 1) + ml];
@@ -88,10 +104,14 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
 
   const int b = blockIdx.x / tg.ntu, ut = blockIdx.x % tg.ntu;
   const int mt = blockIdx.y;
-  const int K = p.K, P = p.P, U = p.Q * P, Cg = p.Cg, Mg = p.Mg;
+  const int r = blockIdx.z;  // output residue of a phased launch (0 otherwise)
+  const int JA = tg.JA, P = p.P, U = p.Q * P, Cg = p.Cg, Mg = p.Mg;
+  // taps of this residue: k = r + j*phases < K
+  const int K = tg.phases > 1 ? (r < p.K ? (p.K - r + tg.phases - 1) / tg.phases : 0) : p.K;
+  const int oo = p.oo + (tg.phases > 1 ? r : 0);
   const int u0 = ut * BN, m0 = mt * BM;
   const int qa = u0 / P;
-  const int jspan = (K - 1) * p.dj;
+  const int jspan = (JA - 1) * p.dj;
   const int jmin = jspan < 0 ? jspan : 0;
   const int f0 = (qa * p.s + p.off + jmin) * P;
   const int BKC = tg.BKC, KKR = tg.KKR;
@@ -116,7 +136,7 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
 
   const long long TinP = (long long)p.Tin * P;
   const float* xb = p.x + (size_t)b * Cg * (size_t)TinP;
-  const float* wtile = wp + (size_t)mt * tg.nch * (size_t)tg.a_floats;
+  const float* wtile = wp + ((size_t)r * gridDim.y + mt) * tg.nch * (size_t)tg.a_floats;
   const int nA = tg.a_floats >> 8;       // 1 KiB wave-instructions per weight slab
   const int nXrow = XW >> 6;             // 256-B wave-instructions per channel span
   const int nX = BKC * nXrow;
@@ -147,7 +167,7 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
     const float* As = smem + (ch & 1) * tg.buf_floats;
     const float* Xs = As + tg.a_floats;
     for (int c2 = 0; c2 < BKC; c2 += 2) {
-      const float* Ab = As + (c2 + h) * K * BM + wm * TM * 32 + l31;
+      const float* Ab = As + (c2 + h) * JA * BM + wm * TM * 32 + l31;
       const float* Xb = Xs + c2 * XW;
       for (int j = 0; j < K; ++j) {
         float a[TM], bb[TN];
@@ -180,7 +200,7 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
     const int u = u0 + (wn * TN + tn) * 32 + l31;
     if (u >= U) continue;
     const int q = u / P, pc = u - q * P;
-    const int trow = q * p.os + p.oo;
+    const int trow = q * p.os + oo;
     if (trow < 0 || trow >= p.Tout) continue;
     const float mk = p.mask ? p.mask[(size_t)b * p.Tout + trow] : 1.f;
     const size_t colbase = ybase + (size_t)trow * P + pc;
@@ -221,7 +241,9 @@ struct Plan {
 };
 
 bool eligible(const VcvConvArgs& a) {
-  return a.a_mode == 0 && a.G == 1 && a.phases <= 1 && (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) &&
+  const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
+  const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1 && a.in_tf == VCV_TF_NONE;
+  return (fwd_type || phased) && a.G == 1 && (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) &&
          a.Mg >= 32 && a.Cg >= 16 && a.K <= 16 && a.s >= 1 && (long long)a.Tin * a.P * 4 < (1ll << 31) &&
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);
 }
@@ -231,21 +253,23 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   DmaGeom& g = pl.g;
   const int qspan = (BN - 1) / a.P + 1;
   const int adj = a.dj < 0 ? -a.dj : a.dj;
-  const int rowmax = (qspan * a.s + (a.K - 1) * adj + 1) * a.P;
+  g.phases = a.phases > 1 ? a.phases : 1;
+  g.JA = vcv_cdiv(a.K, g.phases);
+  const int rowmax = (qspan * a.s + (g.JA - 1) * adj + 1) * a.P;
   g.xw_log = ilog2c(rowmax);
   if (g.xw_log < 6) g.xw_log = 6;
   const int xw = 1 << g.xw_log;
   // chunk: ~64 (c, tap) rows, even channel count, KKR*BM a multiple of 256 floats, two buffers within ~120 KiB
-  int bkc = 64 / a.K;
+  int bkc = 64 / g.JA;
   bkc &= ~1;
   if (bkc < 2) bkc = 2;
   const int cg_even = (a.Cg + 1) & ~1;
   if (bkc > cg_even) bkc = cg_even;
   const size_t lds_cap = (size_t)(getenv("VCV_DMA_LDS_KB") ? atoi(getenv("VCV_DMA_LDS_KB")) : 78) * 1024;
-  while (bkc > 2 && 2ull * ((size_t)bkc * a.K * BM + (size_t)bkc * xw) * 4 > lds_cap) bkc -= 2;
-  if ((bkc * a.K * BM) % 256 != 0) return false;
+  while (bkc > 2 && 2ull * ((size_t)bkc * g.JA * BM + (size_t)bkc * xw) * 4 > lds_cap) bkc -= 2;
+  if ((bkc * g.JA * BM) % 256 != 0) return false;
   g.BKC = bkc;
-  g.KKR = bkc * a.K;
+  g.KKR = bkc * g.JA;
   g.nch = vcv_cdiv(a.Cg, bkc);
   g.ntu = vcv_cdiv(a.Q * a.P, BN);
   g.nmt = vcv_cdiv(a.Mg, BM);
@@ -253,7 +277,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   g.buf_floats = g.a_floats + bkc * xw;
   pl.lds_bytes = 2ull * g.buf_floats * 4;
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
-  pl.ws_floats = (size_t)g.nmt * g.nch * g.a_floats;
+  pl.ws_floats = (size_t)g.phases * g.nmt * g.nch * g.a_floats;
   return true;
 }
 
@@ -262,8 +286,13 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // measured on the bench step: the packed / DMA path wins for deep reductions over long rows (k >= 5,
   // >= 160 positions per batch element); short rows and k = 3 stay on the register-staged kernel, whose
   // smaller tiles and missing pack pass serve them better
-  if (a.K < 5 || U < 160) return false;
-  auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm); };
+  if (a.phases > 1) {
+    if (a.K < 4 || U < 160) return false;
+  } else if (a.K < 5 || U < 160) {
+    return false;
+  }
+  const int nph = a.phases > 1 ? a.phases : 1;
+  auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
   if (U > 160 && U <= 224) {
     if (a.Mg >= 128 && blocks(128, 224) >= 224 && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
     if (a.Mg >= 64 && make_plan(a, 64, 224, pl)) { pl.variant = 3; return true; }
@@ -288,8 +317,9 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
   auto pk = pack_weights_kernel<BM>;
   if (plds > 64 * 1024 && hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
     return VCV_EHIP;
-  hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR, g.nch,
-                     a.accumulate >> 8);
+  const int flip = g.phases > 1 ? (g.phases << 8) : (a.accumulate >> 8);
+  hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt, g.phases), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR,
+                     g.nch, flip);
   void (*kern)(const VcvConvArgs, const DmaGeom, const float*) =
       a.in_tf == VCV_TF_LEAKY ? conv_dma_kernel<TM, TN, WM, WN, true> : conv_dma_kernel<TM, TN, WM, WN, false>;
   if (pl.lds_bytes > 64 * 1024 &&
@@ -297,9 +327,9 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
     return VCV_EHIP;
   VcvConvArgs aa = a;
   aa.accumulate = a.accumulate & 1;
-  dim3 grid(a.B * g.ntu, g.nmt), block(NT);
-  const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Q;
-  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, 1, 0, BM * 1000 + pl.BN, g.BKC};
+  dim3 grid(a.B * g.ntu, g.nmt, g.phases), block(NT);
+  const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
+  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode, BM * 1000 + pl.BN, g.BKC};
   const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st, tag, 12);
   hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws);
   vcv_prof_stop(slot, st);

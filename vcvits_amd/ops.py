@@ -45,7 +45,7 @@ def _launch_conv(a, flip_w=None):
     """Forward-type launches go to the LDS-DMA kernel when it is eligible (vcv_conv_dma_workspace > 0),
     everything else to the register-staged kernel.  flip_w: original [C, M, K] weight of a stride-1 data
     gradient (the DMA pack flips it; the register path needs the explicit flipped copy in a.w)."""
-    if _USE_DMA[0] and a.a_mode == 0:
+    if _USE_DMA[0] and (a.a_mode == 0 or (a.a_mode == 1 and a.phases > 1)):
         L = lib()
         if flip_w is not None:
             saved = a.w
