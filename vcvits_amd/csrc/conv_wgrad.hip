@@ -11,6 +11,8 @@
 //                   at their own offset, so the shifted operand is not re-fetched per tap
 //   tab[u]          the LDS offset of position u inside a staged span (handles P > 1 rows)
 // and feeds v_mfma_f32_32x32x2_f32 with lane half h taking position 2i+h.
+#include <cstdlib>
+
 #include "common.h"
 #include "prof.h"
 
@@ -328,6 +330,8 @@ bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ aux, fl
 
 }  // namespace
 
+int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st);  // wgrad_dma.hip
+
 extern "C" int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream) {
   if (!args) return VCV_EINVAL;
   const VcvWgradArgs& a = *args;
@@ -338,6 +342,11 @@ extern "C" int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream) {
   if (a.b_tf >= VCV_TF_DLEAKY && !a.baux) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int N = a.Cg * a.K;
+  static const bool use_dma = !(getenv("VCVITS_WGRAD_DMA") && getenv("VCVITS_WGRAD_DMA")[0] == '0');
+  if (use_dma) {
+    const int rcd = vcv_wgrad_dma_try(a, st);
+    if (rcd != VCV_ENOFIT) return rcd;
+  }
   int rc = VCV_ENOFIT;
   if (a.Mg > 64) {
     if (N > 64) rc = launch_wgrad<2, 2, 2, 2>(a, st);
