@@ -44,6 +44,11 @@ CONV_CASES = [
     (4, 64, 96, 5, 5, 1, 2, 1, 1),
     (3, 128, 64, 33, 5, 1, 2, 1, 1),
     (2, 1024, 1024, 9, 5, 1, 2, 1, 1),
+    # few output tiles: reduction split over several blocks per tile + finishing pass
+    (16, 512, 512, 20, 5, 1, 2, 1, 1),
+    (2, 256, 256, 256, 11, 1, 5, 1, 1),
+    (2, 256, 192, 200, 3, 1, 3, 3, 1),
+    (1, 300, 130, 150, 7, 1, 3, 1, 1),
 ]
 
 

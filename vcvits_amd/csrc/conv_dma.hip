@@ -35,6 +35,7 @@ struct DmaGeom {
   int buf_floats;  // a_floats + BKC * XW
   int JA;          // taps per channel stored in a weight slab (K, or ceil(K/phases) for a phased launch)
   int phases;      // > 1: transposed / strided-data-gradient launch, one residue per blockIdx.z
+  int ks;          // > 1: the chunks are split over ks blocks per tile, partial sums go to a scratch slab each
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -93,7 +94,7 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
 
 template <int TM, int TN, int WM, int WN, bool LEAKY>
 __global__ void __launch_bounds__(64 * WM * WN)
-conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__ wp) {
+conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
   extern __shared__ float smem[];
 
@@ -102,7 +103,9 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
-  const int b = blockIdx.x / tg.ntu, ut = blockIdx.x % tg.ntu;
+  const int kz = blockIdx.x % tg.ks;
+  const int bx = blockIdx.x / tg.ks;
+  const int b = bx / tg.ntu, ut = bx % tg.ntu;
   const int mt = blockIdx.y;
   const int r = blockIdx.z;  // output residue of a phased launch (0 otherwise)
   const int JA = tg.JA, P = p.P, U = p.Q * P, Cg = p.Cg, Mg = p.Mg;
@@ -158,13 +161,15 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
     }
   };
 
-  issue(0, 0);
-  for (int ch = 0; ch < tg.nch; ++ch) {
+  const int ch_begin = (int)((long long)kz * tg.nch / tg.ks), ch_end = (int)((long long)(kz + 1) * tg.nch / tg.ks);
+  issue(ch_begin, 0);
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
     // publish chunk ch (its DMA is the only traffic in flight here) and retire every wave's reads of the
     // other buffer before it is overwritten
     __syncthreads();
-    if (ch + 1 < tg.nch) issue(ch + 1, (ch + 1) & 1);
-    const float* As = smem + (ch & 1) * tg.buf_floats;
+    const int cb = (ch - ch_begin) & 1;
+    if (ch + 1 < ch_end) issue(ch + 1, cb ^ 1);
+    const float* As = smem + cb * tg.buf_floats;
     const float* Xs = As + tg.a_floats;
     for (int c2 = 0; c2 < BKC; c2 += 2) {
       const float* Ab = As + (c2 + h) * JA * BM + wm * TM * 32 + l31;
@@ -189,9 +194,28 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
     }
   }
 
-  // ---- epilogue (as conv_gemm_kernel) ----
   const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
   const bool mtail = m0 + BM > Mg;
+  if (tg.ks > 1) {
+    // split reduction: raw partial sums to this split's slab [kz][b][m][u]; conv_dma_finish_kernel adds the
+    // slabs and applies the epilogue
+    float* pb = part + (((size_t)kz * p.B + b) * Mg + m0) * (size_t)U;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int u = u0 + (wn * TN + tn) * 32 + l31;
+      if (u >= U) continue;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (mtail && ml >= rows_valid) continue;
+          pb[(size_t)ml * U + u] = acc[tm][tn][e];
+        }
+    }
+    return;
+  }
+  // ---- epilogue (as conv_gemm_kernel) ----
   const unsigned rowstride = (unsigned)(p.Tout * P);
   const size_t ybase = ((size_t)b * Mg + m0) * rowstride;
   const float* bias = p.bias ? p.bias + m0 : nullptr;
@@ -226,6 +250,33 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
   }
 }
 
+// Adds the ks partial slabs of a split launch and applies the epilogue of conv_dma_kernel.
+__global__ void __launch_bounds__(256) conv_dma_finish_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
+  const int U = p.Q * p.P;
+  const size_t n = (size_t)p.B * p.Mg * U;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int u = (int)(i % U);
+  const size_t bm = i / U;
+  const int m = (int)(bm % p.Mg), b = (int)(bm / p.Mg);
+  const int q = u / p.P, pc = u - q * p.P;
+  const int trow = q * p.os + p.oo;
+  if (trow < 0 || trow >= p.Tout) return;
+  float v = 0.f;
+  for (int k = 0; k < ks; ++k) v += part[(size_t)k * n + i];
+  v *= p.alpha;
+  if (p.bias) v += p.bias[m];
+  v = vcv_act(v, p.out_act, p.slope);
+  const size_t idx = (bm * p.Tout + trow) * p.P + pc;
+  if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
+  else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
+  else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
+  if (p.res) v += p.res[idx];
+  if (p.mask) v *= p.mask[(size_t)b * p.Tout + trow];
+  if (p.accumulate) v += p.y[idx];
+  p.y[idx] = v;
+}
+
 inline int ilog2c(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -237,7 +288,7 @@ struct Plan {
                 // 4: 64x256 (8 waves: 2x2 per wave, 1x4 waves... see launch)  5: 64x128
   int BM, BN;
   DmaGeom g;
-  size_t ws_floats, lds_bytes;
+  size_t ws_floats, pack_floats, lds_bytes;
 };
 
 bool eligible(const VcvConvArgs& a) {
@@ -277,7 +328,9 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   g.buf_floats = g.a_floats + bkc * xw;
   pl.lds_bytes = 2ull * g.buf_floats * 4;
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
-  pl.ws_floats = (size_t)g.phases * g.nmt * g.nch * g.a_floats;
+  g.ks = 1;
+  pl.pack_floats = (size_t)g.phases * g.nmt * g.nch * g.a_floats;
+  pl.ws_floats = pl.pack_floats;
   return true;
 }
 
@@ -286,24 +339,40 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // measured on the bench step: the packed / DMA path wins for deep reductions over long rows (k >= 5,
   // >= 160 positions per batch element); short rows and k = 3 stay on the register-staged kernel, whose
   // smaller tiles and missing pack pass serve them better
-  if (a.phases > 1) {
-    if (a.K < 4 || U < 160) return false;
-  } else if (a.K < 5 || U < 160) {
-    return false;
-  }
+  bool normal_ok = a.phases > 1 ? (a.K >= 4 && U >= 160) : (a.K >= 5 && U >= 160);
+  if (!normal_ok && (a.phases > 1 || a.K < 3 || U < 128)) return false;
   const int nph = a.phases > 1 ? a.phases : 1;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
-  if (U > 160 && U <= 224) {
+  if (normal_ok && U > 160 && U <= 224) {
     if (a.Mg >= 128 && blocks(128, 224) >= 224 && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
     if (a.Mg >= 64 && make_plan(a, 64, 224, pl)) { pl.variant = 3; return true; }
   }
-  if (a.Mg >= 128) {
+  if (normal_ok && a.Mg >= 128) {
     if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, pl)) { pl.variant = 1; return true; }
     if (blocks(128, 128) >= 256 && make_plan(a, 128, 128, pl)) { pl.variant = 0; return true; }
   }
-  if (a.Mg >= 64) {
+  if (normal_ok && a.Mg >= 64) {
     if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
     if (make_plan(a, 64, 128, pl) && blocks(64, 128) >= 256) { pl.variant = 5; return true; }
+  }
+  // too few tiles to fill the chip: split the reduction over ks blocks per tile (deterministic slabs + a
+  // finishing pass), which also hides the DMA latency the few resident waves cannot
+  if (nph == 1 && a.Mg >= 64) {
+    bool ok = false;
+    if (U > 128 && U <= 224) {
+      if (a.Mg >= 128 && blocks(128, 224) >= 32 && make_plan(a, 128, 224, pl)) pl.variant = 2, ok = true;
+      else if (make_plan(a, 64, 224, pl)) pl.variant = 3, ok = true;
+    }
+    if (!ok && a.Mg >= 128 && blocks(128, 128) >= 32 && make_plan(a, 128, 128, pl)) pl.variant = 0, ok = true;
+    if (!ok && make_plan(a, 64, 128, pl)) pl.variant = 5, ok = true;
+    if (!ok) return false;
+    const long long nb = blocks(pl.BM, pl.BN);
+    long long ks = (384 + nb - 1) / nb;
+    if (ks > pl.g.nch / 2) ks = pl.g.nch / 2;
+    if (ks < 2) return false;
+    pl.g.ks = (int)ks;
+    pl.ws_floats = pl.pack_floats + (size_t)ks * a.B * a.Mg * U;
+    return true;
   }
   return false;
 }
@@ -320,18 +389,23 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
   const int flip = g.phases > 1 ? (g.phases << 8) : (a.accumulate >> 8);
   hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt, g.phases), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR,
                      g.nch, flip);
-  void (*kern)(const VcvConvArgs, const DmaGeom, const float*) =
+  void (*kern)(const VcvConvArgs, const DmaGeom, const float*, float*) =
       a.in_tf == VCV_TF_LEAKY ? conv_dma_kernel<TM, TN, WM, WN, true> : conv_dma_kernel<TM, TN, WM, WN, false>;
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
   VcvConvArgs aa = a;
   aa.accumulate = a.accumulate & 1;
-  dim3 grid(a.B * g.ntu, g.nmt, g.phases), block(NT);
+  dim3 grid(a.B * g.ntu * g.ks, g.nmt, g.phases), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
-  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode, BM * 1000 + pl.BN, g.BKC};
+  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
   const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st, tag, 12);
-  hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws);
+  float* part = ws + pl.pack_floats;
+  hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws, part);
+  if (g.ks > 1) {
+    const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
+    hipLaunchKernelGGL(conv_dma_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, (const float*)part, g.ks);
+  }
   vcv_prof_stop(slot, st);
   return vcv_check_launch();
 }
