@@ -30,7 +30,7 @@ struct DmaGeom {
   int nch;      // chunks
   int ntu;      // position tiles per batch element
   int nmt;      // M tiles
-  int xw_log;   // log2 of the staged span pitch (>= 6)
+  int xw;       // staged span pitch per channel (floats, a multiple of 64)
   int a_floats; // KKR * BM
   int buf_floats;  // a_floats + BKC * XW
   int JA;          // taps per channel stored in a weight slab (K, or ceil(K/phases) for a phased launch)
@@ -118,7 +118,7 @@ conv_dma_kernel(const VcvConvArgs p, const DmaGeom tg, const float* __restrict__
   const int jmin = jspan < 0 ? jspan : 0;
   const int f0 = (qa * p.s + p.off + jmin) * P;
   const int BKC = tg.BKC, KKR = tg.KKR;
-  const int XW = 1 << tg.xw_log;
+  const int XW = tg.xw;
 
   int laneoff[TN];
 #pragma unroll
@@ -277,12 +277,6 @@ __global__ void __launch_bounds__(256) conv_dma_finish_kernel(const VcvConvArgs 
   p.y[idx] = v;
 }
 
-inline int ilog2c(int v) {
-  int l = 0;
-  while ((1 << l) < v) ++l;
-  return l;
-}
-
 struct Plan {
   int variant;  // 0: 128x128 (4 waves)  1: 128x256 (8 waves)  2: 128x224 (7 waves)  3: 64x224 (7 waves)
                 // 4: 64x256 (8 waves: 2x2 per wave, 1x4 waves... see launch)  5: 64x128
@@ -307,9 +301,8 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   g.phases = a.phases > 1 ? a.phases : 1;
   g.JA = vcv_cdiv(a.K, g.phases);
   const int rowmax = (qspan * a.s + (g.JA - 1) * adj + 1) * a.P;
-  g.xw_log = ilog2c(rowmax);
-  if (g.xw_log < 6) g.xw_log = 6;
-  const int xw = 1 << g.xw_log;
+  const int xw = (rowmax + 63) & ~63;
+  g.xw = xw;
   // chunk: ~64 (c, tap) rows, even channel count, KKR*BM a multiple of 256 floats, two buffers within ~120 KiB
   int bkc = 64 / g.JA;
   bkc &= ~1;
@@ -318,7 +311,15 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   if (bkc > cg_even) bkc = cg_even;
   const size_t lds_cap = (size_t)(getenv("VCV_DMA_LDS_KB") ? atoi(getenv("VCV_DMA_LDS_KB")) : 78) * 1024;
   while (bkc > 2 && 2ull * ((size_t)bkc * g.JA * BM + (size_t)bkc * xw) * 4 > lds_cap) bkc -= 2;
-  if ((bkc * g.JA * BM) % 256 != 0) return false;
+  // weight slabs move as whole 1-KiB DMA instructions: nearest even channel count (down, else up) that fits
+  {
+    int dn = bkc, up = bkc;
+    while (dn >= 2 && (dn * g.JA * BM) % 256 != 0) dn -= 2;
+    while (up <= 2 * bkc + 8 && (up * g.JA * BM) % 256 != 0) up += 2;
+    if (dn >= 2) bkc = dn;
+    else if ((up * g.JA * BM) % 256 == 0) bkc = up;
+    else return false;
+  }
   g.BKC = bkc;
   g.KKR = bkc * g.JA;
   g.nch = vcv_cdiv(a.Cg, bkc);
@@ -351,10 +352,11 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, pl)) { pl.variant = 1; return true; }
     if (blocks(128, 128) >= 256 && make_plan(a, 128, 128, pl)) { pl.variant = 0; return true; }
   }
-  if (normal_ok && a.Mg >= 64) {
+  if (normal_ok && a.Mg >= 64 && !(a.Mg >= 128 && blocks(128, 128) >= 32)) {
     if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
     if (make_plan(a, 64, 128, pl) && blocks(64, 128) >= 256) { pl.variant = 5; return true; }
   }
+  if (normal_ok && a.Mg >= 32 && a.Mg < 64 && blocks(32, 256) >= 256 && make_plan(a, 32, 256, pl)) { pl.variant = 6; return true; }
   // too few tiles to fill the chip: split the reduction over ks blocks per tile (deterministic slabs + a
   // finishing pass), which also hides the DMA latency the few resident waves cannot
   if (nph == 1 && a.Mg >= 64) {
@@ -435,6 +437,7 @@ extern "C" int vcv_conv_dma(const VcvConvArgs* args, float* workspace, int flip,
     case 2: return launch<4, 1, 1, 7>(a, pl, workspace, st);
     case 3: return launch<2, 1, 1, 7>(a, pl, workspace, st);
     case 4: return launch<2, 2, 1, 4>(a, pl, workspace, st);
+    case 6: return launch<1, 2, 1, 4>(a, pl, workspace, st);
     default: return launch<1, 2, 2, 2>(a, pl, workspace, st);
   }
 }

@@ -306,11 +306,11 @@ class _ConvFn(torch.autograd.Function):
             raise RuntimeError("conv: out_act and res cannot be combined")
         kw = dict(bias=bias, res=res, in_tf=TF_LEAKY if in_leaky else TF_NONE, out_act=out_act,
                   slope=slope)
-        # Short sequences (the pooled scales of DiscriminatorS: 5..33 frames): one batch element cannot fill
+        # Short sequences (the last layers of DiscriminatorS and its pooled scales: 5..64 frames): one batch element cannot fill
         # a GEMM tile, so the batch is folded into the kernel's column dimension -- x[b,c,t] is viewed as one
         # "image" [1,C,T,B] (P = B columns) and the tile's N runs over (t, b) pairs.
         ctx.bt = (not transposed and x.dim() == 3 and groups == 1 and res is None and x.shape[0] > 1
-                  and x.shape[2] <= 40 and w.shape[0] >= 32 and w.shape[1] >= 32)
+                  and x.shape[2] <= 64 and w.shape[0] >= 32 and w.shape[1] >= 32)
         if transposed:
             y = convT_forward(x, w, stride=stride, pad=pad, **kw)
         elif ctx.bt:
