@@ -266,11 +266,11 @@ int vcv_slice_fwd(const float* x, const int64_t* ids, int mul, float* y, int B, 
 int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float* dx, int B, int C, int T, int S,
                   void* stream);
 
-/* ---- optional per-launch HIP-event timing of the two MFMA kernel families (bench.py roofline).
- * vcv_prof_begin arms a pool of `max_launches` event pairs; every vcv_conv_gemm / vcv_conv_wgrad
- * launch then records one pair on its own stream.  vcv_prof_end synchronises and fills
- * out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic flops}, cls 0 = conv_gemm,
- * 1 = conv_wgrad (ncls >= 2). ---- */
+/* ---- optional per-launch HIP-event timing of the MFMA kernel families (bench.py roofline).
+ * vcv_prof_begin arms a pool of `max_launches` event pairs; every vcv_conv_gemm / vcv_conv_dma /
+ * vcv_conv_wgrad launch then records one pair around its MFMA kernel on its own stream.  vcv_prof_end
+ * synchronises and fills out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic flops}, cls 0 =
+ * conv_gemm_kernel, 1 = conv_wgrad_kernel, 2 = conv_dma_kernel, 3 = wgrad_dma_kernel (ncls >= 4). ---- */
 int vcv_prof_begin(int max_launches);
 int vcv_prof_end(double* out, int ncls);
 /* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */

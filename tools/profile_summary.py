@@ -68,10 +68,10 @@ def main():
                                                                  (2 * v / c + wv / max(wc, 1)) * 1024 / 1e6))
     # machine-readable per-launch traffic of the dominant kernel for bench.py's roofline.traffic
     import json
-    if "FETCH_SIZE" in traffic and "conv_gemm_kernel" in traffic["FETCH_SIZE"]:
-        c, v = traffic["FETCH_SIZE"]["conv_gemm_kernel"]
-        wc, wv = traffic.get("WRITE_SIZE", {}).get("conv_gemm_kernel", [1, 0.0])
-        json.dump({"kernel": "conv_gemm_kernel", "launches_profiled": c,
+    if "FETCH_SIZE" in traffic and "conv_dma_kernel" in traffic["FETCH_SIZE"]:
+        c, v = traffic["FETCH_SIZE"]["conv_dma_kernel"]
+        wc, wv = traffic.get("WRITE_SIZE", {}).get("conv_dma_kernel", [1, 0.0])
+        json.dump({"kernel": "conv_dma_kernel", "launches_profiled": c,
                    "fetch_bytes_per_launch_raw": v / c * 1024, "fetch_bytes_per_launch_x2": 2 * v / c * 1024,
                    "write_bytes_per_launch": wv / max(wc, 1) * 1024,
                    "hbm_bytes_per_launch": (2 * v / c + wv / max(wc, 1)) * 1024,

@@ -15,8 +15,6 @@
 //     ds_write instructions;
 //   * the leaky-ReLU of the input (ResBlocks / generator stages) is applied to the B fragment as
 //     it is read from LDS (two VALU ops per fragment element).
-#include <cstdlib>
-
 #include "common.h"
 #include "prof.h"
 
@@ -309,7 +307,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
   if (bkc < 2) bkc = 2;
   const int cg_even = (a.Cg + 1) & ~1;
   if (bkc > cg_even) bkc = cg_even;
-  const size_t lds_cap = (size_t)(getenv("VCV_DMA_LDS_KB") ? atoi(getenv("VCV_DMA_LDS_KB")) : 78) * 1024;
+  const size_t lds_cap = 78 * 1024;  // two blocks per CU
   while (bkc > 2 && 2ull * ((size_t)bkc * g.JA * BM + (size_t)bkc * xw) * 4 > lds_cap) bkc -= 2;
   // weight slabs move as whole 1-KiB DMA instructions: nearest even channel count (down, else up) that fits
   {
@@ -401,14 +399,14 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
   dim3 grid(a.B * g.ntu * g.ks, g.nmt, g.phases), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
   const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
-  const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st, tag, 12);
+  const int slot = vcv_prof_start(VCV_PROF_CONV_DMA, flops, st, tag, 12);
   float* part = ws + pl.pack_floats;
   hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws, part);
+  vcv_prof_stop(slot, st);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
     hipLaunchKernelGGL(conv_dma_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, (const float*)part, g.ks);
   }
-  vcv_prof_stop(slot, st);
   return vcv_check_launch();
 }
 
