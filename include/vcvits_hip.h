@@ -157,6 +157,14 @@ int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C,
 int vcv_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, int R, int C, void* stream);
 int vcv_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv,
                         float* dg, int R, int C, void* stream);
+/* Batched form: one launch for all weight-normed layers of a module.  `items_dev` is a DEVICE array of
+ * n_items records of eight int64 {v ptr, g ptr, w offset (floats into wbuf), first row (index into the
+ * row-indexed norm / dg buffers), R, C, dw ptr (backward only), dv offset (floats into dvbuf)}, sorted by
+ * first row; total_rows = sum of R. */
+int vcv_weight_norm_many_fwd(const void* items_dev, int n_items, int total_rows, float* wbuf, float* norm,
+                             void* stream);
+int vcv_weight_norm_many_bwd(const void* items_dev, int n_items, int total_rows, const float* norm,
+                             float* dvbuf, float* dg, void* stream);
 
 /* wt[c, m, K-1-k] = w[m, c, k]: lets the stride-1 data gradient of a conv run as a forward conv */
 int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, void* stream);

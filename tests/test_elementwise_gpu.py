@@ -34,6 +34,35 @@ def test_weight_norm(gpu, shape):
     _cmp("dg", gg.grad, gr.grad)
 
 
+def test_weight_norm_many(gpu):
+    """One launch for a list of (v, g) pairs == torch._weight_norm per pair, forward and gradients; a second
+    call (cached descriptor table) with updated values follows the new values."""
+    from vcvits_amd import ops
+    shapes = [(32, 1, 5, 1), (1024, 1024, 5), (16, 1, 15), (512, 256, 16), (1, 1024, 3), (1024, 4, 41)]
+    gen = torch.Generator().manual_seed(11)
+    vs = [torch.randn(s, generator=gen) for s in shapes]
+    gs = [torch.rand((s[0],) + (1,) * (len(s) - 1), generator=gen) + 0.5 for s in shapes]
+    gws = [torch.randn(s, generator=gen) for s in shapes]
+    vg = [v.clone().to(gpu).requires_grad_(True) for v in vs]
+    gg = [g.clone().to(gpu).requires_grad_(True) for g in gs]
+    for rnd in range(2):
+        if rnd == 1:
+            with torch.no_grad():
+                for i in range(len(vs)):
+                    vs[i] = vs[i] * 0.5 + 0.1
+                    vg[i].copy_(vs[i])
+                    vg[i].grad = gg[i].grad = None
+        ws = ops.weight_norm_many(vg, gg)
+        torch.autograd.backward(list(ws), [t.to(gpu) for t in gws])
+        for i, s in enumerate(shapes):
+            vr, gr = vs[i].clone().requires_grad_(True), gs[i].clone().requires_grad_(True)
+            wr = torch._weight_norm(vr, gr, 0)
+            wr.backward(gws[i])
+            _cmp("w%d" % i, ws[i], wr.detach())
+            _cmp("dv%d" % i, vg[i].grad, vr.grad)
+            _cmp("dg%d" % i, gg[i].grad, gr.grad)
+
+
 def test_avg3_pad_pool(gpu):
     from vcvits_amd import ops
     gen = torch.Generator().manual_seed(2)

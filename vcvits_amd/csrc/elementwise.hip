@@ -56,6 +56,54 @@ weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v
   if (threadIdx.x == 0) dg[r] = s / nrm;
 }
 
+// ---- batched weight norm: one launch for every weight-normed layer of a module ------------------------
+// items[i] = {v ptr, g ptr, w offset (floats, into wbuf), first row (into the row-indexed norm / dg buffers),
+//             R, C, dw ptr (backward), dv offset (floats, into dvbuf)}; one workgroup per row of every tensor.
+struct WnItem { long long v, g, w_off, row0, R, C, dw, dv_off; };
+
+__device__ __forceinline__ int wn_find(const WnItem* __restrict__ items, int n, int row) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].row0 <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+weight_norm_many_fwd_kernel(const WnItem* __restrict__ items, int n, float* __restrict__ wbuf, float* __restrict__ norm) {
+  __shared__ float red[4];
+  const WnItem it = items[wn_find(items, n, blockIdx.x)];
+  const int r = blockIdx.x - (int)it.row0, C = (int)it.C;
+  const float* vr = (const float*)it.v + (size_t)r * C;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) { const float a = vr[i]; s += a * a; }
+  s = block_sum256(s, red);
+  const float nrm = sqrtf(s);
+  const float sc = ((const float*)it.g)[r] / nrm;
+  float* wr = wbuf + it.w_off + (size_t)r * C;
+  for (int i = threadIdx.x; i < C; i += 256) wr[i] = vr[i] * sc;
+  if (threadIdx.x == 0) norm[blockIdx.x] = nrm;
+}
+
+__global__ void __launch_bounds__(256)
+weight_norm_many_bwd_kernel(const WnItem* __restrict__ items, int n, const float* __restrict__ norm,
+                            float* __restrict__ dvbuf, float* __restrict__ dg) {
+  __shared__ float red[4];
+  const WnItem it = items[wn_find(items, n, blockIdx.x)];
+  const int r = blockIdx.x - (int)it.row0, C = (int)it.C;
+  const float* vr = (const float*)it.v + (size_t)r * C;
+  const float* dwr = (const float*)it.dw + (size_t)r * C;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) s += dwr[i] * vr[i];
+  s = block_sum256(s, red);
+  const float nrm = norm[blockIdx.x], gg = ((const float*)it.g)[r];
+  const float a = gg / nrm, bcoef = gg * s / (nrm * nrm * nrm);
+  float* dvr = dvbuf + it.dv_off + (size_t)r * C;
+  for (int i = threadIdx.x; i < C; i += 256) dvr[i] = a * dwr[i] - bcoef * vr[i];
+  if (threadIdx.x == 0) dg[blockIdx.x] = s / nrm;
+}
+
 // ---- small streaming ops --------------------------------------------------------------------
 __global__ void avg3_kernel(const float* __restrict__ a, const float* __restrict__ b,
                             const float* __restrict__ c, float* __restrict__ y, size_t n) {
@@ -214,6 +262,22 @@ extern "C" int vcv_weight_norm_bwd(const float* dw, const float* v, const float*
                                    float* dv, float* dg, int R, int C, void* stream) {
   if (!dw || !v || !g || !norm || !dv || !dg || R <= 0 || C <= 0) return VCV_EINVAL;
   hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(R), dim3(256), 0, ST, dw, v, g, norm, dv, dg, C);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_weight_norm_many_fwd(const void* items_dev, int n_items, int total_rows, float* wbuf, float* norm,
+                                        void* stream) {
+  if (!items_dev || !wbuf || !norm || n_items <= 0 || total_rows <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(weight_norm_many_fwd_kernel, dim3(total_rows), dim3(256), 0, ST, (const WnItem*)items_dev, n_items,
+                     wbuf, norm);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_weight_norm_many_bwd(const void* items_dev, int n_items, int total_rows, const float* norm,
+                                        float* dvbuf, float* dg, void* stream) {
+  if (!items_dev || !norm || !dvbuf || !dg || n_items <= 0 || total_rows <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(weight_norm_many_bwd_kernel, dim3(total_rows), dim3(256), 0, ST, (const WnItem*)items_dev, n_items,
+                     norm, dvbuf, dg);
   return vcv_check_launch();
 }
 

@@ -7,7 +7,7 @@ from torch import nn
 from ... import ops
 from ..._lib import ACT_LEAKY
 from ...commons import get_padding
-from ..modules import Conv, LRELU_SLOPE
+from ..modules import Conv, LRELU_SLOPE, prepare_weight_norm
 
 
 class DiscriminatorP(nn.Module):
@@ -24,6 +24,7 @@ class DiscriminatorP(nn.Module):
         self.conv_post = Conv(1024, 1, 3, padding=1, weight_norm=True, two_d=True)
 
     def forward(self, x):
+        prepare_weight_norm(self)
         fmap = []
         b, c, t = x.shape
         if t % self.period != 0:
@@ -51,6 +52,7 @@ class DiscriminatorS(nn.Module):
         self.conv_post = Conv(1024, 1, 3, padding=1, weight_norm=True)
 
     def forward(self, x):
+        prepare_weight_norm(self)
         fmap = []
         for l in self.convs:
             x = l(x, out_act=ACT_LEAKY, slope=LRELU_SLOPE)

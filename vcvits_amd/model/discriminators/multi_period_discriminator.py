@@ -1,9 +1,11 @@
 """vits/model/discriminators/multi_period_discriminator.py:9-31 (one DiscriminatorS + one
 DiscriminatorP per period)."""
+import os
 from typing import List
 
 from torch import nn
 
+from ..modules import prepare_weight_norm
 from ._pair import run_many
 from .discriminator import DiscriminatorP, DiscriminatorS
 
@@ -17,6 +19,10 @@ class MultiPeriodDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList(discs)
 
     def forward(self, y, y_hat, g=None):
+        if int(os.environ.get("VCVITS_STREAMS", "1")) <= 1:
+            prepare_weight_norm(self)  # one launch for every layer of every sub-discriminator
+            for d in self.discriminators:
+                d._wn_parent_prepared = True
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
         for y_d_r, y_d_g, fmap_r, fmap_g in run_many(self.discriminators, [(y, y_hat)] * len(self.discriminators)):
             y_d_rs.append(y_d_r)

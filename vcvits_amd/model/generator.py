@@ -38,6 +38,7 @@ class Generator(nn.Module):
             m.weight_v.data.normal_(0.0, 0.01)
 
     def forward(self, x, g=None):
+        modules.prepare_weight_norm(self)
         x = self.conv_pre(x)
         if g is not None:
             x = x + self.cond(g)

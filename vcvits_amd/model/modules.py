@@ -19,6 +19,37 @@ def _default_conv_init(weight, bias):
         nn.init.uniform_(bias, -bound, bound)
 
 
+def prepare_weight_norm(root, skip=()):
+    """Compute the effective weights of every weight-normed Conv / ConvT under `root` (minus the sub-modules
+    in `skip`) in one launch and hand them to the layers: each consumes its weight once, in its next forward;
+    a layer whose parameters were re-assigned in between recomputes its own.  Call at the top of a module's
+    forward.  A parent that prepares for its children marks them with `_wn_parent_prepared` so their own
+    call is a no-op for that forward."""
+    if root.__dict__.pop("_wn_parent_prepared", False):
+        return
+    key = "_wn_mods" if not skip else "_wn_mods_skip"
+    mods = root.__dict__.get(key)
+    if mods is None:
+        excluded = set()
+        for sm in skip:
+            excluded.update(id(m) for m in sm.modules())
+        mods = [m for m in root.modules() if isinstance(m, (Conv, ConvT)) and m.is_wn and id(m) not in excluded]
+        root.__dict__[key] = mods
+    if len(mods) < 2 or not mods[0].weight_v.is_cuda:
+        return
+    ws = ops.weight_norm_many([m.weight_v for m in mods], [m.weight_g for m in mods])
+    for m, w in zip(mods, ws):
+        m._w_pre = (w, m.weight_v._version, m.weight_g._version, m.weight_v.data_ptr())
+
+
+def _take_prepared(m):
+    pre = m.__dict__.pop("_w_pre", None)
+    if pre is not None and pre[1] == m.weight_v._version and pre[2] == m.weight_g._version \
+            and pre[3] == m.weight_v.data_ptr():
+        return pre[0]
+    return None
+
+
 class Conv(nn.Module):
     """Conv1d ([M, C/g, K]) or period Conv2d with a (K,1) kernel ([M, C/g, K, 1]).  With
     ``weight_norm=True`` the parameters are the old-style ``weight_g`` / ``weight_v`` pair of
@@ -45,7 +76,10 @@ class Conv(nn.Module):
             self.bias = nn.Parameter(b) if bias else None
 
     def effective_weight(self):
-        return ops.weight_norm(self.weight_v, self.weight_g) if self.is_wn else self.weight
+        if not self.is_wn:
+            return self.weight
+        w = _take_prepared(self)
+        return w if w is not None else ops.weight_norm(self.weight_v, self.weight_g)
 
     def forward(self, x, in_leaky=False, out_act=ACT_NONE, slope=LRELU_SLOPE, res=None, weight=None):
         w = self.effective_weight() if weight is None else weight
@@ -71,7 +105,10 @@ class ConvT(nn.Module):
             self.weight = nn.Parameter(w)
 
     def effective_weight(self):
-        return ops.weight_norm(self.weight_v, self.weight_g) if self.is_wn else self.weight
+        if not self.is_wn:
+            return self.weight
+        w = _take_prepared(self)
+        return w if w is not None else ops.weight_norm(self.weight_v, self.weight_g)
 
     def forward(self, x, in_leaky=False, slope=LRELU_SLOPE):
         return ops.conv_transpose1d(x, self.effective_weight(), self.bias, stride=self.stride,
@@ -114,6 +151,7 @@ class WN(nn.Module):
             self.res_skip_layers.append(Conv(hidden_channels, rs_ch, 1, weight_norm=True))
 
     def forward(self, x, x_mask, g=None, **kwargs):
+        prepare_weight_norm(self, skip=() if g is not None or not hasattr(self, "cond_layer") else (self.cond_layer,))
         mask2 = x_mask.reshape(x_mask.shape[0], x_mask.shape[-1])
         if g is not None:
             g = self.cond_layer(g)  # [B, 2H*L, 1]

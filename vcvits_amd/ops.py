@@ -427,6 +427,72 @@ def weight_norm(v, g):
     return _WeightNormFn.apply(v, g)
 
 
+_WN_TABLES = {}
+
+
+class _WeightNormManyFn(torch.autograd.Function):
+    """weight_norm of a list of (v, g) pairs in one launch (and one launch for all their gradients)."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        n = len(vg) // 2
+        vs, gs = vg[:n], vg[n:]
+        for t in vg:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("weight_norm_many: parameters must be contiguous fp32")
+        dev = vs[0].device
+        key = tuple(t.data_ptr() for t in vg)
+        ent = _WN_TABLES.get(key)
+        if ent is None:
+            import numpy as np
+            tab = np.zeros((n, 8), dtype=np.int64)
+            woff = row0 = 0
+            for i, (v, g) in enumerate(zip(vs, gs)):
+                R = v.shape[0]
+                C = v.numel() // R
+                tab[i] = (v.data_ptr(), g.data_ptr(), woff, row0, R, C, 0, woff)
+                woff += R * C
+                row0 += R
+            ent = (tab, torch.from_numpy(tab).to(dev), woff, row0)
+            if len(_WN_TABLES) > 256:
+                _WN_TABLES.clear()
+            _WN_TABLES[key] = ent
+        tab, tab_dev, total, rows = ent
+        wbuf = torch.empty((total,), device=dev, dtype=torch.float32)
+        norm = torch.empty((rows,), device=dev, dtype=torch.float32)
+        check(lib().vcv_weight_norm_many_fwd(ptr(tab_dev), n, rows, ptr(wbuf), ptr(norm), stream()),
+              "vcv_weight_norm_many_fwd")
+        ctx.n, ctx.tab, ctx.total, ctx.rows = n, tab, total, rows
+        ctx.shapes = [(v.shape, g.shape) for v, g in zip(vs, gs)]
+        ctx.save_for_backward(norm, *vg)  # keeps v / g alive; the table holds their addresses
+        return tuple(wbuf[int(tab[i, 2]):int(tab[i, 2]) + vs[i].numel()].view(vs[i].shape) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dws):
+        norm = ctx.saved_tensors[0]
+        n, dev = ctx.n, norm.device
+        dws = [_f32c(d) for d in dws]
+        tab = ctx.tab.copy()
+        for i, d in enumerate(dws):
+            tab[i, 6] = d.data_ptr()
+        tab_dev = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
+        dvbuf = torch.empty((ctx.total,), device=dev, dtype=torch.float32)
+        dg = torch.empty((ctx.rows,), device=dev, dtype=torch.float32)
+        check(lib().vcv_weight_norm_many_bwd(ptr(tab_dev), n, ctx.rows, ptr(norm), ptr(dvbuf), ptr(dg), stream()),
+              "vcv_weight_norm_many_bwd")
+        dvs, dgs = [], []
+        for i, (vsh, gsh) in enumerate(ctx.shapes):
+            o, r0, R, C = int(tab[i, 7]), int(tab[i, 3]), int(tab[i, 4]), int(tab[i, 5])
+            dvs.append(dvbuf[o:o + R * C].view(vsh))
+            dgs.append(dg[r0:r0 + R].view(gsh))
+        return tuple(dvs) + tuple(dgs)
+
+
+def weight_norm_many(vs, gs):
+    """[weight_norm(v, g) for v, g in zip(vs, gs)] in one launch."""
+    return _WeightNormManyFn.apply(*vs, *gs)
+
+
 # ---------------------------------------------------------------------------------------------
 # streaming helpers
 # ---------------------------------------------------------------------------------------------
