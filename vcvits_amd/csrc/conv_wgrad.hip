@@ -302,30 +302,57 @@ int launch_wgrad(const VcvWgradArgs& a, hipStream_t st, bool allow_sync = false)
   return launch_wgrad_bu<TM, TN, WM, WN, 32>(a, st, allow_sync);
 }
 
+__device__ __forceinline__ float bias_term(float v, float y, int tf, float slope) {
+  if (tf == VCV_TF_DLEAKY) return v * vcv_dleaky(y, slope);
+  if (tf == VCV_TF_DRELU) return y > 0.f ? v : 0.f;
+  if (tf == VCV_TF_DTANH) return v * (1.f - y * y);
+  return v;
+}
+
+// db[c] += sum over (b, t) of dy[b, c, t] (optionally times the activation derivative at aux).  Work units are
+// 1024-float pieces of the contiguous (b, c) rows; VEC = rows are 16-byte aligned (T % 4 == 0).
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ db,
                  int B, int C, int T, int tf, float slope, int nseg) {
   const int c = blockIdx.x, seg = blockIdx.y;
-  const long long total = (long long)B * T;
-  const long long per = (total + nseg - 1) / nseg;
-  const long long lo = seg * per;
-  long long hi = lo + per;
-  if (hi > total) hi = total;
+  const int nchunk = (T + 1023) >> 10;
+  const int units = B * nchunk;
+  const int per = (units + nseg - 1) / nseg;
+  const int lo = seg * per;
+  const int hi = lo + per < units ? lo + per : units;
   float s = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const long long b = i / T, t = i - b * T;
-    const size_t idx = ((size_t)b * C + c) * T + t;
-    float v = dy[idx];
-    if (tf == VCV_TF_DLEAKY) v *= vcv_dleaky(aux[idx], slope);
-    else if (tf == VCV_TF_DRELU) v = aux[idx] > 0.f ? v : 0.f;
-    else if (tf == VCV_TF_DTANH) v *= 1.f - aux[idx] * aux[idx];
-    s += v;
+  for (int unit = lo; unit < hi; ++unit) {
+    const int b = unit / nchunk, ch = unit - b * nchunk;
+    const size_t row = ((size_t)b * C + c) * (size_t)T;
+    if (VEC) {
+      const int t = (ch << 10) + threadIdx.x * 4;
+      if (t < T) {
+        const float4 v = *reinterpret_cast<const float4*>(dy + row + t);
+        if (tf >= VCV_TF_DLEAKY) {
+          const float4 y = *reinterpret_cast<const float4*>(aux + row + t);
+          s += bias_term(v.x, y.x, tf, slope) + bias_term(v.y, y.y, tf, slope) + bias_term(v.z, y.z, tf, slope) +
+               bias_term(v.w, y.w, tf, slope);
+        } else {
+          s += (v.x + v.y) + (v.z + v.w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = (ch << 10) + k * 256 + threadIdx.x;
+        if (t < T) s += bias_term(dy[row + t], tf >= VCV_TF_DLEAKY ? aux[row + t] : 0.f, tf, slope);
+      }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(db + c, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const float r = red[0] + red[1] + red[2] + red[3];
+    if (nseg == 1) db[c] = r; else unsafeAtomicAdd(db + c, r);
+  }
 }
 
 }  // namespace
@@ -375,12 +402,17 @@ extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, in
   if (!dy || !dbias || B <= 0 || C <= 0 || T <= 0) return VCV_EINVAL;
   if (tf >= VCV_TF_DLEAKY && !aux) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
-  const long long total = (long long)B * T;
-  int nseg = (int)((total + 16383) / 16384);
+  // enough workgroups to fill the chip, each with at least ~8 pieces of 1024 floats
+  const long long units = (long long)B * ((T + 1023) / 1024);
+  long long nseg = (1024 + C - 1) / C;
+  if (nseg > units / 8) nseg = units / 8;
   if (nseg < 1) nseg = 1;
-  if (nseg > 64) nseg = 64;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,
-                     slope, nseg);
+  if (nseg > 1 && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
+  if (T % 4 == 0)
+    hipLaunchKernelGGL(bias_grad_kernel<true>, dim3(C, (unsigned)nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,
+                       slope, (int)nseg);
+  else
+    hipLaunchKernelGGL(bias_grad_kernel<false>, dim3(C, (unsigned)nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,
+                       slope, (int)nseg);
   return vcv_check_launch();
 }
