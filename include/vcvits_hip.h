@@ -148,9 +148,10 @@ int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, floa
 int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg, int Tin,
                         int Tout, int dtf, float slope, void* stream);
 
-/* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites).  dy: [B, C, T] (T = Tout*P) */
-int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T,
-                  int tf, float slope, void* stream);
+/* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites, or adds onto dbias when `accumulate`).
+ * dy: [B, C, T] (T = Tout*P) */
+int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T, int tf, float slope,
+                  int accumulate, void* stream);
 
 /* ---- weight norm: torch.nn.utils.weight_norm(dim=0) at modules.py:126,132,143,190-201 and
  * discriminator.py:16-25,52-61.  v,w: [R, C] rows; g, norm: [R] ---- */
@@ -158,13 +159,13 @@ int vcv_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, i
 int vcv_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv,
                         float* dg, int R, int C, void* stream);
 /* Batched form: one launch for all weight-normed layers of a module.  `items_dev` is a DEVICE array of
- * n_items records of eight int64 {v ptr, g ptr, w offset (floats into wbuf), first row (index into the
- * row-indexed norm / dg buffers), R, C, dw ptr (backward only), dv offset (floats into dvbuf)}, sorted by
- * first row; total_rows = sum of R. */
+ * n_items records of ten int64 {v ptr, g ptr, w offset (floats into wbuf), first row (index into the
+ * row-indexed norm buffer), R, C, dw ptr, dv ptr, dg ptr, accumulate}, sorted by first row; total_rows =
+ * sum of R.  Backward writes dv / dg of every record through its own pointers, adding onto the existing
+ * values where `accumulate` is set (gradient buffers of an optimizer). */
 int vcv_weight_norm_many_fwd(const void* items_dev, int n_items, int total_rows, float* wbuf, float* norm,
                              void* stream);
-int vcv_weight_norm_many_bwd(const void* items_dev, int n_items, int total_rows, const float* norm,
-                             float* dvbuf, float* dg, void* stream);
+int vcv_weight_norm_many_bwd(const void* items_dev, int n_items, int total_rows, const float* norm, void* stream);
 
 /* wt[c, m, K-1-k] = w[m, c, k]: lets the stride-1 data gradient of a conv run as a forward conv */
 int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, void* stream);

@@ -87,3 +87,62 @@ def test_full_vcvits_batch(gpu):
     batch["ids_slice"] = torch.tensor([3, 11])
     batch["sid"] = batch["sid"] % 8
     _run(module, trainer, batch, gpu)
+
+
+def test_vocoder_gan_batch_without_grad_sinks(gpu, monkeypatch):
+    """The autograd-accumulation path (VCVITS_GRAD_SINK=0: kernels hand temporaries to autograd instead of
+    adding into the optimizer's flat gradient buffer) gives the same gradients."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import ops, synthetic
+    from vcvits_amd.light.vcvits import VocoderGAN
+    monkeypatch.setenv("VCVITS_GRAD_SINK", "0")
+    ops.clear_grad_sinks()
+    torch.manual_seed(0)
+    cfg = small_cfg()
+    module = VocoderGAN(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, [2, 3], vocoder_only=True)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    assert not ops._GRAD_SINKS
+    _run(module, trainer, synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3), gpu)
+
+
+def test_vocoder_gan_batch_ddp_buckets_single_rank(gpu, monkeypatch):
+    """Bucketed all-reduce machinery on (a 1-rank RCCL group): every bucket must see all of its parameters
+    reported ready -- by autograd hooks or by the gradient sinks' notify -- exactly once per backward pass, and
+    the averaged gradients equal the plain ones."""
+    import torch.distributed as dist
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import synthetic
+    from vcvits_amd.light.vcvits import VocoderGAN
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    monkeypatch.setenv("VCVITS_FORCE_DDP", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(0)
+        cfg = small_cfg()
+        module = VocoderGAN(**cfg)
+        trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, [2, 3], vocoder_only=True)
+        module = module.to(gpu)
+        opts = module.configure_optimizers()
+        assert opts and all(o._ddp for o in (module.optim_g, module.optim_d))
+        counts = []
+        for o in (module.optim_g, module.optim_d):
+            orig = o._launch_bucket
+
+            def wrapped(b, _orig=orig, _o=o):
+                counts.append((id(_o), b["lo"], b["ready"], b["n"]))
+                return _orig(b)
+            o._launch_bucket = wrapped
+        _run(module, trainer, synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3), gpu)
+        # ready never exceeds the bucket's parameter count (a parameter reported twice would launch the
+        # all-reduce before its last contribution), most buckets complete from the backward pass itself, and
+        # no bucket is reduced twice
+        assert counts and all(r <= n for _, _, r, n in counts), counts
+        assert sum(r == n for _, _, r, n in counts) >= len(counts) - 2, counts
+        assert len(set((i, lo) for i, lo, _, _ in counts)) == len(counts), "a bucket was reduced twice"
+    finally:
+        dist.destroy_process_group()

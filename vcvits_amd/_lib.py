@@ -89,7 +89,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _ARGTYPES = {
     "vcv_conv_gemm": [ctypes.POINTER(VcvConvArgs), _P],
     "vcv_conv_wgrad": [ctypes.POINTER(VcvWgradArgs), _P],
-    "vcv_bias_grad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vcv_bias_grad": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "vcv_weight_norm_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "vcv_weight_norm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vcv_avg3": [_P, _P, _P, _P, _L, _P],
@@ -134,7 +134,7 @@ _ARGTYPES = {
     "vcv_stft_complex_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vcv_istft": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vcv_weight_norm_many_fwd": [_P, _I, _I, _P, _P, _P],
-    "vcv_weight_norm_many_bwd": [_P, _I, _I, _P, _P, _P, _P],
+    "vcv_weight_norm_many_bwd": [_P, _I, _I, _P, _P],
     "vcv_conv_dma_workspace": [ctypes.POINTER(VcvConvArgs)],
     "vcv_conv_dma": [ctypes.POINTER(VcvConvArgs), _P, _I, _P],
     "vcv_prof_begin": [_I],

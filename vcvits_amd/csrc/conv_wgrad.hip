@@ -314,7 +314,7 @@ __device__ __forceinline__ float bias_term(float v, float y, int tf, float slope
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ db,
-                 int B, int C, int T, int tf, float slope, int nseg) {
+                 int B, int C, int T, int tf, float slope, int nseg, int acc) {
   const int c = blockIdx.x, seg = blockIdx.y;
   const int nchunk = (T + 1023) >> 10;
   const int units = B * nchunk;
@@ -351,7 +351,7 @@ bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ aux, fl
   __syncthreads();
   if (threadIdx.x == 0) {
     const float r = red[0] + red[1] + red[2] + red[3];
-    if (nseg == 1) db[c] = r; else unsafeAtomicAdd(db + c, r);
+    if (nseg == 1 && !acc) db[c] = r; else unsafeAtomicAdd(db + c, r);
   }
 }
 
@@ -398,7 +398,7 @@ extern "C" int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream) {
 }
 
 extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, int B, int C, int T,
-                             int tf, float slope, void* stream) {
+                             int tf, float slope, int accumulate, void* stream) {
   if (!dy || !dbias || B <= 0 || C <= 0 || T <= 0) return VCV_EINVAL;
   if (tf >= VCV_TF_DLEAKY && !aux) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -407,12 +407,12 @@ extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, in
   long long nseg = (1024 + C - 1) / C;
   if (nseg > units / 8) nseg = units / 8;
   if (nseg < 1) nseg = 1;
-  if (nseg > 1 && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
+  if (nseg > 1 && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
   if (T % 4 == 0)
     hipLaunchKernelGGL(bias_grad_kernel<true>, dim3(C, (unsigned)nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,
-                       slope, (int)nseg);
+                       slope, (int)nseg, accumulate);
   else
     hipLaunchKernelGGL(bias_grad_kernel<false>, dim3(C, (unsigned)nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,
-                       slope, (int)nseg);
+                       slope, (int)nseg, accumulate);
   return vcv_check_launch();
 }

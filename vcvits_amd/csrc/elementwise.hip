@@ -57,9 +57,10 @@ weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v
 }
 
 // ---- batched weight norm: one launch for every weight-normed layer of a module ------------------------
-// items[i] = {v ptr, g ptr, w offset (floats, into wbuf), first row (into the row-indexed norm / dg buffers),
-//             R, C, dw ptr (backward), dv offset (floats, into dvbuf)}; one workgroup per row of every tensor.
-struct WnItem { long long v, g, w_off, row0, R, C, dw, dv_off; };
+// items[i] = {v ptr, g ptr, w offset (floats, into wbuf), first row (into the row-indexed norm buffer), R, C,
+//             dw ptr, dv ptr, dg ptr, accumulate (backward: dv / dg are written, or added onto when set)};
+// one workgroup per row of every tensor.
+struct WnItem { long long v, g, w_off, row0, R, C, dw, dv, dg, acc; };
 
 __device__ __forceinline__ int wn_find(const WnItem* __restrict__ items, int n, int row) {
   int lo = 0, hi = n - 1;
@@ -87,8 +88,7 @@ weight_norm_many_fwd_kernel(const WnItem* __restrict__ items, int n, float* __re
 }
 
 __global__ void __launch_bounds__(256)
-weight_norm_many_bwd_kernel(const WnItem* __restrict__ items, int n, const float* __restrict__ norm,
-                            float* __restrict__ dvbuf, float* __restrict__ dg) {
+weight_norm_many_bwd_kernel(const WnItem* __restrict__ items, int n, const float* __restrict__ norm) {
   __shared__ float red[4];
   const WnItem it = items[wn_find(items, n, blockIdx.x)];
   const int r = blockIdx.x - (int)it.row0, C = (int)it.C;
@@ -99,9 +99,15 @@ weight_norm_many_bwd_kernel(const WnItem* __restrict__ items, int n, const float
   s = block_sum256(s, red);
   const float nrm = norm[blockIdx.x], gg = ((const float*)it.g)[r];
   const float a = gg / nrm, bcoef = gg * s / (nrm * nrm * nrm);
-  float* dvr = dvbuf + it.dv_off + (size_t)r * C;
-  for (int i = threadIdx.x; i < C; i += 256) dvr[i] = a * dwr[i] - bcoef * vr[i];
-  if (threadIdx.x == 0) dg[blockIdx.x] = s / nrm;
+  float* dvr = (float*)it.dv + (size_t)r * C;
+  float* dgp = (float*)it.dg + r;
+  if (it.acc) {
+    for (int i = threadIdx.x; i < C; i += 256) dvr[i] += a * dwr[i] - bcoef * vr[i];
+    if (threadIdx.x == 0) *dgp += s / nrm;
+  } else {
+    for (int i = threadIdx.x; i < C; i += 256) dvr[i] = a * dwr[i] - bcoef * vr[i];
+    if (threadIdx.x == 0) *dgp = s / nrm;
+  }
 }
 
 // ---- small streaming ops --------------------------------------------------------------------
@@ -274,10 +280,10 @@ extern "C" int vcv_weight_norm_many_fwd(const void* items_dev, int n_items, int 
 }
 
 extern "C" int vcv_weight_norm_many_bwd(const void* items_dev, int n_items, int total_rows, const float* norm,
-                                        float* dvbuf, float* dg, void* stream) {
-  if (!items_dev || !norm || !dvbuf || !dg || n_items <= 0 || total_rows <= 0) return VCV_EINVAL;
+                                        void* stream) {
+  if (!items_dev || !norm || n_items <= 0 || total_rows <= 0) return VCV_EINVAL;
   hipLaunchKernelGGL(weight_norm_many_bwd_kernel, dim3(total_rows), dim3(256), 0, ST, (const WnItem*)items_dev, n_items,
-                     norm, dvbuf, dg);
+                     norm);
   return vcv_check_launch();
 }
 

@@ -54,6 +54,7 @@ class FlatAdamW:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self._works = []
         self._buckets = []
+        self._synced = False
         # VCVITS_FORCE_DDP=1 keeps the bucket hooks / collectives active in a 1-rank group (used to exercise
         # the RCCL path on a single-GPU box)
         import os
@@ -62,6 +63,13 @@ class FlatAdamW:
             self._make_buckets(int(bucket_mb * 1024 * 1024 / 4))
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
+        # gradient sinks: the conv / weight-norm backward kernels add parameter gradients straight into the
+        # flat buffer (ops.register_grad_sink) instead of handing autograd a temporary to accumulate.  The
+        # backward then returns None for the parameter; autograd still evaluates its AccumulateGrad node (no
+        # kernel) and fires the post-accumulate hook above, after the producing kernel was enqueued.
+        if dev.type == "cuda" and os.environ.get("VCVITS_GRAD_SINK", "1") == "1":
+            for p in self.params:
+                ops.register_grad_sink(p, p.grad)
 
     # -- gradient buckets ------------------------------------------------------------------------
     def _make_buckets(self, cap):
@@ -98,8 +106,9 @@ class FlatAdamW:
     def finish_grad_sync(self):
         """Wait for the bucket all-reduces of this backward pass (buckets whose parameters got no
         gradient in this pass are reduced here so every rank stays in step)."""
-        if not self._ddp:
+        if not self._ddp or self._synced:
             return
+        self._synced = True  # once per backward pass (zero_grad re-arms it)
         for b in self._buckets:
             if b["ready"] != b["n"]:
                 self._launch_bucket(b)
@@ -113,6 +122,7 @@ class FlatAdamW:
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()
+        self._synced = False
         for b in self._buckets:
             b["ready"] = 0
 

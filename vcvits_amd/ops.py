@@ -251,11 +251,14 @@ def convT_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, a_tf=TF_NONE, aaux=No
     return out
 
 
-def bias_grad(dy, aux=None, tf=TF_NONE, slope=0.1):
+def bias_grad(dy, aux=None, tf=TF_NONE, slope=0.1, out=None):
+    """Per-channel sum of tf(dy); with `out` the sums are ADDED onto it."""
     B, C = dy.shape[0], dy.shape[1]
     T = dy.numel() // (B * C)
-    out = torch.empty((C,), device=dy.device, dtype=torch.float32)
-    check(lib().vcv_bias_grad(ptr(dy), ptr(aux), ptr(out), B, C, T, tf, ctypes.c_float(slope),
+    acc = 0 if out is None else 1
+    if out is None:
+        out = torch.empty((C,), device=dy.device, dtype=torch.float32)
+    check(lib().vcv_bias_grad(ptr(dy), ptr(aux), ptr(out), B, C, T, tf, ctypes.c_float(slope), acc,
                               stream()), "vcv_bias_grad")
     return out
 
@@ -264,6 +267,38 @@ def bias_grad(dy, aux=None, tf=TF_NONE, slope=0.1):
 # autograd
 # ---------------------------------------------------------------------------------------------
 _GRAD_B0 = [0]
+
+# Gradient sinks: an optimizer that owns a flat gradient buffer registers, per parameter, the view its
+# gradient lives in.  The backward of the ops below then adds a leaf parameter's gradient straight into that
+# view from the producing kernel and returns None to autograd -- no temporary, no accumulation launch.
+# (autograd still fires the parameter's post-accumulate hooks for a None gradient, so the data-parallel
+# bucket accounting needs nothing extra; `notify` is for owners that do not use those hooks.)
+_GRAD_SINKS = {}
+
+
+def register_grad_sink(param, grad_view, notify=None):
+    import weakref
+    _GRAD_SINKS[param.data_ptr()] = (grad_view, notify, weakref.ref(param))
+
+
+def clear_grad_sinks():
+    _GRAD_SINKS.clear()
+
+
+def _sunk(sink, grad):
+    """After a kernel added `grad` into its sink: run the notify and hand autograd nothing."""
+    if sink is None:
+        return grad
+    if sink[1] is not None:
+        sink[1]()
+    return None
+
+
+def _sink(t):
+    if not _GRAD_SINKS or t is None or not t.requires_grad or not t.is_leaf:
+        return None
+    e = _GRAD_SINKS.get(t.data_ptr())
+    return e if e is not None and e[2]() is t else None  # identity: a recycled address is not the parameter
 
 
 class grad_batch_start:
@@ -322,6 +357,7 @@ class _ConvFn(torch.autograd.Function):
             y = conv_forward(x, w3, stride=stride, pad=pad, dil=dil, groups=groups, **kw)
         ctx.cfg = (stride, pad, dil, groups, in_leaky, out_act, slope, transposed)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        ctx.w_sink, ctx.b_sink = _sink(w), _sink(bias)
         ctx.b0 = _GRAD_B0[0] if not (w.requires_grad or (bias is not None and bias.requires_grad)) else 0
         ctx.save_for_backward(x, w, y if out_act != ACT_NONE else None)
         return y
@@ -350,10 +386,12 @@ class _ConvFn(torch.autograd.Function):
                     kw.update(out_tf=TF_DLEAKY, oaux=x)
                 dx = _from_bt(conv_dgrad(dyt, w3, x.shape, stride=stride, pad=pad, dil=dil, groups=groups, **kw))
             if ctx.needs_input_grad[1]:
+                wout = ctx.w_sink[0].view(w3.shape) if ctx.w_sink is not None else None
                 dw = conv_wgrad(dyt, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
-                                b_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope).view(w.shape)
+                                b_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope, out=wout).view(w.shape)
+                dw = _sunk(ctx.w_sink, dw)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = bias_grad(dy, slope=slope)
+                db = _sunk(ctx.b_sink, bias_grad(dy, slope=slope, out=ctx.b_sink[0] if ctx.b_sink is not None else None))
             return dx, dw, db, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             b0 = ctx.b0 if 0 < ctx.b0 < x.shape[0] else 0
@@ -369,15 +407,17 @@ class _ConvFn(torch.autograd.Function):
                 conv_dgrad(dys, w3, xs.shape, stride=stride, pad=pad, dil=dil, groups=groups, out=dxs, **kw)
         if ctx.needs_input_grad[1]:
             b_tf = TF_LEAKY if in_leaky else TF_NONE
+            wout = ctx.w_sink[0].view(w3.shape) if ctx.w_sink is not None else None
             if transposed:
                 dw = convT_wgrad(dy, x, w3.shape, stride=stride, pad=pad, a_tf=b_tf, b_tf=dtf,
-                                 baux=y, slope=slope)
+                                 baux=y, slope=slope, out=wout)
             else:
                 dw = conv_wgrad(dy, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
-                                a_tf=dtf, aaux=y, b_tf=b_tf, slope=slope)
-            dw = dw.view(w.shape)
+                                a_tf=dtf, aaux=y, b_tf=b_tf, slope=slope, out=wout)
+            dw = _sunk(ctx.w_sink, dw.view(w.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = bias_grad(dy, aux=y, tf=dtf, slope=slope)
+            db = _sunk(ctx.b_sink, bias_grad(dy, aux=y, tf=dtf, slope=slope,
+                                             out=ctx.b_sink[0] if ctx.b_sink is not None else None))
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
@@ -445,12 +485,12 @@ class _WeightNormManyFn(torch.autograd.Function):
         ent = _WN_TABLES.get(key)
         if ent is None:
             import numpy as np
-            tab = np.zeros((n, 8), dtype=np.int64)
+            tab = np.zeros((n, 10), dtype=np.int64)
             woff = row0 = 0
             for i, (v, g) in enumerate(zip(vs, gs)):
                 R = v.shape[0]
                 C = v.numel() // R
-                tab[i] = (v.data_ptr(), g.data_ptr(), woff, row0, R, C, 0, woff)
+                tab[i, :6] = (v.data_ptr(), g.data_ptr(), woff, row0, R, C)
                 woff += R * C
                 row0 += R
             ent = (tab, torch.from_numpy(tab).to(dev), woff, row0)
@@ -464,6 +504,7 @@ class _WeightNormManyFn(torch.autograd.Function):
               "vcv_weight_norm_many_fwd")
         ctx.n, ctx.tab, ctx.total, ctx.rows = n, tab, total, rows
         ctx.shapes = [(v.shape, g.shape) for v, g in zip(vs, gs)]
+        ctx.sinks = [(_sink(v), _sink(g)) for v, g in zip(vs, gs)]
         ctx.save_for_backward(norm, *vg)  # keeps v / g alive; the table holds their addresses
         return tuple(wbuf[int(tab[i, 2]):int(tab[i, 2]) + vs[i].numel()].view(vs[i].shape) for i in range(n))
 
@@ -473,18 +514,33 @@ class _WeightNormManyFn(torch.autograd.Function):
         n, dev = ctx.n, norm.device
         dws = [_f32c(d) for d in dws]
         tab = ctx.tab.copy()
+        loose = [i for i in range(n) if ctx.sinks[i][0] is None or ctx.sinks[i][1] is None]
+        dvbuf = dg = None
+        if loose:
+            dvbuf = torch.empty((sum(int(tab[i, 4] * tab[i, 5]) for i in loose),), device=dev, dtype=torch.float32)
+            dg = torch.empty((sum(int(tab[i, 4]) for i in loose),), device=dev, dtype=torch.float32)
+        dvs, dgs = [None] * n, [None] * n
+        o = r0 = 0
         for i, d in enumerate(dws):
+            R, C = int(tab[i, 4]), int(tab[i, 5])
             tab[i, 6] = d.data_ptr()
+            sv, sg = ctx.sinks[i]
+            if sv is not None and sg is not None:
+                tab[i, 7], tab[i, 8], tab[i, 9] = sv[0].data_ptr(), sg[0].data_ptr(), 1
+            else:
+                vsh, gsh = ctx.shapes[i]
+                dvs[i], dgs[i] = dvbuf[o:o + R * C].view(vsh), dg[r0:r0 + R].view(gsh)
+                tab[i, 7], tab[i, 8], tab[i, 9] = dvs[i].data_ptr(), dgs[i].data_ptr(), 0
+                o += R * C
+                r0 += R
         tab_dev = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
-        dvbuf = torch.empty((ctx.total,), device=dev, dtype=torch.float32)
-        dg = torch.empty((ctx.rows,), device=dev, dtype=torch.float32)
-        check(lib().vcv_weight_norm_many_bwd(ptr(tab_dev), n, ctx.rows, ptr(norm), ptr(dvbuf), ptr(dg), stream()),
+        check(lib().vcv_weight_norm_many_bwd(ptr(tab_dev), n, ctx.rows, ptr(norm), stream()),
               "vcv_weight_norm_many_bwd")
-        dvs, dgs = [], []
-        for i, (vsh, gsh) in enumerate(ctx.shapes):
-            o, r0, R, C = int(tab[i, 7]), int(tab[i, 3]), int(tab[i, 4]), int(tab[i, 5])
-            dvs.append(dvbuf[o:o + R * C].view(vsh))
-            dgs.append(dg[r0:r0 + R].view(gsh))
+        for sv, sg in ctx.sinks:
+            if sv is not None and sg is not None:
+                for e in (sv, sg):
+                    if e[1] is not None:
+                        e[1]()
         return tuple(dvs) + tuple(dgs)
 
 
