@@ -98,6 +98,14 @@ int vcv_conv_gemm(const VcvConvArgs* args, void* stream);
  */
 int64_t vcv_conv_dma_workspace(const VcvConvArgs* args);
 int vcv_conv_dma(const VcvConvArgs* args, float* workspace, int flip, void* stream);
+/* Split form for callers that keep packed weights across launches (the discriminator weights are the same
+ * in the generator step and the discriminator step of one batch).  vcv_conv_dma_plan: out[0] = floats of the
+ * packed-weight buffer, out[1] = floats of per-launch scratch, out[2] = signature of the pack layout; a packed
+ * buffer may be reused by a later launch over the same unchanged weights with the same out[0] and out[2].
+ * vcv_conv_dma_run: as vcv_conv_dma with the two buffers separate; pack_valid != 0 skips the pack pass. */
+int vcv_conv_dma_plan(const VcvConvArgs* args, int flip, int64_t* out);
+int vcv_conv_dma_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
+                     void* stream);
 
 /*
  * Weight gradient of the same family (torch autograd of the call sites above):

@@ -253,3 +253,42 @@ def test_generator_vs_oracle(gpu):
     close("dx", xg.grad, xc.grad)
     for n, p in gen.named_parameters():
         close("d" + n, p.grad, sdo["g." + n].grad, tol=2e-4)
+
+
+def test_weight_cache_follows_parameter_changes(gpu):
+    """Cached weight-norm results / packed weights are dropped when a parameter changes in place (torch version
+    counter) or through an optimizer's raw-pointer update (ops.invalidate_weights)."""
+    from vcvits_amd import ops
+    from vcvits_amd.model.discriminators.discriminator import DiscriminatorP
+    torch.manual_seed(5)
+    d = DiscriminatorP(3).to(gpu)
+    x = torch.randn(2, 1, 3000, device=gpu)
+    with torch.no_grad():
+        y0, _ = d(x)
+        y0b, _ = d(x)                       # served from the cache
+        assert torch.equal(y0, y0b)
+        d.convs[3].weight_g.mul_(1.5)       # version bump
+        y1, _ = d(x)
+        ops._WN_CACHE_ON[0] = False
+        try:
+            y1_ref, _ = d(x)
+        finally:
+            ops._WN_CACHE_ON[0] = True
+        assert torch.equal(y1, y1_ref) and not torch.equal(y1, y0)
+        # raw-pointer style update: same tensor objects and versions, new contents
+        v = d.convs[2].weight_v
+        tmp = (v.detach() * 0.5)
+        # an alias on the same storage does not share v's version counter (as a kernel writing through a raw
+        # pointer does not)
+        alias = torch.empty(0, device=gpu).set_(v.untyped_storage(), v.storage_offset(), v.shape, v.stride())
+        ver = v._version
+        alias.copy_(tmp)
+        assert v._version == ver
+        ops.invalidate_weights(v.data_ptr(), v.data_ptr() + 4 * v.numel())
+        y2, _ = d(x)
+        ops._WN_CACHE_ON[0] = False
+        try:
+            y2_ref, _ = d(x)
+        finally:
+            ops._WN_CACHE_ON[0] = True
+        assert torch.equal(y2, y2_ref) and not torch.equal(y2, y1)

@@ -81,7 +81,7 @@ EXPORTS = [
     "vcv_layernorm_c_bwd", "vcv_rel_softmax_fwd", "vcv_rel_value_fwd", "vcv_rel_softmax_bwd",
     "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
     "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
-    "vcv_act_grad", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_dgrad", "vcv_grouped41_wgrad",
+    "vcv_act_grad", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_dgrad", "vcv_grouped41_wgrad",
 ]
 
 
@@ -137,6 +137,8 @@ _ARGTYPES = {
     "vcv_weight_norm_many_bwd": [_P, _I, _I, _P, _P],
     "vcv_conv_dma_workspace": [ctypes.POINTER(VcvConvArgs)],
     "vcv_conv_dma": [ctypes.POINTER(VcvConvArgs), _P, _I, _P],
+    "vcv_conv_dma_plan": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(ctypes.c_int64)],
+    "vcv_conv_dma_run": [ctypes.POINTER(VcvConvArgs), _P, _P, _I, _I, _P],
     "vcv_prof_begin": [_I],
     "vcv_prof_end": [ctypes.POINTER(ctypes.c_double), _I],
     "vcv_prof_dump": [ctypes.c_char_p],

@@ -378,7 +378,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
 }
 
 template <int TM, int TN, int WM, int WN>
-int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
+int launch(const VcvConvArgs& a, const Plan& pl, float* ws, float* part, bool pack_valid, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, NT = 64 * WM * WN;
   const DmaGeom& g = pl.g;
   // pack (forward orientation; the data-gradient orientation is packed by the caller through flip)
@@ -387,8 +387,9 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
   if (plds > 64 * 1024 && hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
     return VCV_EHIP;
   const int flip = g.phases > 1 ? (g.phases << 8) : (a.accumulate >> 8);
-  hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt, g.phases), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR,
-                     g.nch, flip);
+  if (!pack_valid)
+    hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt, g.phases), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR,
+                       g.nch, flip);
   void (*kern)(const VcvConvArgs, const DmaGeom, const float*, float*) =
       a.in_tf == VCV_TF_LEAKY ? conv_dma_kernel<TM, TN, WM, WN, true> : conv_dma_kernel<TM, TN, WM, WN, false>;
   if (pl.lds_bytes > 64 * 1024 &&
@@ -400,7 +401,6 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, hipStream_t st) {
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
   const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
   const int slot = vcv_prof_start(VCV_PROF_CONV_DMA, flops, st, tag, 12);
-  float* part = ws + pl.pack_floats;
   hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws, part);
   vcv_prof_stop(slot, st);
   if (g.ks > 1) {
@@ -420,22 +420,53 @@ extern "C" int64_t vcv_conv_dma_workspace(const VcvConvArgs* args) {
   return (int64_t)pl.ws_floats;
 }
 
+namespace {
+int run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, bool pack_valid, void* stream) {
+  if (!args || !pack_ws || !eligible(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose(*args, pl)) return VCV_EINVAL;
+  if (pl.g.ks > 1 && !scratch_ws) return VCV_EINVAL;
+  VcvConvArgs a = *args;
+  a.accumulate = (a.accumulate & 1) | (flip ? 256 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  switch (pl.variant) {
+    case 0: return launch<2, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 1: return launch<2, 2, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 2: return launch<4, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 3: return launch<2, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 4: return launch<2, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 6: return launch<1, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    default: return launch<1, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+  }
+}
+}  // namespace
+
 // `flip`: 0 = w is [M, C, K] (forward); 1 = w is [C, M, K] and the launch is the stride-1 data gradient
 // (the pack applies the flip / transpose, so no separate vcv_weight_flip_transpose pass is needed).
 extern "C" int vcv_conv_dma(const VcvConvArgs* args, float* workspace, int flip, void* stream) {
   if (!args || !workspace || !eligible(*args)) return VCV_EINVAL;
   Plan pl;
   if (!choose(*args, pl)) return VCV_EINVAL;
-  VcvConvArgs a = *args;
-  a.accumulate = (a.accumulate & 1) | (flip ? 256 : 0);
-  hipStream_t st = (hipStream_t)stream;
-  switch (pl.variant) {
-    case 0: return launch<2, 2, 2, 2>(a, pl, workspace, st);
-    case 1: return launch<2, 2, 2, 4>(a, pl, workspace, st);
-    case 2: return launch<4, 1, 1, 7>(a, pl, workspace, st);
-    case 3: return launch<2, 1, 1, 7>(a, pl, workspace, st);
-    case 4: return launch<2, 2, 1, 4>(a, pl, workspace, st);
-    case 6: return launch<1, 2, 1, 4>(a, pl, workspace, st);
-    default: return launch<1, 2, 2, 2>(a, pl, workspace, st);
-  }
+  return run(args, workspace, workspace + pl.pack_floats, flip, false, stream);
+}
+
+// Split form for callers that keep packed weights across launches.  vcv_conv_dma_plan: out[0] = floats of the
+// packed-weight buffer, out[1] = floats of per-launch scratch (0 unless the reduction is split), out[2] = a
+// signature of the pack layout (tile height, chunk size, taps, phases, flip): a packed buffer may be reused
+// by any later launch over the SAME unchanged weights whose plan has the same signature and pack size.
+// Returns 0, or VCV_EINVAL when the launch is not eligible.  vcv_conv_dma_run: pack_valid != 0 skips the pack.
+extern "C" int vcv_conv_dma_plan(const VcvConvArgs* args, int flip, int64_t* out) {
+  if (!args || !out || !eligible(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose(*args, pl)) return VCV_EINVAL;
+  out[0] = (int64_t)pl.pack_floats;
+  out[1] = (int64_t)(pl.ws_floats - pl.pack_floats);
+  const DmaGeom& g = pl.g;
+  out[2] = ((int64_t)pl.BM << 40) | ((int64_t)g.BKC << 28) | ((int64_t)g.JA << 20) | ((int64_t)g.phases << 8) | (flip ? 1 : 0);
+  return 0;
+}
+
+extern "C" int vcv_conv_dma_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
+                                void* stream) {
+  return run(args, pack_ws, scratch_ws, flip, pack_valid != 0, stream);
 }

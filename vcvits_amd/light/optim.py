@@ -132,6 +132,8 @@ class FlatAdamW:
         if self.flat.is_cuda:
             ops.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas, self.eps,
                            self.weight_decay, self.step_count)
+            # the kernel wrote the parameters through raw pointers: drop weights derived from them
+            ops.invalidate_weights(self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel)
         else:
             raise RuntimeError("FlatAdamW.step: parameters are not on the GPU (no CPU fallback)")
 

@@ -42,18 +42,30 @@ _USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
 
 
 def _launch_conv(a, flip_w=None):
-    """Forward-type launches go to the LDS-DMA kernel when it is eligible (vcv_conv_dma_workspace > 0),
+    """Forward-type launches go to the LDS-DMA kernel when it is eligible (vcv_conv_dma_plan succeeds),
     everything else to the register-staged kernel.  flip_w: original [C, M, K] weight of a stride-1 data
-    gradient (the DMA pack flips it; the register path needs the explicit flipped copy in a.w)."""
+    gradient (the DMA pack flips it; the register path needs the explicit flipped copy in a.w).
+    Packed weights of tensors inside a cached weight-norm buffer (see _WeightNormManyFn) are kept with that
+    buffer and reused until its parameters change."""
     if _USE_DMA[0] and (a.a_mode == 0 or (a.a_mode == 1 and a.phases > 1)):
         L = lib()
         if flip_w is not None:
             saved = a.w
             a.w = ptr(flip_w)
-        ws = L.vcv_conv_dma_workspace(ctypes.byref(a))
-        if ws > 0:
-            buf = torch.empty((ws,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
-            check(L.vcv_conv_dma(ctypes.byref(a), ptr(buf), 1 if flip_w is not None else 0, stream()), "vcv_conv_dma")
+        flip = 1 if flip_w is not None else 0
+        plan = (ctypes.c_int64 * 3)()
+        if L.vcv_conv_dma_plan(ctypes.byref(a), flip, plan) == 0:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            packs = _stable_packs(a.w)
+            key = (a.w, plan[0], plan[2])
+            pack = packs.get(key) if packs is not None else None
+            valid = 1 if pack is not None else 0
+            if pack is None:
+                pack = torch.empty((plan[0],), device=dev, dtype=torch.float32)
+                if packs is not None:
+                    packs[key] = pack
+            scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
+            check(L.vcv_conv_dma_run(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), "vcv_conv_dma_run")
             return
         if flip_w is not None:
             a.w = saved
@@ -137,7 +149,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = 1, dil, pad - (K - 1) * dil, 1, 0, 1, Tin, 0
         _common(a, **kw)
         a.w = ptr(w)
-        if _USE_DMA[0] and lib().vcv_conv_dma_workspace(ctypes.byref(a)) > 0:
+        if _USE_DMA[0] and lib().vcv_conv_dma_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0:
             _launch_conv(a, flip_w=w)
             return out
         wt = torch.empty((C, M, K), device=dy.device, dtype=torch.float32)
@@ -468,6 +480,31 @@ def weight_norm(v, g):
 
 
 _WN_TABLES = {}
+# Cached results of _WeightNormManyFn per parameter set: {key: dict(versions, wbuf, norm, lo, hi, packs)}.  An
+# entry is valid until one of its parameters changes: in place through torch (version counters) or through an
+# optimizer's raw-pointer update (invalidate_weights).  The discriminators' weights are identical in the
+# generator step and the discriminator step of a batch, and inference never changes them.
+_WN_CACHE = {}
+_WN_CACHE_ON = [__import__("os").environ.get("VCVITS_WEIGHT_CACHE", "1") == "1"]
+
+
+def invalidate_weights(lo=None, hi=None):
+    """Parameters stored in [lo, hi) (all parameters when None) were modified behind torch's back."""
+    if lo is None:
+        _WN_CACHE.clear()
+        return
+    for k in [k for k in _WN_CACHE if any(lo <= p < hi for p in k)]:
+        del _WN_CACHE[k]
+
+
+def _stable_packs(w_ptr):
+    """The pack cache of the cached weight-norm buffer that contains address w_ptr, if any."""
+    if w_ptr is None:
+        return None
+    for e in _WN_CACHE.values():
+        if e["lo"] <= w_ptr < e["hi"]:
+            return e["packs"]
+    return None
 
 
 class _WeightNormManyFn(torch.autograd.Function):
@@ -498,10 +535,20 @@ class _WeightNormManyFn(torch.autograd.Function):
                 _WN_TABLES.clear()
             _WN_TABLES[key] = ent
         tab, tab_dev, total, rows = ent
-        wbuf = torch.empty((total,), device=dev, dtype=torch.float32)
-        norm = torch.empty((rows,), device=dev, dtype=torch.float32)
-        check(lib().vcv_weight_norm_many_fwd(ptr(tab_dev), n, rows, ptr(wbuf), ptr(norm), stream()),
-              "vcv_weight_norm_many_fwd")
+        versions = tuple(t._version for t in vg)
+        hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
+        if hit is not None and hit["versions"] == versions:
+            wbuf, norm = hit["wbuf"], hit["norm"]
+        else:
+            wbuf = torch.empty((total,), device=dev, dtype=torch.float32)
+            norm = torch.empty((rows,), device=dev, dtype=torch.float32)
+            check(lib().vcv_weight_norm_many_fwd(ptr(tab_dev), n, rows, ptr(wbuf), ptr(norm), stream()),
+                  "vcv_weight_norm_many_fwd")
+            if _WN_CACHE_ON[0]:
+                if len(_WN_CACHE) > 64:
+                    _WN_CACHE.clear()
+                _WN_CACHE[key] = dict(versions=versions, wbuf=wbuf, norm=norm, lo=wbuf.data_ptr(),
+                                      hi=wbuf.data_ptr() + 4 * total, packs={})
         ctx.n, ctx.tab, ctx.total, ctx.rows = n, tab, total, rows
         ctx.shapes = [(v.shape, g.shape) for v, g in zip(vs, gs)]
         ctx.sinks = [(_sink(v), _sink(g)) for v, g in zip(vs, gs)]
