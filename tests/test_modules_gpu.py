@@ -260,13 +260,16 @@ def test_weight_cache_follows_parameter_changes(gpu):
     counter) or through an optimizer's raw-pointer update (ops.invalidate_weights)."""
     from vcvits_amd import ops
     from vcvits_amd.model.discriminators.discriminator import DiscriminatorP
+    # (the 1024->1 post conv combines channel ranges with atomics: repeat runs agree to rounding, not bitwise)
+    same = lambda a, b: torch.allclose(a, b, rtol=1e-4, atol=1e-7)
+    near = lambda a, b: torch.allclose(a, b, rtol=1e-2, atol=1e-5)
     torch.manual_seed(5)
     d = DiscriminatorP(3).to(gpu)
     x = torch.randn(2, 1, 3000, device=gpu)
     with torch.no_grad():
         y0, _ = d(x)
         y0b, _ = d(x)                       # served from the cache
-        assert torch.equal(y0, y0b)
+        assert same(y0, y0b)
         d.convs[3].weight_g.mul_(1.5)       # version bump
         y1, _ = d(x)
         ops._WN_CACHE_ON[0] = False
@@ -274,10 +277,10 @@ def test_weight_cache_follows_parameter_changes(gpu):
             y1_ref, _ = d(x)
         finally:
             ops._WN_CACHE_ON[0] = True
-        assert torch.equal(y1, y1_ref) and not torch.equal(y1, y0)
+        assert same(y1, y1_ref) and not near(y1, y0)
         # raw-pointer style update: same tensor objects and versions, new contents
         v = d.convs[2].weight_v
-        tmp = (v.detach() * 0.5)
+        tmp = v.detach() + 0.5 * v.detach().std() * torch.randn_like(v)  # (a pure rescale of v would cancel in w)
         # an alias on the same storage does not share v's version counter (as a kernel writing through a raw
         # pointer does not)
         alias = torch.empty(0, device=gpu).set_(v.untyped_storage(), v.storage_offset(), v.shape, v.stride())
@@ -291,4 +294,4 @@ def test_weight_cache_follows_parameter_changes(gpu):
             y2_ref, _ = d(x)
         finally:
             ops._WN_CACHE_ON[0] = True
-        assert torch.equal(y2, y2_ref) and not torch.equal(y2, y1)
+        assert same(y2, y2_ref) and not near(y2, y1)
