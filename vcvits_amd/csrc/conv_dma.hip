@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) conv_dma_finish_kernel(const VcvConvArgs 
 }
 
 struct Plan {
-  int variant;  // 0: 128x128 (4 waves)  1: 128x256 (8 waves)  2: 128x224 (7 waves)  3: 64x224 (7 waves)
+  int variant;  // 8: 128x128 with 8 waves (2 per SIMD when only one workgroup fits / exists per CU)
+                // 0: 128x128 (4 waves)  1: 128x256 (8 waves)  2: 128x224 (7 waves)  3: 64x224 (7 waves)
                 // 4: 64x256 (8 waves: 2x2 per wave, 1x4 waves... see launch)  5: 64x128
   int BM, BN;
   DmaGeom g;
@@ -348,7 +349,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   }
   if (normal_ok && a.Mg >= 128) {
     if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, pl)) { pl.variant = 1; return true; }
-    if (blocks(128, 128) >= 256 && make_plan(a, 128, 128, pl)) { pl.variant = 0; return true; }
+    if (blocks(128, 128) >= 256 && make_plan(a, 128, 128, pl)) { pl.variant = blocks(128, 128) < 512 ? 8 : 0; return true; }
   }
   if (normal_ok && a.Mg >= 64 && !(a.Mg >= 128 && blocks(128, 128) >= 32)) {
     if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
@@ -363,7 +364,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
       if (a.Mg >= 128 && blocks(128, 224) >= 32 && make_plan(a, 128, 224, pl)) pl.variant = 2, ok = true;
       else if (make_plan(a, 64, 224, pl)) pl.variant = 3, ok = true;
     }
-    if (!ok && a.Mg >= 128 && blocks(128, 128) >= 32 && make_plan(a, 128, 128, pl)) pl.variant = 0, ok = true;
+    if (!ok && a.Mg >= 128 && blocks(128, 128) >= 32 && make_plan(a, 128, 128, pl)) pl.variant = 8, ok = true;
     if (!ok && make_plan(a, 64, 128, pl)) pl.variant = 5, ok = true;
     if (!ok) return false;
     const long long nb = blocks(pl.BM, pl.BN);
@@ -436,6 +437,7 @@ int run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, bo
     case 3: return launch<2, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 4: return launch<2, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 6: return launch<1, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 8: return launch<2, 1, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     default: return launch<1, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
   }
 }

@@ -210,8 +210,8 @@ int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st) {
   int rc = -100;
   if (a.Mg >= 128) {
     if (N >= 1024) rc = launch<2, 2, 2, 4>(a, st);
-    if (rc == -100) rc = launch<2, 2, 2, 2>(a, st);
-    if (rc == -100) rc = launch<2, 1, 2, 2>(a, st);
+    if (rc == -100) rc = launch<2, 1, 2, 4>(a, st);  // 128x128, 8 waves: its LDS allows one workgroup per CU
+    if (rc == -100) rc = launch<1, 1, 4, 2>(a, st);  // 128x64, 8 waves
     return rc;
   }
   if (a.Mg >= 64) {
