@@ -430,14 +430,18 @@ int run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, bo
   VcvConvArgs a = *args;
   a.accumulate = (a.accumulate & 1) | (flip ? 256 : 0);
   hipStream_t st = (hipStream_t)stream;
+  // more, smaller waves where measured faster: 14 waves on the 128x224 tile (non-phased), 8 on 32x256
+  if (pl.variant == 2 && pl.g.phases == 1) pl.variant = 12;
+  if (pl.variant == 6) pl.variant = 16;
   switch (pl.variant) {
     case 0: return launch<2, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 1: return launch<2, 2, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 2: return launch<4, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 3: return launch<2, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 4: return launch<2, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
-    case 6: return launch<1, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 8: return launch<2, 1, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 12: return launch<2, 1, 2, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 16: return launch<1, 1, 1, 8>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     default: return launch<1, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
   }
 }
