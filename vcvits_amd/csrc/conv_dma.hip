@@ -433,16 +433,19 @@ int run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, bo
   // more, smaller waves where measured faster: 14 waves on the 128x224 tile (non-phased), 8 on 32x256
   if (pl.variant == 2 && pl.g.phases == 1) pl.variant = 12;
   if (pl.variant == 6) pl.variant = 16;
+  if (pl.variant == 1) pl.variant = 21;  // 128x256 with 16 waves
+  if (pl.variant == 3) pl.variant = 23;  // 64x224 with 14 waves
+  if (pl.variant == 5) pl.variant = 25;  // 64x128 with 8 waves
   switch (pl.variant) {
     case 0: return launch<2, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
-    case 1: return launch<2, 2, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 2: return launch<4, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
-    case 3: return launch<2, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 4: return launch<2, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 8: return launch<2, 1, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 12: return launch<2, 1, 2, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 16: return launch<1, 1, 1, 8>(a, pl, pack_ws, scratch_ws, pack_valid, st);
-    default: return launch<1, 2, 2, 2>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 21: return launch<2, 1, 2, 8>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 23: return launch<1, 1, 2, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    default: return launch<1, 1, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
   }
 }
 }  // namespace

@@ -209,13 +209,13 @@ int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st) {
   if (U * 4 >= (1ll << 31) || (long long)a.Tb * a.P * 4 >= (1ll << 31)) return -100;
   int rc = -100;
   if (a.Mg >= 128) {
-    if (N >= 1024) rc = launch<2, 2, 2, 4>(a, st);
+    if (N >= 1024) rc = launch<2, 1, 2, 8>(a, st);  // 128x256, 16 waves
     if (rc == -100) rc = launch<2, 1, 2, 4>(a, st);  // 128x128, 8 waves: its LDS allows one workgroup per CU
     if (rc == -100) rc = launch<1, 1, 4, 2>(a, st);  // 128x64, 8 waves
     return rc;
   }
   if (a.Mg >= 64) {
-    rc = launch<1, 2, 2, 2>(a, st);
+    rc = launch<1, 1, 2, 4>(a, st);  // 64x128, 8 waves
     if (rc == -100) rc = launch<1, 1, 2, 2>(a, st);
     return rc;
   }
