@@ -286,7 +286,7 @@ struct Plan {
 
 bool eligible(const VcvConvArgs& a) {
   const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
-  const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1 && a.in_tf == VCV_TF_NONE;
+  const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1;
   return (fwd_type || phased) && a.G == 1 && (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) &&
          a.Mg >= 32 && a.Cg >= 16 && a.K <= 16 && a.s >= 1 && (long long)a.Tin * a.P * 4 < (1ll << 31) &&
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);
@@ -336,10 +336,10 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, Plan& pl) {
 
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
-  // measured on the bench step: the packed / DMA path wins for deep reductions over long rows (k >= 5,
-  // >= 160 positions per batch element); short rows and k = 3 stay on the register-staged kernel, whose
-  // smaller tiles and missing pack pass serve them better
-  bool normal_ok = a.phases > 1 ? (a.K >= 4 && U >= 160) : (a.K >= 5 && U >= 160);
+  // measured on the bench step: the packed / DMA path wins for deep reductions over long rows (k >= 5, or
+  // k >= 3 for <= 64 output channels, and >= 160 positions per batch element); short rows and wide k = 3
+  // layers stay on the register-staged kernel (or take the split mode below)
+  bool normal_ok = a.phases > 1 ? (a.K >= 4 && U >= 160) : (a.K >= (a.Mg <= 64 ? 3 : 5) && U >= 160);
   if (!normal_ok && (a.phases > 1 || a.K < 3 || U < 128)) return false;
   const int nph = a.phases > 1 ? a.phases : 1;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
@@ -349,7 +349,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   }
   if (normal_ok && a.Mg >= 128) {
     if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, pl)) { pl.variant = 1; return true; }
-    if (blocks(128, 128) >= 256 && make_plan(a, 128, 128, pl)) { pl.variant = blocks(128, 128) < 512 ? 8 : 0; return true; }
+    if (blocks(128, 128) >= (nph > 1 ? 128 : 256) && make_plan(a, 128, 128, pl)) { pl.variant = blocks(128, 128) < 512 ? 8 : 0; return true; }
   }
   if (normal_ok && a.Mg >= 64 && !(a.Mg >= 128 && blocks(128, 128) >= 32)) {
     if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
