@@ -141,6 +141,12 @@ int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
 int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int Tin,
                     int Tout, int P, int K, int stride, int dil, int pad, int in_leaky, int out_act,
                     float slope, void* stream);
+/* One INPUT channel (first discriminator layers, discriminator.py:18,53): x [B,1,Tin,P], w [M,1,K] (M <= 64,
+ * K <= 16), y / dy [B,M,Tout,P].  Forward fuses bias + out_act; dgrad gives dx [B,1,Tin,P] (overwrites). */
+int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin, int Tout,
+                    int P, int K, int stride, int dil, int pad, int out_act, float slope, void* stream);
+int vcv_conv_c1_dgrad(const float* dy, const float* w, float* dx, int B, int M, int Tin, int Tout, int P, int K,
+                      int stride, int dil, int pad, void* stream);
 int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const float* baux, float* dw, int B,
                    int M, int C, int Ta, int Tb, int P, int K, int s, int d, int off, int a_tf, int b_tf,
                    float slope, float alpha, void* stream);

@@ -109,7 +109,91 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
   }
 }
 
+// ---- one INPUT channel (first layers of the discriminators: 1 -> 16 k15, 1 -> 32 k5 stride 3) -------------
+// forward: each lane holds the K input taps of its position in registers and produces all M output channels
+// (M*K FMAs per position, coalesced row writes) -- the layer is an HBM write stream, not a GEMM.
+constexpr int C1_MMAX = 64;
+
+__global__ void __launch_bounds__(256)
+conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int M, int Tin, int Tout, int P, int K, int s, int d, int pad, int out_act,
+                   float slope) {
+  __shared__ float ws[C1_MMAX * KMAX];
+  __shared__ float bs[C1_MMAX];
+  for (int i = threadIdx.x; i < M * K; i += 256) ws[i] = w[i];
+  for (int i = threadIdx.x; i < M; i += 256) bs[i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int U = Tout * P;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= U) return;
+  const int b = blockIdx.y;
+  const int t = u / P, pc = u - t * P;
+  const float* xb = x + (size_t)b * Tin * P;
+  float xv[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int r = t * s + k * d - pad;
+    xv[k] = (k < K && r >= 0 && r < Tin) ? xb[(size_t)r * P + pc] : 0.f;
+  }
+  float* yb = y + (size_t)b * M * U + u;
+  for (int m = 0; m < M; ++m) {
+    float acc = bs[m];
+    const float* wr = ws + m * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) acc += wr[k] * xv[k];
+    yb[(size_t)m * U] = vcv_act(acc, out_act, slope);
+  }
+}
+
+// data gradient w.r.t. the single input channel: dx[b,t,p] = sum_{m,k} w[m,k] * dy[b,m,q,p], q*s + k*d - pad == t
+__global__ void __launch_bounds__(256)
+conv_c1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int M, int Tin,
+                     int Tout, int P, int K, int s, int d, int pad) {
+  __shared__ float ws[C1_MMAX * KMAX];
+  for (int i = threadIdx.x; i < M * K; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int UI = Tin * P;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= UI) return;
+  const int b = blockIdx.y;
+  const int t = u / P, pc = u - t * P;
+  const size_t UO = (size_t)Tout * P;
+  const float* dyb = dy + (size_t)b * M * UO;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int r = t + pad - k * d;
+    if (r < 0 || r % s != 0) continue;
+    const int q = r / s;
+    if (q >= Tout) continue;
+    const float* dp = dyb + (size_t)q * P + pc;
+    for (int m = 0; m < M; ++m) acc += ws[m * K + k] * dp[(size_t)m * UO];
+  }
+  dx[(size_t)b * UI + u] = acc;
+}
+
 }  // namespace
+
+extern "C" int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin,
+                               int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
+                               void* stream) {
+  if (!x || !w || !y || B <= 0 || M <= 0 || M > C1_MMAX || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || K > KMAX ||
+      stride <= 0)
+    return VCV_EINVAL;
+  hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(vcv_cdiv(Tout * P, 256), B), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     y, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_conv_c1_dgrad(const float* dy, const float* w, float* dx, int B, int M, int Tin, int Tout, int P,
+                                 int K, int stride, int dil, int pad, void* stream) {
+  if (!dy || !w || !dx || B <= 0 || M <= 0 || M > C1_MMAX || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || K > KMAX ||
+      stride <= 0)
+    return VCV_EINVAL;
+  hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3(vcv_cdiv(Tin * P, 256), B), dim3(256), 0, (hipStream_t)stream, dy, w, dx,
+                     M, Tin, Tout, P, K, stride, dil, pad);
+  return vcv_check_launch();
+}
 
 extern "C" int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
                                int Tin, int Tout, int P, int K, int stride, int dil, int pad, int in_leaky,

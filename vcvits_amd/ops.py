@@ -107,6 +107,12 @@ def conv_forward(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, out=None, **
         check(lib().vcv_grouped41_fwd(ptr(x), ptr(w), ptr(bias), ptr(out), B, groups, M // groups, Tin, Tout,
                                       kw.get("out_act", ACT_NONE), kw.get("slope", 0.1), stream()), "vcv_grouped41_fwd")
         return out
+    if (C == 1 and groups == 1 and M <= 64 and K <= 16 and plain and kw.get("in_tf", TF_NONE) == TF_NONE
+            and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_LEAKY)):
+        # one input channel: every position produces all M channels from K register taps (HBM write stream)
+        check(lib().vcv_conv_c1_fwd(ptr(x), ptr(w), ptr(bias), ptr(out), B, M, Tin, Tout, P, K, stride, dil, pad,
+                                    kw.get("out_act", ACT_NONE), kw.get("slope", 0.1), stream()), "vcv_conv_c1_fwd")
+        return out
     if (M == 1 and groups == 1 and C >= 16 and plain
             and kw.get("in_tf", TF_NONE) in (TF_NONE, TF_LEAKY)
             and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_TANH)):
@@ -138,6 +144,11 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         check(lib().vcv_grouped41_dgrad(ptr(dy), ptr(kw.get("xaux")), ptr(w), ptr(out), B, groups, M // groups, Tin,
                                         Tout, kw.get("in_tf", TF_NONE), kw.get("slope", 0.1), stream()),
               "vcv_grouped41_dgrad")
+        return out
+    if (C == 1 and groups == 1 and M <= 64 and K <= 16 and kw.get("in_tf", TF_NONE) == TF_NONE
+            and set(kw) <= {"in_tf", "xaux", "slope"}):
+        check(lib().vcv_conv_c1_dgrad(ptr(dy), ptr(w), ptr(out), B, M, Tin, Tout, P, K, stride, dil, pad, stream()),
+              "vcv_conv_c1_dgrad")
         return out
     if stride == 1 and groups == 1 and M >= 32 and C >= 32:
         # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
