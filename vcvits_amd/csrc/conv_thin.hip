@@ -70,7 +70,7 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
                   int P, int K, int s, int d, int off, int a_tf, int b_tf, float slope, float alpha, int bper) {
   __shared__ float red[4][KMAX];
   const int m = blockIdx.x / C, c = blockIdx.x % C;
-  const long long U = (long long)Ta * P;
+  const int U = Ta * P;  // < 2^31 (checked by the launcher)
   float acc[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
@@ -80,10 +80,10 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
   for (int b = b_lo; b < b_hi; ++b) {
     const size_t abase = ((size_t)b * M + m) * (size_t)U;
     const size_t bbase = ((size_t)b * C + c) * (size_t)Tb * P;
-    for (long long u = threadIdx.x; u < U; u += 256) {
+    for (int u = threadIdx.x; u < U; u += 256) {
       float av = a[abase + u];
       av = vcv_tf(av, a_tf, aaux, abase + u, slope);
-      const int q = (int)(u / P), pc = (int)(u - (long long)q * P);
+      const int q = u / P, pc = u - q * P;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
@@ -223,6 +223,7 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   if (!a || !bsh || !dw || B <= 0 || M <= 0 || C <= 0 || Ta <= 0 || Tb <= 0 || P <= 0 || K <= 0 || K > KMAX)
     return VCV_EINVAL;
   if ((a_tf >= VCV_TF_DLEAKY && !aaux) || (b_tf >= VCV_TF_DLEAKY && !baux)) return VCV_EINVAL;
+  if ((long long)Ta * P >= (1ll << 31) || (long long)Tb * P >= (1ll << 31)) return VCV_EINVAL;
   int splits = 1;
   while (splits < B && (long long)M * C * splits < 1024) splits *= 2;
   if (splits > B) splits = B;
