@@ -207,6 +207,14 @@ int vcv_loss_sum(const float* a, const float* b, float target, int mode, float s
                  int64_t n, void* stream);
 int vcv_loss_grad(const float* a, const float* b, float target, int mode, float scale, const float* gout,
                   float* da, int accumulate, int64_t n, void* stream);
+/* Batched form of the two calls above over a list of tensors.  `items_dev`: DEVICE array of n_items records
+ * of six int64 {a ptr, b ptr (mode 0), n, first workgroup, float bits of scale, offset of da_i (floats) in
+ * dabuf}, sorted by first workgroup; total_blocks = workgroups of the launch.  sum: out[i] += scale_i *
+ * sum f(a_i, b_i) (out zeroed by the caller); grad: da_i = scale_i * gout[i] * f'(a_i, b_i). */
+int vcv_loss_many_sum(const void* items_dev, int n_items, int total_blocks, float target, int mode, float* out,
+                      void* stream);
+int vcv_loss_many_grad(const void* items_dev, int n_items, int total_blocks, float target, int mode,
+                       const float* gout, float* dabuf, void* stream);
 
 /* ---- torch.optim.AdamW step over a flat buffer (vcvits.py:247-257) ---- */
 int vcv_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,

@@ -81,7 +81,7 @@ EXPORTS = [
     "vcv_layernorm_c_bwd", "vcv_rel_softmax_fwd", "vcv_rel_value_fwd", "vcv_rel_softmax_bwd",
     "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
     "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_conv_c1_fwd", "vcv_conv_c1_dgrad", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
-    "vcv_act_grad", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_dgrad", "vcv_grouped41_wgrad",
+    "vcv_act_grad", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_loss_many_sum", "vcv_loss_many_grad", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_dgrad", "vcv_grouped41_wgrad",
 ]
 
 
@@ -135,6 +135,8 @@ _ARGTYPES = {
     "vcv_act_grad": [_P, _P, _P, _I, _F, _L, _P],
     "vcv_stft_complex_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vcv_istft": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vcv_loss_many_sum": [_P, _I, _I, _F, _I, _P, _P],
+    "vcv_loss_many_grad": [_P, _I, _I, _F, _I, _P, _P, _P],
     "vcv_weight_norm_many_fwd": [_P, _I, _I, _P, _P, _P],
     "vcv_weight_norm_many_bwd": [_P, _I, _I, _P, _P],
     "vcv_conv_dma_workspace": [ctypes.POINTER(VcvConvArgs)],

@@ -224,6 +224,57 @@ __global__ void loss_grad_kernel(const float* __restrict__ a, const float* __res
   da[i] = accumulate ? da[i] + v : v;
 }
 
+// ---- batched loss terms: one launch for a list of tensors --------------------------------------------------
+// items[i] = {a ptr, b ptr (mode 0), n, first block, float bits of scale, offset of da_i (floats) in dabuf}
+struct LossItem { long long a, b, n, blk0, scale_bits, da_off; };
+
+__device__ __forceinline__ int loss_find(const LossItem* __restrict__ items, int n, int blk) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+loss_many_sum_kernel(const LossItem* __restrict__ items, int nitems, int total_blocks, float target, int mode,
+                     float* __restrict__ out) {
+  __shared__ float red[4];
+  const int ti = loss_find(items, nitems, blockIdx.x);
+  const LossItem it = items[ti];
+  const int nb = (int)((ti + 1 < nitems ? items[ti + 1].blk0 : total_blocks) - it.blk0);
+  const float* a = (const float*)it.a;
+  const float* b = (const float*)it.b;
+  const size_t n = (size_t)it.n;
+  float s = 0.f;
+  for (size_t i = (size_t)(blockIdx.x - it.blk0) * 256 + threadIdx.x; i < n; i += (size_t)nb * 256) {
+    if (mode == 0) s += fabsf(a[i] - b[i]);
+    else { const float d = a[i] - target; s += d * d; }
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out + ti, __int_as_float((int)it.scale_bits) * s);
+}
+
+__global__ void __launch_bounds__(256)
+loss_many_grad_kernel(const LossItem* __restrict__ items, int nitems, int total_blocks, float target, int mode,
+                      const float* __restrict__ gout, float* __restrict__ dabuf) {
+  const int ti = loss_find(items, nitems, blockIdx.x);
+  const LossItem it = items[ti];
+  const int nb = (int)((ti + 1 < nitems ? items[ti + 1].blk0 : total_blocks) - it.blk0);
+  const float* a = (const float*)it.a;
+  const float* b = (const float*)it.b;
+  float* da = dabuf + it.da_off;
+  const size_t n = (size_t)it.n;
+  const float g = __int_as_float((int)it.scale_bits) * gout[ti];
+  for (size_t i = (size_t)(blockIdx.x - it.blk0) * 256 + threadIdx.x; i < n; i += (size_t)nb * 256) {
+    float v;
+    if (mode == 0) { const float d = a[i] - b[i]; v = d > 0.f ? g : (d < 0.f ? -g : 0.f); }
+    else v = 2.f * (a[i] - target) * g;
+    da[i] = v;
+  }
+}
+
 // ---- AdamW over a flat parameter buffer (torch.optim.AdamW semantics) -------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
@@ -364,6 +415,22 @@ extern "C" int vcv_loss_grad(const float* a, const float* b, float target, int m
   if (!a || !gout || !da || n <= 0 || (mode == 0 && !b)) return VCV_EINVAL;
   hipLaunchKernelGGL(loss_grad_kernel, grid1d(n), dim3(256), 0, ST, a, b, target, mode, scale, gout, da,
                      accumulate, (size_t)n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_loss_many_sum(const void* items_dev, int n_items, int total_blocks, float target, int mode, float* out,
+                                 void* stream) {
+  if (!items_dev || !out || n_items <= 0 || total_blocks <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(loss_many_sum_kernel, dim3(total_blocks), dim3(256), 0, ST, (const LossItem*)items_dev, n_items,
+                     total_blocks, target, mode, out);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_loss_many_grad(const void* items_dev, int n_items, int total_blocks, float target, int mode,
+                                  const float* gout, float* dabuf, void* stream) {
+  if (!items_dev || !gout || !dabuf || n_items <= 0 || total_blocks <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(loss_many_grad_kernel, dim3(total_blocks), dim3(256), 0, ST, (const LossItem*)items_dev, n_items,
+                     total_blocks, target, mode, gout, dabuf);
   return vcv_check_launch();
 }
 

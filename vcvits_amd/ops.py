@@ -716,41 +716,46 @@ def avgpool4(x):
 # losses:  sum_i scale_i * sum f(a_i, b_i)   as ONE autograd node over many tensors
 # ---------------------------------------------------------------------------------------------
 class _LossTermsFn(torch.autograd.Function):
-    """terms[i] = scale_i * sum f(a_i, b_i) as ONE autograd node over many tensors.
+    """terms[i] = scale_i * sum f(a_i, b_i) as ONE autograd node -- and one launch each way -- over many tensors.
     mode 0: |a-b| (b carries no grad), mode 1: (a-target)^2."""
 
     @staticmethod
     def forward(ctx, mode, target, scales, n_a, *tensors):
+        import struct
+        import numpy as np
         a_list = [_f32c(t) for t in tensors[:n_a]]
         b_list = [_f32c(t) for t in tensors[n_a:]] if mode == 0 else [None] * n_a
-        out = torch.zeros((n_a,), device=a_list[0].device, dtype=torch.float32)
-        base = out.data_ptr()
+        dev = a_list[0].device
+        out = torch.zeros((n_a,), device=dev, dtype=torch.float32)
+        tab = np.zeros((n_a, 6), dtype=np.int64)
+        blk = off = 0
         for i, (a, b, sc) in enumerate(zip(a_list, b_list, scales)):
-            check(lib().vcv_loss_sum(ptr(a), ptr(b), target, mode, sc, ctypes.c_void_p(base + 4 * i),
-                                     a.numel(), stream()), "vcv_loss_sum")
-        ctx.mode, ctx.target, ctx.scales, ctx.n_a = mode, target, scales, n_a
-        ctx.save_for_backward(*a_list, *[b for b in b_list if b is not None])
+            if mode == 0 and b.numel() != a.numel():
+                raise RuntimeError("loss terms: shape mismatch")
+            n = a.numel()
+            tab[i] = (a.data_ptr(), b.data_ptr() if b is not None else 0, n, blk,
+                      struct.unpack("<i", struct.pack("<f", sc))[0], off)
+            blk += max(1, min((n + 2047) // 2048, 512))
+            off += n
+        tab_dev = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
+        check(lib().vcv_loss_many_sum(ptr(tab_dev), n_a, blk, target, mode, ptr(out), stream()), "vcv_loss_many_sum")
+        ctx.mode, ctx.target, ctx.n_a, ctx.blocks, ctx.total = mode, target, n_a, blk, off
+        ctx.offs = [int(o) for o in tab[:, 5]]
+        ctx.save_for_backward(tab_dev, *a_list, *[b for b in b_list if b is not None])
         return out
 
     @staticmethod
     def backward(ctx, gout):
         n_a = ctx.n_a
-        saved = ctx.saved_tensors
-        a_list = saved[:n_a]
-        b_list = saved[n_a:] if ctx.mode == 0 else [None] * n_a
+        tab_dev = ctx.saved_tensors[0]
+        a_list = ctx.saved_tensors[1:1 + n_a]
         gout = _f32c(gout)
-        gbase = gout.data_ptr()
-        grads = []
-        for i, (a, b, sc) in enumerate(zip(a_list, b_list, ctx.scales)):
-            if not ctx.needs_input_grad[4 + i]:
-                grads.append(None)
-                continue
-            da = torch.empty_like(a)
-            check(lib().vcv_loss_grad(ptr(a), ptr(b), ctx.target, ctx.mode, sc,
-                                      ctypes.c_void_p(gbase + 4 * i), ptr(da), 0, a.numel(), stream()),
-                  "vcv_loss_grad")
-            grads.append(da)
-        grads += [None] * (len(saved) - n_a)
+        dabuf = torch.empty((ctx.total,), device=gout.device, dtype=torch.float32)
+        check(lib().vcv_loss_many_grad(ptr(tab_dev), n_a, ctx.blocks, ctx.target, ctx.mode, ptr(gout), ptr(dabuf),
+                                       stream()), "vcv_loss_many_grad")
+        grads = [dabuf[o:o + a.numel()].view(a.shape) if ctx.needs_input_grad[4 + i] else None
+                 for i, (a, o) in enumerate(zip(a_list, ctx.offs))]
+        grads += [None] * (len(ctx.saved_tensors) - 1 - n_a)
         return (None, None, None, None, *grads)
 
 
