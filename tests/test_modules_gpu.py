@@ -295,3 +295,26 @@ def test_weight_cache_follows_parameter_changes(gpu):
         finally:
             ops._WN_CACHE_ON[0] = True
         assert same(y2, y2_ref) and not near(y2, y1)
+
+
+def test_weight_cache_not_fooled_by_recycled_addresses(gpu):
+    """A new module whose parameters land on a freed module's addresses (same shapes, same version counters)
+    must not be served the old module's cached weights."""
+    from vcvits_amd import ops
+    from vcvits_amd.model.discriminators.discriminator import DiscriminatorP
+    x = torch.randn(2, 1, 3000, device=gpu)
+    outs = []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        d = DiscriminatorP(3).to(gpu)
+        with torch.no_grad():
+            y, _ = d(x)
+            ops._WN_CACHE_ON[0] = False
+            try:
+                y_ref, _ = d(x)
+            finally:
+                ops._WN_CACHE_ON[0] = True
+        assert torch.allclose(y, y_ref, rtol=1e-4, atol=1e-7), seed
+        outs.append(y)
+        del d
+    assert not torch.allclose(outs[0], outs[1], rtol=1e-2, atol=1e-5)

@@ -21,7 +21,9 @@ def run_pair(disc, y, y_hat):
     from ... import ops
     with ops.grad_batch_start(B):
         out, fmap = disc(torch.cat([y.detach(), y_hat], dim=0))
-    return out[:B].detach(), out[B:], [f[:B].detach() for f in fmap], [f[B:] for f in fmap]
+    taps = [isinstance(f, ops.FmapTap) for f in fmap]
+    return (out[:B].detach(), out[B:], [f.real if t else f[:B].detach() for f, t in zip(fmap, taps)],
+            [f.fake if t else f[B:] for f, t in zip(fmap, taps)])
 
 
 _STREAMS = []

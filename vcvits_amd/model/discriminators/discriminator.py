@@ -33,10 +33,10 @@ class DiscriminatorP(nn.Module):
             t = t + n_pad
         x = x.view(b, c, t // self.period, self.period)
         for l in self.convs:
-            x = l(x, out_act=ACT_LEAKY, slope=LRELU_SLOPE)
-            fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
+            x, rec = ops.fmap_tap(l(x, out_act=ACT_LEAKY, slope=LRELU_SLOPE))
+            fmap.append(rec)
+        x, rec = ops.fmap_tap(self.conv_post(x))
+        fmap.append(rec)
         return torch.flatten(x, 1, -1), fmap
 
 
@@ -55,8 +55,8 @@ class DiscriminatorS(nn.Module):
         prepare_weight_norm(self)
         fmap = []
         for l in self.convs:
-            x = l(x, out_act=ACT_LEAKY, slope=LRELU_SLOPE)
-            fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
+            x, rec = ops.fmap_tap(l(x, out_act=ACT_LEAKY, slope=LRELU_SLOPE))
+            fmap.append(rec)
+        x, rec = ops.fmap_tap(self.conv_post(x))
+        fmap.append(rec)
         return torch.flatten(x, 1, -1), fmap

@@ -343,6 +343,53 @@ class grad_batch_start:
         return False
 
 
+class FmapTap:
+    """A feature map recorded inside grad_batch_start(b0): `real` = the leading b0 batch elements (no gradient),
+    `fake` = the trailing ones (gradient flows through fmap_tap's node)."""
+    __slots__ = ("real", "fake")
+
+    def __init__(self, real, fake):
+        self.real, self.fake = real, fake
+
+
+class _TapFn(torch.autograd.Function):
+    """(x, x[b0:]) with one backward node: the gradient of the trailing slice is added IN PLACE onto the
+    trailing part of the pass-through gradient (no zero-filled full-size temporary, no copy, no full-size add,
+    which is what slicing after the fact costs).  The leading part of the returned gradient is unspecified, as
+    grad_batch_start promises its consumers."""
+
+    @staticmethod
+    def forward(ctx, x, b0):
+        ctx.b0 = b0
+        return x.view(x.shape), x[b0:]
+
+    @staticmethod
+    def backward(ctx, g_pass, g_tail):
+        b0 = ctx.b0
+        if g_pass is None and g_tail is None:
+            return None, None
+        if g_pass is None:
+            g_pass = torch.empty((b0 + g_tail.shape[0],) + tuple(g_tail.shape[1:]), device=g_tail.device, dtype=g_tail.dtype)
+            g_pass[b0:].copy_(g_tail)
+            return g_pass, None
+        if g_tail is not None:
+            if not g_pass.is_contiguous():
+                g_pass = g_pass.contiguous()
+            g_pass[b0:].add_(g_tail)
+        return g_pass, None
+
+
+def fmap_tap(x):
+    """Record a discriminator feature map: returns (x to continue with, the recorded map).  Inside
+    grad_batch_start(b0) with gradients flowing, the record is a FmapTap whose `fake` half shares one backward
+    node with the pass-through; otherwise it is x itself."""
+    b0 = _GRAD_B0[0]
+    if b0 > 0 and x.requires_grad and torch.is_grad_enabled() and b0 < x.shape[0]:
+        xp, tail = _TapFn.apply(x, b0)
+        return xp, FmapTap(x.detach()[:b0], tail)
+    return x, x
+
+
 def _to_bt(t):
     """[B, C, T] -> [1, C, T, B] (batch as the innermost column; pure data movement)."""
     return t.permute(1, 2, 0).contiguous().unsqueeze(0)
@@ -548,8 +595,8 @@ class _WeightNormManyFn(torch.autograd.Function):
         tab, tab_dev, total, rows = ent
         versions = tuple(t._version for t in vg)
         hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
-        if hit is not None and hit["versions"] == versions:
-            wbuf, norm = hit["wbuf"], hit["norm"]
+        if hit is not None and hit["versions"] == versions and all(r() is t for r, t in zip(hit["refs"], vg)):
+            wbuf, norm = hit["wbuf"], hit["norm"]  # (identity: a recycled address is not the same parameter)
         else:
             wbuf = torch.empty((total,), device=dev, dtype=torch.float32)
             norm = torch.empty((rows,), device=dev, dtype=torch.float32)
@@ -558,8 +605,9 @@ class _WeightNormManyFn(torch.autograd.Function):
             if _WN_CACHE_ON[0]:
                 if len(_WN_CACHE) > 64:
                     _WN_CACHE.clear()
-                _WN_CACHE[key] = dict(versions=versions, wbuf=wbuf, norm=norm, lo=wbuf.data_ptr(),
-                                      hi=wbuf.data_ptr() + 4 * total, packs={})
+                import weakref
+                _WN_CACHE[key] = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
+                                      lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={})
         ctx.n, ctx.tab, ctx.total, ctx.rows = n, tab, total, rows
         ctx.shapes = [(v.shape, g.shape) for v, g in zip(vs, gs)]
         ctx.sinks = [(_sink(v), _sink(g)) for v, g in zip(vs, gs)]
