@@ -37,12 +37,12 @@ def profiled_traffic():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         d = json.load(open(files[-1]))
-        return {"bytes_per_launch": round(d["hbm_bytes_per_launch"]), "source": os.path.relpath(files[-1], ROOT)}
+        return round(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def parse():
@@ -169,8 +169,10 @@ def main():
         dma = cls(2, "conv_dma_kernel (fwd + dgrad + convT, LDS-DMA staging, all tile variants)")
         if dma:
             # dominant kernel by time; the other MFMA kernel families ride along for the record
+            traffic, traffic_src = profiled_traffic()
             roof = {"bound": "mfma", "kernel": dma["kernel"], "achieved": dma["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": dma["frac"], "traffic": profiled_traffic(),
+                    "unit": "TFLOP/s", "frac": dma["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "traffic_source": traffic_src,
                     "launches_per_step": dma["launches_per_step"], "avg_launch_us": dma["avg_launch_us"],
                     "gflop_per_launch": dma["gflop_per_launch"], "share_of_step_time": dma["share_of_step_time"],
                     "other_kernels": [k for k in (cls(3, "wgrad_dma_kernel"), cls(0, "conv_gemm_kernel (register-staged)"),
