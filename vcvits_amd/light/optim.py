@@ -123,6 +123,8 @@ class FlatAdamW:
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()
         self._synced = False
+        if self.grad.is_cuda:
+            ops.wgrad_arena_reset()  # temporaries of the previous backward pass are dead by now
         for b in self._buckets:
             b["ready"] = 0
 

@@ -185,14 +185,48 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
     return out
 
 
+# Zero-initialised accumulators for weight gradients of INTERMEDIATE weights (weight-normed layers: the
+# gradient is consumed by the weight-norm backward of the same pass and then dead).  Instead of one fill
+# launch per layer, slices of one arena are handed out and the used part is re-zeroed once per backward pass
+# (wgrad_arena_reset, called from the optimizer's zero_grad).
+_ARENA = {"buf": None, "off": 0, "need": 0, "on": False}
+
+
+def wgrad_arena_reset():
+    a = _ARENA
+    if a["buf"] is not None and a["off"] > 0:
+        a["buf"][:a["off"]].zero_()
+    if a["need"] > (a["buf"].numel() if a["buf"] is not None else 0) and torch.cuda.is_available():
+        a["buf"] = torch.zeros((int(a["need"] * 1.1) + 1024,), device=torch.device("cuda", torch.cuda.current_device()),
+                               dtype=torch.float32)
+    a["off"] = a["need"] = 0
+    a["on"] = True
+
+
+def _wgrad_zeros(shape, dev, arena):
+    a = _ARENA
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if arena and a["on"]:
+        n64 = (n + 63) & ~63
+        a["need"] += n64
+        buf = a["buf"]
+        if buf is not None and buf.device == dev and a["off"] + n64 <= buf.numel():
+            o = a["off"]
+            a["off"] = o + n64
+            return buf[o:o + n].view(tuple(shape))
+    return torch.zeros(tuple(shape), device=dev, dtype=torch.float32)
+
+
 def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=TF_NONE, aaux=None,
-               b_tf=TF_NONE, baux=None, alpha=1.0, slope=0.1):
+               b_tf=TF_NONE, baux=None, alpha=1.0, slope=0.1, arena=False):
     """Weight gradient of conv_forward (accumulates onto `out` when given, else onto zeros)."""
     B, M, Tout, P = _rows(dy)
     _, C, Tin, _ = _rows(x)
     Cg, K = w_shape[1], w_shape[2]
     if out is None:
-        out = torch.zeros(tuple(w_shape), device=dy.device, dtype=torch.float32)
+        out = _wgrad_zeros(w_shape, dy.device, arena)
     if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
             and M // groups in (4, 16) and b_tf == TF_NONE and a_tf in (TF_NONE, TF_DLEAKY) and alpha == 1.0):
         check(lib().vcv_grouped41_wgrad(ptr(dy), ptr(aaux), ptr(x), ptr(out), B, groups, M // groups, Tin, Tout, a_tf,
@@ -257,13 +291,13 @@ def convT_dgrad(dy, w, x_shape, stride=1, pad=0, out=None, **kw):
 
 
 def convT_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, a_tf=TF_NONE, aaux=None, b_tf=TF_NONE,
-                baux=None, alpha=1.0, slope=0.1):
+                baux=None, alpha=1.0, slope=0.1, arena=False):
     """dW[ci,co,k] of conv_transpose1d: `a` = x (un-shifted), `b` = dy (shifted)."""
     B, Cin, Tin, P = _rows(x)
     _, Cout, Tout, _ = _rows(dy)
     K = w_shape[2]
     if out is None:
-        out = torch.zeros(tuple(w_shape), device=dy.device, dtype=torch.float32)
+        out = _wgrad_zeros(w_shape, dy.device, arena)
     a = VcvWgradArgs()
     a.a, a.b, a.aaux, a.baux, a.dw = ptr(x), ptr(dy), ptr(aaux), ptr(baux), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, 1, Cout, Cin
@@ -428,6 +462,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, groups, in_leaky, out_act, slope, transposed)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         ctx.w_sink, ctx.b_sink = _sink(w), _sink(bias)
+        ctx.w_tmp = w.requires_grad and not w.is_leaf  # its gradient is an intermediate of this backward pass
         ctx.b0 = _GRAD_B0[0] if not (w.requires_grad or (bias is not None and bias.requires_grad)) else 0
         ctx.save_for_backward(x, w, y if out_act != ACT_NONE else None)
         return y
@@ -458,7 +493,8 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 wout = ctx.w_sink[0].view(w3.shape) if ctx.w_sink is not None else None
                 dw = conv_wgrad(dyt, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
-                                b_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope, out=wout).view(w.shape)
+                                b_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope, out=wout,
+                                arena=ctx.w_tmp).view(w.shape)
                 dw = _sunk(ctx.w_sink, dw)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = _sunk(ctx.b_sink, bias_grad(dy, slope=slope, out=ctx.b_sink[0] if ctx.b_sink is not None else None))
@@ -480,10 +516,10 @@ class _ConvFn(torch.autograd.Function):
             wout = ctx.w_sink[0].view(w3.shape) if ctx.w_sink is not None else None
             if transposed:
                 dw = convT_wgrad(dy, x, w3.shape, stride=stride, pad=pad, a_tf=b_tf, b_tf=dtf,
-                                 baux=y, slope=slope, out=wout)
+                                 baux=y, slope=slope, out=wout, arena=ctx.w_tmp)
             else:
                 dw = conv_wgrad(dy, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
-                                a_tf=dtf, aaux=y, b_tf=b_tf, slope=slope, out=wout)
+                                a_tf=dtf, aaux=y, b_tf=b_tf, slope=slope, out=wout, arena=ctx.w_tmp)
             dw = _sunk(ctx.w_sink, dw.view(w.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _sunk(ctx.b_sink, bias_grad(dy, aux=y, tf=dtf, slope=slope,
