@@ -49,6 +49,7 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = ch * BKC, m0 = mt * BM;
   if (!flip) {
+#pragma unroll 8
     for (int ml = wave; ml < BM; ml += 4) {
       const int m = m0 + ml;
       const float* wr = w + ((size_t)m * C + c0) * K;
@@ -62,6 +63,7 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
     for (int cl = wave; cl < BKC; cl += 4) {
       const int c = c0 + cl;
       const float* wc = w + ((size_t)c * M + m0) * K;
+#pragma unroll 8
       for (int e = lane; e < BM * K; e += 64) {
         const int ml = e / K, k = e - ml * K;
         t[(cl * K + (K - 1 - k)) * (BM + 1) + ml] = (c < C && m0 + ml < M) ? wc[e] : 0.f;
@@ -84,9 +86,11 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
   }
   __syncthreads();
   float* out = wp + (((size_t)blockIdx.z * gridDim.y + mt) * nch + ch) * (size_t)KKR * BM;
-  for (int i = tid; i < KKR * BM; i += 256) {
+  // BM is a multiple of 4 and the slab is 16-byte aligned: 16-byte stores
+  for (int i = tid * 4; i < KKR * BM; i += 1024) {
     const int kk = i / BM, ml = i - kk * BM;
-    out[i] = t[kk * (BM + 1) + ml];
+    const float* tr = t + kk * (BM + 1) + ml;
+    *reinterpret_cast<float4*>(out + i) = make_float4(tr[0], tr[1], tr[2], tr[3]);
   }
 }
 
@@ -401,9 +405,9 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, float* part, bool pa
   dim3 grid(a.B * g.ntu * g.ks, g.nmt, g.phases), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
   const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
-  const int slot = vcv_prof_start(VCV_PROF_CONV_DMA, flops, st, tag, 12);
-  hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, aa, g, (const float*)ws, part);
-  vcv_prof_stop(slot, st);
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, aa, g, (const float*)ws, part);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
     hipLaunchKernelGGL(conv_dma_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, (const float*)part, g.ks);

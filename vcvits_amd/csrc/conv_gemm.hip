@@ -393,9 +393,9 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   dim3 grid(a.B * tg.ntu, a.G * tg.nmt, phases), block(NT);
   const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)(phases > 1 ? a.Tin : a.Q);
   const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, phases, a.a_mode, BM * 1000 + BN, tg.BKC};
-  const int slot = vcv_prof_start(VCV_PROF_CONV, flops, st, tag, 12);
-  hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
-  vcv_prof_stop(slot, st);
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_CONV, flops, tag, 12, &ev0, &ev1);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, tg);
   return vcv_check_launch();
 }
 

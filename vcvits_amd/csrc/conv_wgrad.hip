@@ -287,9 +287,9 @@ int launch_wgrad_bu(const VcvWgradArgs& a, hipStream_t st, bool allow_sync) {
   dim3 grid(tg.nnt, a.G * tg.nmt, tg.Z), block(NT);
   const double flops = 2.0 * a.B * a.G * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
   const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, tg.Z, 0, BM * 1000 + BN, tg.NCH};
-  const int slot = vcv_prof_start(VCV_PROF_WGRAD, flops, st, tag, 12);
-  hipLaunchKernelGGL(kern, grid, block, lds, st, a, tg);
-  vcv_prof_stop(slot, st);
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_WGRAD, flops, tag, 12, &ev0, &ev1);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, tg);
   return vcv_check_launch();
 }
 

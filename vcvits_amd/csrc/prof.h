@@ -2,6 +2,7 @@
 // roofline line: achieved FLOP/s of the dominant kernel measured on the launch stream itself).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #define VCV_PROF_CONV 0       /* conv_gemm_kernel */
 #define VCV_PROF_WGRAD 1      /* conv_wgrad_kernel */
@@ -12,3 +13,7 @@
 // returns a slot (>= 0) when profiling is on and an event pair was recorded before the launch
 int vcv_prof_start(int cls, double flops, hipStream_t st, const int* tag = nullptr, int ntag = 0);
 void vcv_prof_stop(int slot, hipStream_t st);
+// Dispatch-attached timing: reserves a slot and returns its two events for hipExtLaunchKernelGGL (the kernel's own
+// start / completion timestamps: no marker packets in the queue, so profiling does not serialise the stream).
+// Both events are null when profiling is off.
+void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop);

@@ -29,6 +29,18 @@ int vcv_prof_start(int cls, double flops, hipStream_t st, const int* tag, int nt
   return slot;
 }
 
+void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop) {
+  *start = *stop = nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on || g_used >= g_start.size()) return;
+  const int slot = (int)g_used++;
+  g_cls[slot] = cls;
+  g_flops[slot] = flops;
+  for (int i = 0; i < NTAG; ++i) g_tags[slot * NTAG + i] = (tag && i < ntag) ? tag[i] : 0;
+  *start = g_start[slot];
+  *stop = g_stop[slot];
+}
+
 void vcv_prof_stop(int slot, hipStream_t st) {
   if (slot < 0) return;
   hipEventRecord(g_stop[slot], st);

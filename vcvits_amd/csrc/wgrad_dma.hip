@@ -191,9 +191,9 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
   dim3 grid(g.nnt, g.nmt, g.Z), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
   const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, BM * 1000 + BN, g.nXrow};
-  const int slot = vcv_prof_start(VCV_PROF_WGRAD_DMA, flops, st, tag, 12);
-  hipLaunchKernelGGL(kern, grid, block, lds, st, a, g);
-  vcv_prof_stop(slot, st);
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g);
   return vcv_check_launch();
 }
 
