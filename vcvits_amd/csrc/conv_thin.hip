@@ -67,7 +67,7 @@ __global__ void fill_bias_kernel(float* __restrict__ y, const float* __restrict_
 __global__ void __launch_bounds__(256)
 thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, const float* __restrict__ aaux,
                   const float* __restrict__ baux, float* __restrict__ dw, int B, int M, int C, int Ta, int Tb,
-                  int P, int K, int s, int d, int off, int a_tf, int b_tf, float slope, float alpha, int bper) {
+                  int P, int K, int s, int d, int off, int a_tf, int b_tf, float slope, float alpha, int bper, int uper) {
   __shared__ float red[4][KMAX];
   const int m = blockIdx.x / C, c = blockIdx.x % C;
   const int U = Ta * P;  // < 2^31 (checked by the launcher)
@@ -80,7 +80,8 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
   for (int b = b_lo; b < b_hi; ++b) {
     const size_t abase = ((size_t)b * M + m) * (size_t)U;
     const size_t bbase = ((size_t)b * C + c) * (size_t)Tb * P;
-    for (int u = threadIdx.x; u < U; u += 256) {
+    const int u_lo = blockIdx.z * uper, u_hi = u_lo + uper < U ? u_lo + uper : U;
+    for (int u = u_lo + threadIdx.x; u < u_hi; u += 256) {
       float av = a[abase + u];
       av = vcv_tf(av, a_tf, aaux, abase + u, slope);
       const int q = u / P, pc = u - q * P;
@@ -228,7 +229,13 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   while (splits < B && (long long)M * C * splits < 1024) splits *= 2;
   if (splits > B) splits = B;
   const int bper = vcv_cdiv(B, splits);
-  hipLaunchKernelGGL(thin_wgrad_kernel, dim3(M * C, vcv_cdiv(B, bper)), dim3(256), 0, (hipStream_t)stream, a, bsh, aaux,
-                     baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha, bper);
+  // long rows: also split the positions so that the grid has a few thousand workgroups of >= 1024 positions
+  const int U = Ta * P;
+  long long usplit = 4096 / ((long long)M * C * vcv_cdiv(B, bper));
+  if (usplit > U / 1024) usplit = U / 1024;
+  if (usplit < 1) usplit = 1;
+  const int uper = (vcv_cdiv(U, (int)usplit) + 255) & ~255;
+  hipLaunchKernelGGL(thin_wgrad_kernel, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0, (hipStream_t)stream,
+                     a, bsh, aaux, baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha, bper, uper);
   return vcv_check_launch();
 }
