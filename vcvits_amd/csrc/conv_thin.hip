@@ -226,12 +226,12 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   if ((a_tf >= VCV_TF_DLEAKY && !aaux) || (b_tf >= VCV_TF_DLEAKY && !baux)) return VCV_EINVAL;
   if ((long long)Ta * P >= (1ll << 31) || (long long)Tb * P >= (1ll << 31)) return VCV_EINVAL;
   int splits = 1;
-  while (splits < B && (long long)M * C * splits < 1024) splits *= 2;
+  while (splits < B && (long long)M * C * splits < 4096) splits *= 2;  // short serial batch loops: latency-bound
   if (splits > B) splits = B;
   const int bper = vcv_cdiv(B, splits);
   // long rows: also split the positions so that the grid has a few thousand workgroups of >= 1024 positions
   const int U = Ta * P;
-  long long usplit = 4096 / ((long long)M * C * vcv_cdiv(B, bper));
+  long long usplit = 8192 / ((long long)M * C * vcv_cdiv(B, bper));
   if (usplit > U / 1024) usplit = U / 1024;
   if (usplit < 1) usplit = 1;
   const int uper = (vcv_cdiv(U, (int)usplit) + 255) & ~255;
