@@ -356,7 +356,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     if (blocks(128, 128) >= (nph > 1 ? 128 : 256) && make_plan(a, 128, 128, pl)) { pl.variant = blocks(128, 128) < 512 ? 8 : 0; return true; }
   }
   if (normal_ok && a.Mg >= 64 && !(a.Mg >= 128 && blocks(128, 128) >= 32)) {
-    if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
+    if (a.K < 5 && U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, pl)) { pl.variant = 4; return true; }
     if (make_plan(a, 64, 128, pl) && blocks(64, 128) >= 256) { pl.variant = 5; return true; }
   }
   if (normal_ok && a.Mg >= 32 && a.Mg < 64 && blocks(32, 256) >= 256 && make_plan(a, 32, 256, pl)) { pl.variant = 6; return true; }
