@@ -348,8 +348,13 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   const int nph = a.phases > 1 ? a.phases : 1;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
   if (normal_ok && U > 160 && U <= 224) {
-    if (a.Mg >= 128 && blocks(128, 224) >= 224 && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
+    if (a.Mg >= 128 && blocks(128, 224) >= (nph > 1 ? 128 : 224) && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
     if (a.Mg >= 64 && make_plan(a, 64, 224, pl)) { pl.variant = 3; return true; }
+  }
+  // rows just past 256 positions (period 37 strided gradients: 259): one 288-wide tile, not 256 + 3
+  if (normal_ok && U > 256 && U <= 288 && a.Mg >= 128 && blocks(128, 288) >= 128 && make_plan(a, 128, 288, pl)) {
+    pl.variant = 9;
+    return true;
   }
   if (normal_ok && a.Mg >= 128) {
     if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, pl)) { pl.variant = 1; return true; }
@@ -445,6 +450,7 @@ int run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, bo
     case 2: return launch<4, 1, 1, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 4: return launch<2, 2, 1, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 8: return launch<2, 1, 2, 4>(a, pl, pack_ws, scratch_ws, pack_valid, st);
+    case 9: return launch<4, 1, 1, 9>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 12: return launch<2, 1, 2, 7>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 16: return launch<1, 1, 1, 8>(a, pl, pack_ws, scratch_ws, pack_valid, st);
     case 21: return launch<2, 1, 2, 8>(a, pl, pack_ws, scratch_ws, pack_valid, st);
