@@ -44,6 +44,7 @@ CONV_CASES = [
     (4, 64, 96, 5, 5, 1, 2, 1, 1),
     (3, 128, 64, 33, 5, 1, 2, 1, 1),
     (2, 1024, 1024, 9, 5, 1, 2, 1, 1),
+    (4, 64, 96, 64, 5, 1, 2, 1, 1),   # folded forward / data gradient, unfolded weight gradient
     # few output tiles: reduction split over several blocks per tile + finishing pass
     (16, 512, 512, 20, 5, 1, 2, 1, 1),
     (2, 256, 256, 256, 11, 1, 5, 1, 1),

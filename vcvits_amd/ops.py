@@ -492,7 +492,10 @@ class _ConvFn(torch.autograd.Function):
                 dx = _from_bt(conv_dgrad(dyt, w3, x.shape, stride=stride, pad=pad, dil=dil, groups=groups, **kw))
             if ctx.needs_input_grad[1]:
                 wout = ctx.w_sink[0].view(w3.shape) if ctx.w_sink is not None else None
-                dw = conv_wgrad(dyt, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
+                # rows of >= 64 frames fill the weight-gradient kernel's 64-position stages on their own: the
+                # unfolded layout is faster there (the fold only pays for the forward / data-gradient tiles)
+                wa, wb = (dy, _from_bt(x)) if dy.shape[2] >= 64 else (dyt, x)
+                dw = conv_wgrad(wa, wb, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
                                 b_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope, out=wout,
                                 arena=ctx.w_tmp).view(w.shape)
                 dw = _sunk(ctx.w_sink, dw)
