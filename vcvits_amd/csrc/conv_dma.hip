@@ -43,14 +43,17 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 template <int BM>
 __global__ void __launch_bounds__(256)
 pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int C, int K, int BKC, int KKR,
-                    int nch, int flip) {
+                    int nch, int flip, int rsplit) {
   extern __shared__ float t[];  // [KKR][BM + 1]
-  const int ch = blockIdx.x, mt = blockIdx.y;
+  // blockIdx.y = m-tile * rsplit + row slice: small weights are split over more workgroups (RB rows each)
+  const int ch = blockIdx.x, mt = blockIdx.y / rsplit, rs = blockIdx.y - mt * rsplit;
+  const int RB = BM / rsplit, r0 = rs * RB;
+  const int nmt = gridDim.y / rsplit;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = ch * BKC, m0 = mt * BM;
   if (!flip) {
 #pragma unroll 8
-    for (int ml = wave; ml < BM; ml += 4) {
+    for (int ml = r0 + wave; ml < r0 + RB; ml += 4) {
       const int m = m0 + ml;
       const float* wr = w + ((size_t)m * C + c0) * K;
       for (int kk = lane; kk < KKR; kk += 64) {
@@ -64,7 +67,7 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
       const int c = c0 + cl;
       const float* wc = w + ((size_t)c * M + m0) * K;
 #pragma unroll 8
-      for (int e = lane; e < BM * K; e += 64) {
+      for (int e = r0 * K + lane; e < (r0 + RB) * K; e += 64) {
         const int ml = e / K, k = e - ml * K;
         t[(cl * K + (K - 1 - k)) * (BM + 1) + ml] = (c < C && m0 + ml < M) ? wc[e] : 0.f;
       }
@@ -78,19 +81,19 @@ pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, 
     for (int cl = wave; cl < BKC; cl += 4) {
       const int c = c0 + cl;
       const float* wc = w + ((size_t)c * M + m0) * K;
-      for (int e = lane; e < BM * K; e += 64) {
+      for (int e = r0 * K + lane; e < (r0 + RB) * K; e += 64) {
         const int ml = e / K, k = e - ml * K;
         if (k % phases == r && c < C && m0 + ml < M) t[(cl * JA + k / phases) * (BM + 1) + ml] = wc[e];
       }
     }
   }
   __syncthreads();
-  float* out = wp + (((size_t)blockIdx.z * gridDim.y + mt) * nch + ch) * (size_t)KKR * BM;
-  // BM is a multiple of 4 and the slab is 16-byte aligned: 16-byte stores
-  for (int i = tid * 4; i < KKR * BM; i += 1024) {
-    const int kk = i / BM, ml = i - kk * BM;
+  float* out = wp + (((size_t)blockIdx.z * nmt + mt) * nch + ch) * (size_t)KKR * BM;
+  // RB is a multiple of 4 and the slab is 16-byte aligned: 16-byte stores
+  for (int i = tid * 4; i < KKR * RB; i += 1024) {
+    const int kk = i / RB, ml = r0 + (i - kk * RB);
     const float* tr = t + kk * (BM + 1) + ml;
-    *reinterpret_cast<float4*>(out + i) = make_float4(tr[0], tr[1], tr[2], tr[3]);
+    *reinterpret_cast<float4*>(out + kk * BM + ml) = make_float4(tr[0], tr[1], tr[2], tr[3]);
   }
 }
 
@@ -397,9 +400,13 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, float* part, bool pa
   if (plds > 64 * 1024 && hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
     return VCV_EHIP;
   const int flip = g.phases > 1 ? (g.phases << 8) : (a.accumulate >> 8);
-  if (!pack_valid)
-    hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt, g.phases), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC, g.KKR,
-                       g.nch, flip);
+  if (!pack_valid) {
+    // small weights: split the rows of a tile over up to BM/32 workgroups so the pack is not a 16-workgroup launch
+    int rsplit = 1;
+    while (rsplit * 32 < BM && (long long)g.nch * g.nmt * g.phases * rsplit < 256) rsplit *= 2;
+    hipLaunchKernelGGL(pk, dim3(g.nch, g.nmt * rsplit, g.phases), dim3(256), plds, st, a.w, ws, a.Mg, a.Cg, a.K, g.BKC,
+                       g.KKR, g.nch, flip, rsplit);
+  }
   void (*kern)(const VcvConvArgs, const DmaGeom, const float*, float*) =
       a.in_tf == VCV_TF_LEAKY ? conv_dma_kernel<TM, TN, WM, WN, true> : conv_dma_kernel<TM, TN, WM, WN, false>;
   if (pl.lds_bytes > 64 * 1024 &&
