@@ -123,12 +123,16 @@ class VCVITS(nn.Module):
         raise ValueError("optimizer_idx must be 0 (generator) or 1 (discriminators)")
 
     def validation_step(self, batch, batch_idx):
-        """vcvits.py:185-245 without the TensorBoard writes: returns (y_hat, y_hat_lengths, mel, y_hat_mel)."""
+        """vcvits.py:185-245: returns (y_hat, y_hat_lengths, mel, y_hat_mel); when a logger with a TensorBoard-style
+        `.experiment` writer is attached (`self.logger`), also writes the reference's summary -- gen/mel, gt/mel
+        images and gen/audio, gt/audio clips of the first utterance -- through utils.summarize."""
         d = self.hparams.data
         self.net_g.eval()
         with torch.no_grad():
             y_spec, mel = self._spec_mel(batch["y_wav_values"].squeeze(1)[:1])
-            len_scale = (d.target_sampling_rate / d.hop_length) / d.source_sampling_rate
+            # target frames per source SAMPLE (vcvits.py:206); this build feeds HuBERT features, whose lengths are
+            # in feature frames = source samples / 320 (content_encoder.py:54-56), so the scale is per frame
+            len_scale = (d.target_sampling_rate / d.hop_length) / d.source_sampling_rate * 320
             y_hat, mask, _ = self.net_g.infer(batch["x_hubert_features_values"], batch["x_hubert_features_lengths"],
                                               batch["x_pitch_values"], batch["x_pitch_lengths"],
                                               sid=batch.get("sid", None), length_scale=len_scale, max_len=1000)
@@ -137,6 +141,16 @@ class VCVITS(nn.Module):
                                               d.target_sampling_rate, d.hop_length, d.win_length, d.mel_fmin,
                                               d.mel_fmax)
         self.net_g.train()
+        writer = getattr(getattr(self, "logger", None), "experiment", None)
+        if writer is not None:
+            from .. import utils
+            y_wav, y_len = batch["y_wav_values"], batch["y_wav_lengths"]
+            utils.summarize(writer=writer, global_step=getattr(self, "global_step", 0),
+                            images={"gen/mel": utils.plot_spectrogram_to_numpy(y_hat_mel[0].cpu().numpy()),
+                                    "gt/mel": utils.plot_spectrogram_to_numpy(mel[0].cpu().numpy())},
+                            audios={"gen/audio": y_hat[0, :, :int(y_hat_lengths[0])],
+                                    "gt/audio": y_wav[0, :, :int(y_len[0])]},
+                            audio_sampling_rate=d.target_sampling_rate)
         return y_hat, y_hat_lengths, mel, y_hat_mel
 
     # ------------------------------------------------------------------------------------------
