@@ -44,6 +44,8 @@ CONV_CASES = [
     (4, 64, 96, 5, 5, 1, 2, 1, 1),
     (3, 128, 64, 33, 5, 1, 2, 1, 1),
     (2, 1024, 1024, 9, 5, 1, 2, 1, 1),
+    (3, 256, 512, 384, 1, 1, 0, 1, 1),  # pointwise conv on the DMA kernel
+    (2, 1025, 256, 204, 1, 1, 0, 1, 1),
     (4, 64, 96, 64, 5, 1, 2, 1, 1),   # folded forward / data gradient, unfolded weight gradient
     # few output tiles: reduction split over several blocks per tile + finishing pass
     (16, 512, 512, 20, 5, 1, 2, 1, 1),

@@ -346,13 +346,16 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // measured on the bench step: the packed / DMA path wins for deep reductions over long rows (k >= 5, or
   // k >= 3 for <= 64 output channels, and >= 160 positions per batch element); short rows and wide k = 3
   // layers stay on the register-staged kernel (or take the split mode below)
-  bool normal_ok = a.phases > 1 ? (a.K >= 4 && U >= 160) : (a.K >= (a.Mg <= 64 ? 3 : 5) && U >= 160);
-  if (!normal_ok && (a.phases > 1 || a.K < 3 || U < 128)) return false;
+  // k = 1 / 2 (pointwise convs of the WaveNet stacks, flow and attention projections): plain GEMMs, taken when the
+  // reduction is deep enough to amortise the staging
+  const bool pointwise_ok = a.K <= 2 && a.Cg * a.K >= 128;
+  bool normal_ok = a.phases > 1 ? (a.K >= 4 && U >= 160) : ((a.K >= (a.Mg <= 64 ? 3 : 5) || pointwise_ok) && U >= 160);
+  if (!normal_ok && (a.phases > 1 || (a.K < 3 && !pointwise_ok) || U < 128)) return false;
   const int nph = a.phases > 1 ? a.phases : 1;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
   if (normal_ok && U > 160 && U <= 224) {
     if (a.Mg >= 128 && blocks(128, 224) >= (nph > 1 ? 128 : 224) && make_plan(a, 128, 224, pl)) { pl.variant = 2; return true; }
-    if (a.Mg >= 64 && make_plan(a, 64, 224, pl)) { pl.variant = 3; return true; }
+    if (a.Mg >= 64 && blocks(64, 224) >= (a.Mg >= 128 ? 192 : 1) && make_plan(a, 64, 224, pl)) { pl.variant = 3; return true; }
   }
   // rows just past 256 positions (period 37 strided gradients: 259): one 288-wide tile, not 256 + 3
   if (normal_ok && U > 256 && U <= 288 && a.Mg >= 128 && blocks(128, 288) >= 128 && make_plan(a, 128, 288, pl)) {
