@@ -147,6 +147,12 @@ int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y,
                     int P, int K, int stride, int dil, int pad, int out_act, float slope, void* stream);
 int vcv_conv_c1_dgrad(const float* dy, const float* w, float* dx, int B, int M, int Tin, int Tout, int P, int K,
                       int stride, int dil, int pad, void* stream);
+/* One-frame pointwise layers (speaker conditioning `cond_layer` / `cond`: Conv1d(gin, M, 1) applied to g [B, gin, 1],
+ * modules.py:126-131 and the hub generator): x [B, C], w [M, C], y / dy [B, M], B <= 32.  Forward fuses the bias;
+ * dgrad overwrites dx [B, C]; wgrad ADDS onto dw [M, C]. */
+int vcv_linear_t1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int M, void* stream);
+int vcv_linear_t1_dgrad(const float* dy, const float* w, float* dx, int B, int C, int M, void* stream);
+int vcv_linear_t1_wgrad(const float* dy, const float* x, float* dw, int B, int C, int M, void* stream);
 int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const float* baux, float* dw, int B,
                    int M, int C, int Ta, int Tb, int P, int K, int s, int d, int off, int a_tf, int b_tf,
                    float slope, float alpha, void* stream);

@@ -164,3 +164,25 @@ def test_resblock_style_fusions(gpu):
     _cmp("dw1", w1g.grad, w1r.grad)
     _cmp("dw2", w2g.grad, w2r.grad)
     _cmp("db1", b1g.grad, b1r.grad)
+
+
+@pytest.mark.parametrize("case", [(16, 256, 6144), (2, 8, 96), (32, 256, 1024), (1, 300, 33)])
+def test_one_frame_pointwise_layer(gpu, case):
+    """Speaker-conditioning layers: Conv1d(C, M, 1) on [B, C, 1] (vcv_linear_t1_*), forward and all gradients."""
+    from vcvits_amd import ops
+    B, C, M = case
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, C, 1, generator=gen)
+    w = torch.randn(M, C, 1, generator=gen) / C ** 0.5
+    b = torch.randn(M, generator=gen)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv1d(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=gen)
+    yr.backward(gy)
+    xg, wg, bg = (t.clone().to(gpu).requires_grad_(True) for t in (x, w, b))
+    yg = ops.conv1d(xg, wg, bg)
+    yg.backward(gy.to(gpu))
+    _cmp("y", yg, yr.detach())
+    _cmp("dx", xg.grad, xr.grad)
+    _cmp("dw", wg.grad, wr.grad)
+    _cmp("db", bg.grad, br.grad)

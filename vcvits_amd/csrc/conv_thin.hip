@@ -175,6 +175,100 @@ conv_c1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, 
 
 }  // namespace
 
+// ---- one-frame pointwise layers (speaker conditioning: Conv1d(gin, 2*H*L, 1) on g [B, gin, 1]) ------------
+// A [M, C] matrix against B <= 32 vectors: HBM-bound on the weight matrix, far too few columns for a GEMM tile.
+constexpr int T1_BMAX = 32;
+
+namespace {
+// y[b, m] = bias[m] + sum_c w[m, c] * x[b, c]: one wavefront per output row, lanes along c
+__global__ void __launch_bounds__(256)
+linear_t1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                     float* __restrict__ y, int B, int C, int M) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float acc[T1_BMAX];
+#pragma unroll
+  for (int b = 0; b < T1_BMAX; ++b) acc[b] = 0.f;
+  const float* wr = w + (size_t)m * C;
+  for (int c = lane; c < C; c += 64) {
+    const float wv = wr[c];
+#pragma unroll
+    for (int b = 0; b < T1_BMAX; ++b)
+      if (b < B) acc[b] += wv * x[(size_t)b * C + c];
+  }
+  const float bv = bias ? bias[m] : 0.f;
+#pragma unroll
+  for (int b = 0; b < T1_BMAX; ++b) {
+    if (b < B) {
+      const float s = wsum(acc[b]);
+      if (lane == 0) y[(size_t)b * M + m] = s + bv;
+    }
+  }
+}
+
+// dx[b, c] = sum_m w[m, c] * dy[b, m]: threads along c, the rows split over grid.y and combined with atomics
+__global__ void __launch_bounds__(256)
+linear_t1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B, int C,
+                       int M, int mper) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int m_lo = blockIdx.y * mper, m_hi = m_lo + mper < M ? m_lo + mper : M;
+  if (c >= C) return;
+  float acc[T1_BMAX];
+#pragma unroll
+  for (int b = 0; b < T1_BMAX; ++b) acc[b] = 0.f;
+  for (int m = m_lo; m < m_hi; ++m) {
+    const float wv = w[(size_t)m * C + c];
+#pragma unroll
+    for (int b = 0; b < T1_BMAX; ++b)
+      if (b < B) acc[b] += wv * dy[(size_t)b * M + m];  // wave-uniform address: one broadcast load
+  }
+#pragma unroll
+  for (int b = 0; b < T1_BMAX; ++b)
+    if (b < B) unsafeAtomicAdd(dx + (size_t)b * C + c, acc[b]);
+}
+
+// dw[m, c] += sum_b dy[b, m] * x[b, c]
+__global__ void __launch_bounds__(256)
+linear_t1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int B, int C,
+                       int M) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i - (size_t)m * C);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dy[(size_t)b * M + m] * x[(size_t)b * C + c];
+  dw[i] += s;
+}
+}  // namespace
+
+extern "C" int vcv_linear_t1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int M,
+                                 void* stream) {
+  if (!x || !w || !y || B <= 0 || B > T1_BMAX || C <= 0 || M <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(linear_t1_fwd_kernel, dim3(vcv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, C, M);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_linear_t1_dgrad(const float* dy, const float* w, float* dx, int B, int C, int M, void* stream) {
+  if (!dy || !w || !dx || B <= 0 || B > T1_BMAX || C <= 0 || M <= 0) return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * C, st) != hipSuccess) return VCV_EHIP;
+  const int nct = vcv_cdiv(C, 256);
+  int msplit = 512 / nct;
+  if (msplit > M / 16) msplit = M / 16;
+  if (msplit < 1) msplit = 1;
+  const int mper = vcv_cdiv(M, msplit);
+  hipLaunchKernelGGL(linear_t1_dgrad_kernel, dim3(nct, vcv_cdiv(M, mper)), dim3(256), 0, st, dy, w, dx, B, C, M, mper);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_linear_t1_wgrad(const float* dy, const float* x, float* dw, int B, int C, int M, void* stream) {
+  if (!dy || !x || !dw || B <= 0 || C <= 0 || M <= 0) return VCV_EINVAL;
+  const size_t n = (size_t)M * C;
+  hipLaunchKernelGGL(linear_t1_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dw,
+                     B, C, M);
+  return vcv_check_launch();
+}
+
 extern "C" int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin,
                                int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
                                void* stream) {

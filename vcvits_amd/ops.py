@@ -532,9 +532,46 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
+class _LinearT1Fn(torch.autograd.Function):
+    """Pointwise conv on ONE frame: y[b, m, 0] = bias[m] + sum_c w[m, c, 0] x[b, c, 0] (the speaker-conditioning
+    layers: a [M, C] matrix against <= 32 vectors -- matrix-vector kernels, not a GEMM tile)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w, bias = _f32c(x), _f32c(w), _f32c(bias)
+        B, C, M = x.shape[0], x.shape[1], w.shape[0]
+        y = torch.empty((B, M, 1), device=x.device, dtype=torch.float32)
+        check(lib().vcv_linear_t1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, M, stream()), "vcv_linear_t1_fwd")
+        ctx.has_bias = bias is not None
+        ctx.w_sink, ctx.b_sink = _sink(w), _sink(bias)
+        ctx.w_tmp = w.requires_grad and not w.is_leaf
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C, M = x.shape[0], x.shape[1], w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().vcv_linear_t1_dgrad(ptr(dy), ptr(w), ptr(dx), B, C, M, stream()), "vcv_linear_t1_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = ctx.w_sink[0].view(w.shape) if ctx.w_sink is not None else _wgrad_zeros(w.shape, dy.device, ctx.w_tmp)
+            check(lib().vcv_linear_t1_wgrad(ptr(dy), ptr(x), ptr(dw), B, C, M, stream()), "vcv_linear_t1_wgrad")
+            dw = _sunk(ctx.w_sink, dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _sunk(ctx.b_sink, bias_grad(dy, out=ctx.b_sink[0] if ctx.b_sink is not None else None))
+        return dx, dw, db
+
+
 def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, in_leaky=False, out_act=ACT_NONE,
            slope=0.1, res=None):
     """Conv1d on [B,C,T] or the (k,1) Conv2d of the period discriminators on [B,C,H,P]."""
+    if (x.dim() == 3 and x.shape[2] == 1 and w.dim() == 3 and w.shape[2] == 1 and groups == 1 and stride == 1 and pad == 0
+            and not in_leaky and out_act == ACT_NONE and res is None and x.shape[0] <= 32 and w.shape[0] >= 32):
+        return _LinearT1Fn.apply(x, w, bias)
     return _ConvFn.apply(x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, False)
 
 
