@@ -324,6 +324,12 @@ __global__ void rel_value_fwd_kernel(const float* __restrict__ P, const float* _
 //   dS = P * (dPfull - sum_j dPfull*P), zero where masked; writes dS (in place over dP) and dSt.
 //   dembv[r,d] += P[i,i+r-w]*dO[d,i];  dembk[r,d] += dS[i,i+r-w]*qscale*q[d,i];
 //   dq_band[g,d,i] = qscale * sum_r dS[i,i+r-w]*embk[r,d]   (written, not accumulated)
+// One workgroup (a wavefront) handles RS_ROWS query rows of one (batch, head): the gradients of the two
+// relative-position tables are summed over those rows in registers and leave with ONE atomic per table entry
+// (a workgroup per row hammered 2*(2w+1)*dk addresses with T*B*H-way contention: 385 us for a 1.3 M-element
+// softmax).
+constexpr int RS_ROWS = 16, RS_NRMAX = 16, RS_DD = 2;
+
 __global__ void __launch_bounds__(64)
 rel_softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ Pd, float* __restrict__ dP,
                        const float* __restrict__ dO,
@@ -331,53 +337,77 @@ rel_softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ Pd
                        const float* __restrict__ embv, const float* __restrict__ mask, float* __restrict__ dSt,
                        float* __restrict__ dqband, float* __restrict__ dembk, float* __restrict__ dembv, int H,
                        int dk, int T, int w, float qscale) {
-  const int i = blockIdx.x, g = blockIdx.y;
+  const int g = blockIdx.y;
   const int b = g / H;
   const int lane = threadIdx.x;
   const int nr = 2 * w + 1;
   __shared__ float relv[32];
   __shared__ float dsb[32];
-  for (int r = 0; r < nr; ++r) {
-    float s = 0.f;
-    for (int d = lane; d < dk; d += 64) s += dO[((size_t)g * dk + d) * T + i] * embv[r * dk + d];
-    s = wsum_all(s);
-    if (lane == 0) relv[r] = s;
-  }
-  __syncthreads();
-  const float* Prow = P + ((size_t)g * T + i) * T;
-  const float* Pdrow = Pd + ((size_t)g * T + i) * T;  // dropped probabilities (== P when p_dropout = 0)
-  float* dProw = dP + ((size_t)g * T + i) * T;
-  float dot = 0.f;
-  for (int j = lane; j < T; j += 64) {
-    float v = dProw[j];
-    const int r = j - i + w;
-    if (r >= 0 && r < nr) v += relv[r];
-    dProw[j] = v;
-    dot += v * Pdrow[j];
-  }
-  dot = wsum_all(dot);
-  const float mi = mask[(size_t)b * T + i];
-  for (int j = lane; j < T; j += 64) {
-    float ds = Pdrow[j] * dProw[j] - Prow[j] * dot;
-    if (mi * mask[(size_t)b * T + j] == 0.f) ds = 0.f;
-    dProw[j] = ds;
-    dSt[((size_t)g * T + j) * T + i] = ds;
-    const int r = j - i + w;
-    if (r >= 0 && r < nr) dsb[r] = ds;
-  }
-  __syncthreads();
-  for (int d = lane; d < dk; d += 64) {
-    const float qv = q[((size_t)g * dk + d) * T + i] * qscale;
-    const float dov = dO[((size_t)g * dk + d) * T + i];
-    float acc = 0.f;
+  float ek[RS_NRMAX][RS_DD], ev[RS_NRMAX][RS_DD];
+#pragma unroll
+  for (int r = 0; r < RS_NRMAX; ++r)
+#pragma unroll
+    for (int dd = 0; dd < RS_DD; ++dd) ek[r][dd] = ev[r][dd] = 0.f;
+  const int i_lo = blockIdx.x * RS_ROWS, i_hi = i_lo + RS_ROWS < T ? i_lo + RS_ROWS : T;
+  for (int i = i_lo; i < i_hi; ++i) {
     for (int r = 0; r < nr; ++r) {
-      const int j = i + r - w;
-      if (j < 0 || j >= T) continue;
-      acc += dsb[r] * embk[r * dk + d];
-      unsafeAtomicAdd(dembk + r * dk + d, dsb[r] * qv);
-      unsafeAtomicAdd(dembv + r * dk + d, Pdrow[j] * dov);
+      float s = 0.f;
+      for (int d = lane; d < dk; d += 64) s += dO[((size_t)g * dk + d) * T + i] * embv[r * dk + d];
+      s = wsum_all(s);
+      if (lane == 0) relv[r] = s;
     }
-    dqband[((size_t)g * dk + d) * T + i] = acc * qscale;
+    __syncthreads();
+    const float* Prow = P + ((size_t)g * T + i) * T;
+    const float* Pdrow = Pd + ((size_t)g * T + i) * T;  // dropped probabilities (== P when p_dropout = 0)
+    float* dProw = dP + ((size_t)g * T + i) * T;
+    float dot = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      float v = dProw[j];
+      const int r = j - i + w;
+      if (r >= 0 && r < nr) v += relv[r];
+      dProw[j] = v;
+      dot += v * Pdrow[j];
+    }
+    dot = wsum_all(dot);
+    const float mi = mask[(size_t)b * T + i];
+    for (int j = lane; j < T; j += 64) {
+      float ds = Pdrow[j] * dProw[j] - Prow[j] * dot;
+      if (mi * mask[(size_t)b * T + j] == 0.f) ds = 0.f;
+      dProw[j] = ds;
+      dSt[((size_t)g * T + j) * T + i] = ds;
+      const int r = j - i + w;
+      if (r >= 0 && r < nr) dsb[r] = ds;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dd = 0; dd < RS_DD; ++dd) {
+      const int d = lane + 64 * dd;
+      if (d >= dk) continue;
+      const float qv = q[((size_t)g * dk + d) * T + i] * qscale;
+      const float dov = dO[((size_t)g * dk + d) * T + i];
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < RS_NRMAX; ++r) {
+        const int j = i + r - w;
+        if (r >= nr || j < 0 || j >= T) continue;
+        acc += dsb[r] * embk[r * dk + d];
+        ek[r][dd] += dsb[r] * qv;
+        ev[r][dd] += Pdrow[j] * dov;
+      }
+      dqband[((size_t)g * dk + d) * T + i] = acc * qscale;
+    }
+    __syncthreads();  // relv / dsb are rewritten by the next row
+  }
+#pragma unroll
+  for (int dd = 0; dd < RS_DD; ++dd) {
+    const int d = lane + 64 * dd;
+    if (d >= dk) continue;
+#pragma unroll
+    for (int r = 0; r < RS_NRMAX; ++r) {
+      if (r >= nr) continue;
+      unsafeAtomicAdd(dembk + r * dk + d, ek[r][dd]);
+      unsafeAtomicAdd(dembv + r * dk + d, ev[r][dd]);
+    }
   }
 }
 
@@ -598,7 +628,8 @@ extern "C" int vcv_rel_softmax_bwd(const float* P, const float* Pd, float* dP, c
   const size_t ne = sizeof(float) * (2 * w + 1) * dk;
   if (hipMemsetAsync(dembk, 0, ne, ST) != hipSuccess) return VCV_EHIP;
   if (hipMemsetAsync(dembv, 0, ne, ST) != hipSuccess) return VCV_EHIP;
-  hipLaunchKernelGGL(rel_softmax_bwd_kernel, dim3(T, B * H), dim3(64), 0, ST, P, Pd, dP, dO, q, embk, embv, mask, dSt,
+  if (2 * w + 1 > RS_NRMAX || dk > 64 * RS_DD) return VCV_EINVAL;
+  hipLaunchKernelGGL(rel_softmax_bwd_kernel, dim3(vcv_cdiv(T, RS_ROWS), B * H), dim3(64), 0, ST, P, Pd, dP, dO, q, embk, embv, mask, dSt,
                      dqband, dembk, dembv, H, dk, T, w, qscale);
   return vcv_check_launch();
 }
