@@ -64,6 +64,8 @@ __global__ void fill_bias_kernel(float* __restrict__ y, const float* __restrict_
 }
 
 // one workgroup per weight row (m, c); a: [B, M, Ta, P] (un-shifted), bsh: [B, C, Tb, P] (shifted)
+// PLAIN: no operand transforms (the usual case: dy arrives pre-masked) -- no per-element transform switch
+template <bool PLAIN>
 __global__ void __launch_bounds__(256)
 thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, const float* __restrict__ aaux,
                   const float* __restrict__ baux, float* __restrict__ dw, int B, int M, int C, int Ta, int Tb,
@@ -81,17 +83,22 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
     const size_t abase = ((size_t)b * M + m) * (size_t)U;
     const size_t bbase = ((size_t)b * C + c) * (size_t)Tb * P;
     const int u_lo = blockIdx.z * uper, u_hi = u_lo + uper < U ? u_lo + uper : U;
+    const float* brow = bsh + bbase;
+    const int kstep = d * P;
     for (int u = u_lo + threadIdx.x; u < u_hi; u += 256) {
       float av = a[abase + u];
-      av = vcv_tf(av, a_tf, aaux, abase + u, slope);
+      if (!PLAIN) av = vcv_tf(av, a_tf, aaux, abase + u, slope);
       const int q = u / P, pc = u - q * P;
+      const int r0 = q * s + off;
+      const int i0 = r0 * P + pc;  // element offset of tap 0 inside the (b, c) row (fits 32 bits: checked by the launcher)
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-          const int r = q * s + k * d + off;
+          const int r = r0 + k * d;
           if (r >= 0 && r < Tb) {
-            const size_t bi = bbase + (size_t)r * P + pc;
-            acc[k] += av * vcv_tf(bsh[bi], b_tf, baux, bi, slope);
+            const int bi = i0 + k * kstep;
+            const float bv = PLAIN ? brow[bi] : vcv_tf(brow[bi], b_tf, baux, bbase + bi, slope);
+            acc[k] += av * bv;
           }
         }
       }
@@ -100,6 +107,7 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
+    if (k >= K) break;  // uniform
     const float v = wsum(acc[k]);
     if (lane == 0) red[wv][k] = v;
   }
@@ -329,7 +337,13 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   if (usplit > U / 1024) usplit = U / 1024;
   if (usplit < 1) usplit = 1;
   const int uper = (vcv_cdiv(U, (int)usplit) + 255) & ~255;
-  hipLaunchKernelGGL(thin_wgrad_kernel, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0, (hipStream_t)stream,
-                     a, bsh, aaux, baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha, bper, uper);
+  if (a_tf == VCV_TF_NONE && b_tf == VCV_TF_NONE)
+    hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0,
+                       (hipStream_t)stream, a, bsh, aaux, baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha,
+                       bper, uper);
+  else
+    hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0,
+                       (hipStream_t)stream, a, bsh, aaux, baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha,
+                       bper, uper);
   return vcv_check_launch();
 }
