@@ -36,16 +36,27 @@ conv_m1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   const int t = u / P, pc = u - t * P;
   const long long TinP = (long long)Tin * P;
   const float* xb = x + (size_t)b * C * TinP;
+  // the tap offsets inside a channel row do not depend on the channel: hoisted (0 with weight 0 outside the row)
+  int offk[KMAX];
+  float okk[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int r = t * s + k * d - pad;
+    const bool ok = k < K && r >= 0 && r < Tin;
+    offk[k] = ok ? r * P + pc : 0;
+    okk[k] = ok ? 1.f : 0.f;
+  }
   float acc = 0.f;
+#pragma unroll 4
   for (int c = c_lo; c < c_hi; ++c) {
     const float* xr = xb + (size_t)c * TinP;
     const float* wr = w + (size_t)c * K;
-    for (int k = 0; k < K; ++k) {
-      const int r = t * s + k * d - pad;
-      if (r >= 0 && r < Tin) {
-        float v = xr[(size_t)r * P + pc];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        float v = xr[offk[k]];
         if (in_leaky) v = vcv_leaky(v, slope);
-        acc += wr[k] * v;
+        acc += wr[k] * okk[k] * v;
       }
     }
   }
