@@ -2,8 +2,10 @@
 // (discriminator.py:55-58: 16->64 g4, 64->256 g16, 256->1024 g64, 1024->1024 g256; 4 input
 // channels per group, 16 or 4 output channels per group).
 //
-// With 4x(4|16) channels per group a 32x32 MFMA tile would be 75-88 % padding, so these run as
-// direct fp32 FMA kernels: a workgroup owns one (batch element, group, time tile); the group's
+// With 4x(4|16) channels per group a 32x32 MFMA tile would be 75-88 % padding.  The 16-channel groups' forward
+// and weight gradient run on v_mfma_f32_16x16x4_f32 (one group = one 16-row tile, K = the 4 input channels: no
+// padding; grouped_fwd_mfma_kernel / grouped_wgrad_mfma_kernel below); the 4-channel groups and every data
+// gradient (4 output rows per group) run as direct fp32 FMA kernels: a workgroup owns one (batch element, group, time tile); the group's
 // input span and its (tiny) weight block sit in LDS; each lane computes a few output times for
 // ALL channels of the group from 16-byte LDS reads (conflict-free x windows, broadcast weights).
 //   forward   y[b,g*Mg+m,t]   = act(bias + sum_{ci,k} w[g*Mg+m,ci,k] * x[b,g*4+ci,4t+k-20])
@@ -200,11 +202,69 @@ grouped_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
 }  // namespace
 
 // x [B, G*4, Tin], w [G*Mg, 4, 41], y [B, G*Mg, Tout], Tout = (Tin + 40 - 41)/4 + 1; Mg in {4, 16}
+namespace {
+// ---- forward on the matrix cores (16 output channels per group = one 16x16 tile) -----------------------------
+// v_mfma_f32_16x16x4_f32 per tap: A[m][ci] = w[g*16+m][ci][tap], B[ci][n] = x[g*4+ci][4*(t0+n) + tap - 20], so the
+// K dimension of the instruction is exactly the group's 4 input channels and nothing is padded.  The input span
+// is staged de-interleaved by position mod 4 (xs[ci][phase][q]): for one tap all 16 columns read consecutive
+// floats (conflict-free), the weights are staged [tap][ci][m] (a 64-float row per instruction).
+// Workgroup = 4 waves = 4 x 64 output times of one (batch, group); grid (Tout/256, G, B).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+grouped_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                        float* __restrict__ y, int G, int Tin, int Tout, int act, float slope) {
+  constexpr int TT = 256, MG = 16;
+  constexpr int QN = TT + 11;           // quarter-rate samples per phase: 4*(TT-1) + 40 < 4*QN
+  constexpr int QP = QN + 1;            // phase pitch
+  __shared__ float xs[CG][4][QP];
+  __shared__ float ws[K][CG * MG + 1];  // [tap][ci*16 + m], odd pitch: the staging scatter below is conflict-free
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
+  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+  const int in0 = t0 * S - PAD;  // a multiple of 4
+  for (int i = tid; i < CG * 4 * QN; i += 256) {
+    const int ci = i / (4 * QN), j = i - ci * (4 * QN);  // j: offset inside the span, coalesced global reads
+    const int ti = in0 + j;
+    xs[ci][j & 3][j >> 2] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+  }
+  const float* wg = w + (size_t)g * MG * CG * K;  // the group's [m][ci][k] block is contiguous: coalesced reads
+  for (int i = tid; i < K * CG * MG; i += 256) {
+    const int k = i % K, ci = (i / K) % CG, m = i / (K * CG);
+    ws[k][ci * MG + m] = wg[i];
+  }
+  __syncthreads();
+  const int n = lane & 15, kq = lane >> 4;  // column / k index of this lane's A and B elements
+  f32x4_t acc[4];
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int tw = wave * 64;  // first output time of this wave inside the tile
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const float a = ws[k][lane];                  // A[m = n][ci = kq]: lane = kq*16 + n
+    const float* xr = &xs[kq][k & 3][(k >> 2) + tw + n];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xr[tl * 16], acc[tl], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) {
+    const int t = t0 + tw + tl * 16 + n;
+    if (t >= Tout) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = kq * 4 + r;
+      float v = acc[tl][r] + (bias ? bias[g * MG + m] : 0.f);
+      y[((size_t)b * G * MG + (size_t)g * MG + m) * Tout + t] = vcv_act(v, act, slope);
+    }
+  }
+}
+}  // namespace
+
 extern "C" int vcv_grouped41_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg,
                                  int Tin, int Tout, int out_act, float slope, void* stream) {
   if (!x || !w || !y || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
   dim3 grid(vcv_cdiv(Tout, 256), G, B);
-  if (Mg == 16) hipLaunchKernelGGL(grouped_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
+  if (Mg == 16) hipLaunchKernelGGL(grouped_fwd_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
   else hipLaunchKernelGGL(grouped_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
   return vcv_check_launch();
 }
@@ -219,12 +279,102 @@ extern "C" int vcv_grouped41_dgrad(const float* dy, const float* yaux, const flo
   return vcv_check_launch();
 }
 
+namespace {
+// ---- weight gradient on the matrix cores (16 output channels per group) ---------------------------------------
+// Per group a [16 x 164] result, reduction over (batch, time): v_mfma_f32_16x16x4_f32 with A[m][kk] = dye[m][t+kk]
+// (4 consecutive output times), B[kk][(ci, k)] = x[ci][4*(t+kk) + k - 20]: 11 column tiles of 16 (164 -> 176,
+// the padding columns are clamped reads and never stored).  Workgroup = (group, batch element, time chunk); its
+// four waves take a quarter of each 256-time stage, add their partial tiles into one LDS tile and the workgroup
+// leaves with one atomic per weight.
+__global__ void __launch_bounds__(256)
+grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ x,
+                          float* __restrict__ dw, int G, int Tin, int Tout, int dtf, float slope, int nstage, int uper,
+                          int nunit) {
+  constexpr int MG = 16, TT = 256, NT = 11, NW = CG * K;   // 164 weights per output channel
+  constexpr int SPAN = S * TT + KP, DP = TT + 1;
+  __shared__ float xs[CG][SPAN];
+  __shared__ float ds[MG][DP];
+  __shared__ float racc[MG][NT * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x;
+  // work units = (batch element, 256-time stage); this workgroup takes units [u_lo, u_hi) so that the whole grid
+  // is ~512 workgroups and each leaves with one set of atomics
+  const int u_lo = blockIdx.y * uper, u_hi = u_lo + uper < nunit ? u_lo + uper : nunit;
+  const int j16 = lane & 15, kk = lane >> 4;
+  int boff[NT];  // LDS offset of this lane's B element per column tile: xs[ci][4*kk + k]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = nt * 16 + j16;
+    if (n > NW - 1) n = NW - 1;
+    const int ci = n / K, k = n - ci * K;
+    boff[nt] = ci * SPAN + S * kk + k;
+  }
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < MG * NT * 16; i += 256) (&racc[0][0])[i] = 0.f;
+  for (int unit = u_lo; unit < u_hi; ++unit) {
+    const int b = unit / nstage, t0 = (unit - b * nstage) * TT;
+    const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+    const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
+    __syncthreads();
+    const int in0 = t0 * S - PAD;
+    for (int i = tid; i < CG * SPAN; i += 256) {
+      const int ci = i / SPAN, j = i - ci * SPAN;
+      const int ti = in0 + j;
+      xs[ci][j] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+    }
+    for (int i = tid; i < MG * TT; i += 256) {
+      const int m = i / TT, j = i - m * TT;
+      const int t = t0 + j;
+      float v = 0.f;
+      if (t < Tout) {
+        const size_t gi = ybase + (size_t)m * Tout + t;
+        v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
+      }
+      ds[m][j] = v;
+    }
+    __syncthreads();
+    const float* xf = &xs[0][0];
+#pragma unroll 2
+    for (int tq = wave * 64; tq < wave * 64 + 64; tq += 4) {
+      const float a = ds[j16][tq + kk];            // A[m = j16][kk]
+      const float* xq = xf + S * tq;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xq[boff[nt]], acc[nt], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&racc[kk * 4 + r][nt * 16 + j16], acc[nt][r]);
+  __syncthreads();
+  float* dwg = dw + (size_t)g * MG * NW;
+  for (int i = tid; i < MG * NW; i += 256) {
+    const int m = i / NW, n = i - m * NW;
+    unsafeAtomicAdd(dwg + i, racc[m][n]);
+  }
+}
+}  // namespace
+
 extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
                                    int Tin, int Tout, int dtf, float slope, void* stream) {
   if (!dy || !x || !dw || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
   if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
   // time chunks so that the grid has >= ~1000 workgroups
   int nchunk = 1;
+  if (Mg == 16) {
+    const int nstage = vcv_cdiv(Tout, 256), nunit = B * nstage;
+    int wg_per_group = 512 / G;
+    if (wg_per_group < 1) wg_per_group = 1;
+    if (wg_per_group > nunit) wg_per_group = nunit;
+    const int uper = vcv_cdiv(nunit, wg_per_group);
+    hipLaunchKernelGGL(grouped_wgrad_mfma_kernel, dim3(G, vcv_cdiv(nunit, uper)), dim3(256), 0, (hipStream_t)stream, dy, yaux,
+                       x, dw, G, Tin, Tout, dtf, slope, nstage, uper, nunit);
+    return vcv_check_launch();
+  }
   while ((long long)G * B * nchunk < 1024 && Tout / (nchunk * 2) >= 128) nchunk *= 2;
   const int tchunk = vcv_cdiv(vcv_cdiv(Tout, nchunk), 128) * 128;
   dim3 grid(G, vcv_cdiv(Tout, tchunk), B);
