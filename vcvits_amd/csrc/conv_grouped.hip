@@ -269,12 +269,78 @@ extern "C" int vcv_grouped41_fwd(const float* x, const float* w, const float* bi
   return vcv_check_launch();
 }
 
+namespace {
+// ---- data gradient on the matrix cores (16 output channels per group) -----------------------------------------
+// dx[ci][4q+r] = sum_j sum_m w[m][ci][r+4j] * dye[m][q+5-j]: with rows = (ci, r) -- the 4 input channels x the 4
+// residues of the stride -- this is a 16-row GEMM whose shift (5 - j) does not depend on the row, so each of the
+// 11 tap groups is four v_mfma_f32_16x16x4_f32 (K = the 16 output channels in chunks of 4).  A lane ends up with
+// the four residues of one (ci, q): one 16-byte store, 256 B per 16 lanes.
+__global__ void __launch_bounds__(256)
+grouped_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ w,
+                          float* __restrict__ dx, int G, int Tin, int Tout, int dtf, float slope) {
+  constexpr int MG = 16, QT = 256, NJ = 11;
+  constexpr int DSP = 272;  // >= QT + 10 + 1, and == 16 (mod 32): the two k-halves of a B fragment hit disjoint banks
+  __shared__ float ds[MG][DSP];
+  __shared__ float wsd[NJ * 4][64];  // [(j, m chunk)][kq*16 + ci*4 + r]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.x * QT, g = blockIdx.y, b = blockIdx.z;
+  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
+  for (int i = tid; i < MG * DSP; i += 256) {
+    const int m = i / DSP, j = i - m * DSP;
+    const int t = q0 - 5 + j;
+    float v = 0.f;
+    if (t >= 0 && t < Tout) {
+      const size_t gi = ybase + (size_t)m * Tout + t;
+      v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
+    }
+    ds[m][j] = v;
+  }
+  for (int i = tid; i < NJ * 4 * 64; i += 256) (&wsd[0][0])[i] = 0.f;
+  __syncthreads();
+  const float* wg = w + (size_t)g * MG * CG * K;
+  for (int i = tid; i < MG * CG * K; i += 256) {
+    const int k = i % K, ci = (i / K) % CG, m = i / (K * CG);
+    wsd[(k >> 2) * 4 + (m >> 2)][(m & 3) * 16 + ci * 4 + (k & 3)] = wg[i];
+  }
+  __syncthreads();
+  const int n = lane & 15, kq = lane >> 4;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int qw = wave * 64;
+#pragma unroll 1
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int mc = 0; mc < 4; ++mc) {
+      const float a = wsd[j * 4 + mc][lane];                     // A[row = (ci, r)][m = mc*4 + kq]
+      const float* dr = &ds[mc * 4 + kq][qw + n + 10 - j];       // B[m][q]: dye[m][q + 5 - j]
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dr[tl * 16], acc[tl], 0, 0, 0);
+    }
+  }
+  // lane holds rows 4*kq .. 4*kq+3 = (ci = kq, r = 0..3) of column q: four consecutive input times
+  float* dxr = dx + ((size_t)b * G * CG + (size_t)g * CG + kq) * Tin;
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) {
+    const int q = q0 + qw + tl * 16 + n;
+    const int u = 4 * q;
+    if (u + 3 < Tin && (Tin & 3) == 0) {
+      *reinterpret_cast<f32x4_t*>(dxr + u) = acc[tl];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (u + r < Tin) dxr[u + r] = acc[tl][r];
+    }
+  }
+}
+}  // namespace
+
 extern "C" int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg,
                                    int Tin, int Tout, int dtf, float slope, void* stream) {
   if (!dy || !w || !dx || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
   if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
   dim3 grid(vcv_cdiv(vcv_cdiv(Tin, 4), 256), G, B);
-  if (Mg == 16) hipLaunchKernelGGL(grouped_dgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
+  if (Mg == 16) hipLaunchKernelGGL(grouped_dgrad_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
   else hipLaunchKernelGGL(grouped_dgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
   return vcv_check_launch();
 }
