@@ -18,27 +18,31 @@ namespace {
 
 constexpr int CG = 4, K = 41, S = 4, PAD = 20, KP = 44;  // taps padded to a multiple of 4
 
-// ---- forward: block = 256 lanes, TT = 256 output times, lane = one output time, all Mg outputs ----
-template <int MG>
+// ---- forward: block = 256 lanes = GB groups x TT output times (TT = 256 / GB: short pooled scales would leave
+// three quarters of a 256-time tile idle); lane = one output time of one group, all Mg outputs ----
+template <int MG, int TT>
 __global__ void __launch_bounds__(256)
 grouped_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                    float* __restrict__ y, int G, int Tin, int Tout, int act, float slope) {
-  constexpr int TT = 256;
+  constexpr int GB = 256 / TT;
   constexpr int SPAN = S * TT + KP;  // input samples per channel needed by the tile
-  __shared__ __attribute__((aligned(16))) float xs[CG][SPAN];
-  __shared__ __attribute__((aligned(16))) float ws[CG][KP][MG];  // [ci][k][m]: m contiguous -> b128 broadcast reads
+  __shared__ __attribute__((aligned(16))) float xs[GB][CG][SPAN];
+  __shared__ __attribute__((aligned(16))) float ws[GB][CG][KP][MG];  // [ci][k][m]: m contiguous -> b128 broadcast reads
   const int tid = threadIdx.x;
-  const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
-  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+  const int gl = tid / TT, tl = tid - gl * TT;
+  const int t0 = blockIdx.x * TT, g0 = blockIdx.y * GB, b = blockIdx.z;
   const int in0 = t0 * S - PAD;
-  for (int i = tid; i < CG * SPAN; i += 256) {
-    const int ci = i / SPAN, j = i - ci * SPAN;
+  for (int i = tid; i < GB * CG * SPAN; i += 256) {
+    const int gg = i / (CG * SPAN), r = i - gg * (CG * SPAN);
+    const int ci = r / SPAN, j = r - ci * SPAN;
     const int ti = in0 + j;
-    xs[ci][j] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+    const bool ok = g0 + gg < G && ti >= 0 && ti < Tin;
+    xs[gg][ci][j] = ok ? x[((size_t)b * G * CG + (size_t)(g0 + gg) * CG + ci) * Tin + ti] : 0.f;
   }
-  for (int i = tid; i < CG * KP * MG; i += 256) {
-    const int m = i % MG, k = (i / MG) % KP, ci = i / (MG * KP);
-    ws[ci][k][m] = k < K ? w[((size_t)(g * MG + m) * CG + ci) * K + k] : 0.f;
+  for (int i = tid; i < GB * CG * KP * MG; i += 256) {
+    const int gg = i / (CG * KP * MG), r = i - gg * (CG * KP * MG);
+    const int m = r % MG, k = (r / MG) % KP, ci = r / (MG * KP);
+    ws[gg][ci][k][m] = (k < K && g0 + gg < G) ? w[((size_t)((g0 + gg) * MG + m) * CG + ci) * K + k] : 0.f;
   }
   __syncthreads();
   float acc[MG];
@@ -48,21 +52,21 @@ grouped_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   for (int ci = 0; ci < CG; ++ci) {
 #pragma unroll 1
     for (int k4 = 0; k4 < KP; k4 += 4) {
-      const f32x4 xv = *(const f32x4*)&xs[ci][S * tid + k4];
+      const f32x4 xv = *(const f32x4*)&xs[gl][ci][S * tl + k4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const float xk = xv[kk];
 #pragma unroll
         for (int m4 = 0; m4 < MG; m4 += 4) {
-          const f32x4 wv = *(const f32x4*)&ws[ci][k4 + kk][m4];
+          const f32x4 wv = *(const f32x4*)&ws[gl][ci][k4 + kk][m4];
           acc[m4 + 0] += wv[0] * xk; acc[m4 + 1] += wv[1] * xk;
           acc[m4 + 2] += wv[2] * xk; acc[m4 + 3] += wv[3] * xk;
         }
       }
     }
   }
-  const int t = t0 + tid;
-  if (t < Tout) {
+  const int t = t0 + tl, g = g0 + gl;
+  if (t < Tout && g < G) {
 #pragma unroll
     for (int m = 0; m < MG; ++m) {
       const int mg = g * MG + m;
@@ -74,30 +78,32 @@ grouped_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 
 // ---- dgrad: lane = one quad of input times u = 4q..4q+3 (the 4 residues), all 4 input channels ----
 // dx[ci][4q+r] = sum_m sum_j w[m][ci][r + 4j] * dye[m][q + 5 - j]   (j = 0..10; k = r+4j <= 40)
-template <int MG>
+template <int MG, int QT>
 __global__ void __launch_bounds__(256)
 grouped_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ w,
                      float* __restrict__ dx, int G, int Tin, int Tout, int dtf, float slope) {
-  constexpr int QT = 256;        // quads per block -> 1024 input times
-  constexpr int DSPAN = QT + 12; // dy positions q-5 .. q+QT-1+5 (+ pad)
-  __shared__ float ds[MG][DSPAN];
-  __shared__ __attribute__((aligned(16))) float ws[MG][KP][CG];  // [m][k][ci]
+  constexpr int GB = 256 / QT;     // groups per block (QT quads = 4*QT input times each)
+  constexpr int DSPAN = QT + 12;   // dy positions q-5 .. q+QT-1+5 (+ pad)
+  __shared__ float ds[GB][MG][DSPAN];
+  __shared__ __attribute__((aligned(16))) float ws[GB][MG][KP][CG];  // [m][k][ci]
   const int tid = threadIdx.x;
-  const int q0 = blockIdx.x * QT, g = blockIdx.y, b = blockIdx.z;
-  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
-  for (int i = tid; i < MG * DSPAN; i += 256) {
-    const int m = i / DSPAN, j = i - m * DSPAN;
+  const int gl = tid / QT, ql = tid - gl * QT;
+  const int q0 = blockIdx.x * QT, g0 = blockIdx.y * GB, b = blockIdx.z;
+  for (int i = tid; i < GB * MG * DSPAN; i += 256) {
+    const int gg = i / (MG * DSPAN), r = i - gg * (MG * DSPAN);
+    const int m = r / DSPAN, j = r - m * DSPAN;
     const int t = q0 - 5 + j;
     float v = 0.f;
-    if (t >= 0 && t < Tout) {
-      const size_t gi = ybase + (size_t)m * Tout + t;
+    if (t >= 0 && t < Tout && g0 + gg < G) {
+      const size_t gi = ((size_t)b * G * MG + (size_t)(g0 + gg) * MG + m) * Tout + t;
       v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
     }
-    ds[m][j] = v;
+    ds[gg][m][j] = v;
   }
-  for (int i = tid; i < MG * KP * CG; i += 256) {
-    const int ci = i % CG, k = (i / CG) % KP, m = i / (CG * KP);
-    ws[m][k][ci] = k < K ? w[((size_t)(g * MG + m) * CG + ci) * K + k] : 0.f;
+  for (int i = tid; i < GB * MG * KP * CG; i += 256) {
+    const int gg = i / (MG * KP * CG), r = i - gg * (MG * KP * CG);
+    const int ci = r % CG, k = (r / CG) % KP, m = r / (CG * KP);
+    ws[gg][m][k][ci] = (k < K && g0 + gg < G) ? w[((size_t)((g0 + gg) * MG + m) * CG + ci) * K + k] : 0.f;
   }
   __syncthreads();
   float acc[4][CG];  // [r][ci]
@@ -110,16 +116,17 @@ grouped_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
   for (int m = 0; m < MG; ++m) {
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
-      const float dv = ds[m][tid + 10 - j];
+      const float dv = ds[gl][m][ql + 10 - j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const f32x4 wv = *(const f32x4*)&ws[m][r + 4 * j][0];  // k = r + 4j (k > 40 rows are zero)
+        const f32x4 wv = *(const f32x4*)&ws[gl][m][r + 4 * j][0];  // k = r + 4j (k > 40 rows are zero)
         acc[r][0] += wv[0] * dv; acc[r][1] += wv[1] * dv; acc[r][2] += wv[2] * dv; acc[r][3] += wv[3] * dv;
       }
     }
   }
   // u + 20 = 4q' + r with q' = q + 5  ->  u = 4(q + 5) + r - 20 = 4q + r
-  const int q = q0 + tid;
+  const int q = q0 + ql, g = g0 + gl;
+  if (g >= G) return;
   float* dxb = dx + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
 #pragma unroll
   for (int ci = 0; ci < CG; ++ci)
@@ -265,7 +272,15 @@ extern "C" int vcv_grouped41_fwd(const float* x, const float* w, const float* bi
   if (!x || !w || !y || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
   dim3 grid(vcv_cdiv(Tout, 256), G, B);
   if (Mg == 16) hipLaunchKernelGGL(grouped_fwd_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
-  else hipLaunchKernelGGL(grouped_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act, slope);
+  else if (Tout <= 64)
+    hipLaunchKernelGGL((grouped_fwd_kernel<4, 64>), dim3(vcv_cdiv(Tout, 64), vcv_cdiv(G, 4), B), dim3(256), 0, (hipStream_t)stream, x,
+                       w, bias, y, G, Tin, Tout, out_act, slope);
+  else if (Tout <= 128)
+    hipLaunchKernelGGL((grouped_fwd_kernel<4, 128>), dim3(vcv_cdiv(Tout, 128), vcv_cdiv(G, 2), B), dim3(256), 0, (hipStream_t)stream,
+                       x, w, bias, y, G, Tin, Tout, out_act, slope);
+  else
+    hipLaunchKernelGGL((grouped_fwd_kernel<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, G, Tin, Tout, out_act,
+                       slope);
   return vcv_check_launch();
 }
 
@@ -341,7 +356,18 @@ extern "C" int vcv_grouped41_dgrad(const float* dy, const float* yaux, const flo
   if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
   dim3 grid(vcv_cdiv(vcv_cdiv(Tin, 4), 256), G, B);
   if (Mg == 16) hipLaunchKernelGGL(grouped_dgrad_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
-  else hipLaunchKernelGGL(grouped_dgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
+  else {
+    const int nq = vcv_cdiv(Tin, 4);
+    if (nq <= 64)
+      hipLaunchKernelGGL((grouped_dgrad_kernel<4, 64>), dim3(vcv_cdiv(nq, 64), vcv_cdiv(G, 4), B), dim3(256), 0, (hipStream_t)stream, dy,
+                         yaux, w, dx, G, Tin, Tout, dtf, slope);
+    else if (nq <= 128)
+      hipLaunchKernelGGL((grouped_dgrad_kernel<4, 128>), dim3(vcv_cdiv(nq, 128), vcv_cdiv(G, 2), B), dim3(256), 0, (hipStream_t)stream,
+                         dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
+    else
+      hipLaunchKernelGGL((grouped_dgrad_kernel<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf,
+                         slope);
+  }
   return vcv_check_launch();
 }
 
