@@ -141,19 +141,17 @@ grouped_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
 template <int MG>
 __global__ void __launch_bounds__(256)
 grouped_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ x,
-                     float* __restrict__ dw, int G, int Tin, int Tout, int dtf, float slope, int tchunk) {
+                     float* __restrict__ dw, int G, int Tin, int Tout, int dtf, float slope, int tchunk, int bper, int B) {
   constexpr int TT = 128;  // output times per stage
   constexpr int SPAN = S * TT + KP;
   constexpr int NOUT = MG * CG * (KP / 4);  // lanes with work: MG*4*11
   __shared__ __attribute__((aligned(16))) float xs[CG][SPAN];
   __shared__ float ds[MG][TT];
   const int tid = threadIdx.x;
-  const int g = blockIdx.x, b = blockIdx.z;
+  const int g = blockIdx.x;
   const int tlo = blockIdx.y * tchunk;
   int thi = tlo + tchunk;
   if (thi > Tout) thi = Tout;
-  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
-  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
   // each thread may own up to ceil(NOUT/256) (m, ci, k4) triples
   constexpr int NOWN = (NOUT + 255) / 256;
   float acc[NOWN][4];
@@ -161,6 +159,11 @@ grouped_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
   for (int o = 0; o < NOWN; ++o)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
+  // blockIdx.z takes bper batch elements: the partial sums stay in registers across them (one set of atomics)
+  const int b_lo = blockIdx.z * bper, b_hi = b_lo + bper < B ? b_lo + bper : B;
+  for (int b = b_lo; b < b_hi; ++b) {
+  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
   for (int t0 = tlo; t0 < thi; t0 += TT) {
     __syncthreads();
     const int in0 = t0 * S - PAD;
@@ -193,6 +196,7 @@ grouped_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
         }
       }
     }
+  }
   }
 #pragma unroll
   for (int o = 0; o < NOWN; ++o) {
@@ -469,8 +473,11 @@ extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const flo
   }
   while ((long long)G * B * nchunk < 1024 && Tout / (nchunk * 2) >= 128) nchunk *= 2;
   const int tchunk = vcv_cdiv(vcv_cdiv(Tout, nchunk), 128) * 128;
-  dim3 grid(G, vcv_cdiv(Tout, tchunk), B);
-  if (Mg == 16) hipLaunchKernelGGL(grouped_wgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk);
-  else hipLaunchKernelGGL(grouped_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk);
+  // batch elements per workgroup: as many as keep the grid at >= ~1024 workgroups (fewer atomics per weight)
+  int bper = 1;
+  while (bper * 2 <= B && (long long)G * vcv_cdiv(Tout, tchunk) * (B / (bper * 2)) >= 1024) bper *= 2;
+  dim3 grid(G, vcv_cdiv(Tout, tchunk), vcv_cdiv(B, bper));
+  if (Mg == 16) hipLaunchKernelGGL(grouped_wgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk, bper, B);
+  else hipLaunchKernelGGL(grouped_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk, bper, B);
   return vcv_check_launch();
 }
