@@ -510,7 +510,15 @@ class _ConvFn(torch.autograd.Function):
                 kw.update(out_tf=TF_DLEAKY, oaux=xs)
             dx = torch.empty_like(x)
             dxs = dx[b0:] if b0 else dx
-            if transposed:
+            if transposed and xs.dim() == 3 and xs.shape[2] <= 64 and xs.shape[0] > 1 and kw.get("xaux") is None:
+                # short input (first generator stage: 32 frames): fold the batch into the column dimension as the
+                # forward convs of short sequences do, so the strided conv this gradient is has tiles to fill
+                kwb = dict(kw)
+                if kwb.get("oaux") is not None:
+                    kwb["oaux"] = _to_bt(kwb["oaux"])
+                dxb = convT_dgrad(_to_bt(dys), w3, (1, xs.shape[1], xs.shape[2], xs.shape[0]), stride=stride, pad=pad, **kwb)
+                dxs.copy_(_from_bt(dxb))
+            elif transposed:
                 convT_dgrad(dys, w3, xs.shape, stride=stride, pad=pad, out=dxs, **kw)
             else:
                 conv_dgrad(dys, w3, xs.shape, stride=stride, pad=pad, dil=dil, groups=groups, out=dxs, **kw)
