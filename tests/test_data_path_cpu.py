@@ -105,3 +105,35 @@ def test_infer_length_scale():
     from vcvits_amd.data import infer_length_scale
     hp = types.SimpleNamespace(target_sampling_rate=22050, hop_length=256, source_sampling_rate=16000)
     assert infer_length_scale(hp) == D.length_scale(22050, 256, 16000) == (22050 / 256) / 16000
+
+
+@pytest.mark.parametrize("n,world", [(23, 2), (23, 8), (64, 8), (5, 8), (1, 2), (100, 3)])
+def test_rank_sharding_matches_torch_distributed_sampler(n, world):
+    """Utterance sharding: same per-rank index lists as torch.utils.data.DistributedSampler -- what the
+    reference's Lightning DDP run uses -- for several epochs, with and without shuffle / drop_last; the ranks
+    partition the (padded) epoch."""
+    from torch.utils.data import DistributedSampler
+    from vcvits_amd.data import DistributedUtteranceSampler, rank_indices
+
+    class _DS:
+        def __len__(self):
+            return n
+
+    for shuffle in (True, False):
+        for drop_last in (False, True):
+            for epoch in (0, 1, 7):
+                seen = []
+                for rank in range(world):
+                    ref = DistributedSampler(_DS(), num_replicas=world, rank=rank, shuffle=shuffle, seed=1234, drop_last=drop_last)
+                    ref.set_epoch(epoch)
+                    mine = rank_indices(n, world, rank, epoch=epoch, seed=1234, shuffle=shuffle, drop_last=drop_last)
+                    assert mine == list(ref), (shuffle, drop_last, epoch, rank)
+                    s = DistributedUtteranceSampler(n, world, rank, seed=1234, shuffle=shuffle, drop_last=drop_last)
+                    s.set_epoch(epoch)
+                    assert list(s) == mine and len(s) == len(ref)
+                    seen += mine
+                if not drop_last:
+                    assert set(seen) == set(range(n))          # every utterance visited
+                assert len(seen) % world == 0                   # equal work per rank
+    with pytest.raises(ValueError):
+        rank_indices(10, 2, 2)
