@@ -81,10 +81,10 @@ class Conv(nn.Module):
         w = _take_prepared(self)
         return w if w is not None else ops.weight_norm(self.weight_v, self.weight_g)
 
-    def forward(self, x, in_leaky=False, out_act=ACT_NONE, slope=LRELU_SLOPE, res=None, weight=None):
+    def forward(self, x, in_leaky=False, out_act=ACT_NONE, slope=LRELU_SLOPE, res=None, weight=None, link=None):
         w = self.effective_weight() if weight is None else weight
         return ops.conv1d(x, w, self.bias, stride=self.stride, pad=self.padding, dil=self.dilation,
-                          groups=self.groups, in_leaky=in_leaky, out_act=out_act, slope=slope, res=res)
+                          groups=self.groups, in_leaky=in_leaky, out_act=out_act, slope=slope, res=res, link=link)
 
 
 class ConvT(nn.Module):
@@ -185,8 +185,9 @@ class ResBlock1(nn.Module):
         if x_mask is not None:
             raise NotImplementedError("ResBlock1 with x_mask is never used on the VC path")
         for c1, c2 in zip(self.convs1, self.convs2):
-            xt = c1(x, in_leaky=True, slope=LRELU_SLOPE)
-            x = c2(xt, in_leaky=True, slope=LRELU_SLOPE, res=x)
+            link = ops.ResGradLink() if x.requires_grad else None  # x's two gradients are summed in c1's dgrad launch
+            xt = c1(x, in_leaky=True, slope=LRELU_SLOPE, link=(link, "dst") if link else None)
+            x = c2(xt, in_leaky=True, slope=LRELU_SLOPE, res=x, link=(link, "src") if link else None)
         return x
 
 

@@ -438,7 +438,8 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv(in_act(x), w) + bias) + res      (act and res are mutually exclusive)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, transposed):
+    def forward(ctx, x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, transposed, link=None):
+        ctx.link = link
         x, w = _f32c(x), _f32c(w)
         bias, res = _f32c(bias), _f32c(res)
         if out_act != ACT_NONE and res is not None:
@@ -472,6 +473,11 @@ class _ConvFn(torch.autograd.Function):
         stride, pad, dil, groups, in_leaky, out_act, slope, transposed = ctx.cfg
         x, w, y = ctx.saved_tensors
         dy = _f32c(dy)
+        # residual-gradient link (ResGradLink): the conv whose INPUT is another conv's residual adds that conv's
+        # residual gradient inside its own data-gradient launch instead of leaving the sum to autograd
+        link_dres = None
+        if ctx.link is not None and ctx.link[1] == "dst":
+            link_dres, ctx.link[0].dres = ctx.link[0].dres, None
         dtf = _ACT_TO_DTF[out_act]
         dx = dw = db = dres = None
         w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
@@ -490,6 +496,8 @@ class _ConvFn(torch.autograd.Function):
                 if in_leaky:
                     kw.update(out_tf=TF_DLEAKY, oaux=x)
                 dx = _from_bt(conv_dgrad(dyt, w3, x.shape, stride=stride, pad=pad, dil=dil, groups=groups, **kw))
+                if link_dres is not None:
+                    dx.add_(link_dres)
             if ctx.needs_input_grad[1]:
                 wout = ctx.w_sink[0].view(w3.shape) if ctx.w_sink is not None else None
                 # rows of >= 64 frames fill the weight-gradient kernel's 64-position stages on their own: the
@@ -501,13 +509,16 @@ class _ConvFn(torch.autograd.Function):
                 dw = _sunk(ctx.w_sink, dw)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = _sunk(ctx.b_sink, bias_grad(dy, slope=slope, out=ctx.b_sink[0] if ctx.b_sink is not None else None))
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             b0 = ctx.b0 if 0 < ctx.b0 < x.shape[0] else 0
             dys, ys, xs = (dy[b0:], (y[b0:] if y is not None else None), x[b0:]) if b0 else (dy, y, x)
             kw = dict(in_tf=dtf, xaux=ys, slope=slope)
             if in_leaky:
                 kw.update(out_tf=TF_DLEAKY, oaux=xs)
+            if link_dres is not None and not transposed:
+                kw["res"] = link_dres[b0:] if b0 else link_dres
+                link_dres = None
             dx = torch.empty_like(x)
             dxs = dx[b0:] if b0 else dx
             if transposed and xs.dim() == 3 and xs.shape[2] <= 64 and xs.shape[0] > 1 and kw.get("xaux") is None:
@@ -535,9 +546,14 @@ class _ConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _sunk(ctx.b_sink, bias_grad(dy, aux=y, tf=dtf, slope=slope,
                                              out=ctx.b_sink[0] if ctx.b_sink is not None else None))
+        if link_dres is not None:  # not consumed by a fused launch above (no data gradient wanted / transposed)
+            dx = link_dres if dx is None else dx.add_(link_dres)
         if ctx.has_res and ctx.needs_input_grad[3]:
-            dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+            if ctx.link is not None and ctx.link[1] == "src":
+                ctx.link[0].dres = dy  # handed to the linked conv's data gradient (runs later in this backward)
+            else:
+                dres = dy
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 class _LinearT1Fn(torch.autograd.Function):
@@ -574,17 +590,27 @@ class _LinearT1Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+class ResGradLink:
+    """Shared by two conv1d calls of one residual pair y = c2(f(c1(x))) + x: pass link=(obj, "dst") to c1 (whose
+    input is x) and link=(obj, "src") to c2 (whose `res` is the same x).  In backward c2 hands its residual gradient
+    to c1, which adds it in its data-gradient kernel's epilogue; autograd then sees one gradient for x."""
+    __slots__ = ("dres",)
+
+    def __init__(self):
+        self.dres = None
+
+
 def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, in_leaky=False, out_act=ACT_NONE,
-           slope=0.1, res=None):
+           slope=0.1, res=None, link=None):
     """Conv1d on [B,C,T] or the (k,1) Conv2d of the period discriminators on [B,C,H,P]."""
     if (x.dim() == 3 and x.shape[2] == 1 and w.dim() == 3 and w.shape[2] == 1 and groups == 1 and stride == 1 and pad == 0
             and not in_leaky and out_act == ACT_NONE and res is None and x.shape[0] <= 32 and w.shape[0] >= 32):
         return _LinearT1Fn.apply(x, w, bias)
-    return _ConvFn.apply(x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, False)
+    return _ConvFn.apply(x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, False, link)
 
 
 def conv_transpose1d(x, w, bias=None, stride=1, pad=0, in_leaky=False, out_act=ACT_NONE, slope=0.1):
-    return _ConvFn.apply(x, w, bias, None, stride, pad, 1, 1, in_leaky, out_act, slope, True)
+    return _ConvFn.apply(x, w, bias, None, stride, pad, 1, 1, in_leaky, out_act, slope, True, None)
 
 
 # ---------------------------------------------------------------------------------------------
