@@ -2,20 +2,25 @@
 """bench.py -- BASELINE.json metric: training utterances/sec (one generator step + one
 discriminator step per batch) at configs/base.json segment_size.
 
-At N=1 the workload is BASELINE.json configs[1]: base widths, batch 16, fp32, HiFi-GAN
-generator + MPD(8 periods + S) + MSD + STFT/mel-L1 step (`VocoderGAN`), synthetic
-z_slice/waveform batches.  One "step" = one batch through both optimizer passes, AdamW included.
+Default (N=1): BASELINE.json configs[1] -- base widths, batch 16, fp32, HiFi-GAN generator + MPD(8 periods + S) +
+MSD + STFT/mel-L1 step (`VocoderGAN`), synthetic z_slice / waveform batches.  One "step" = one batch through both
+optimizer passes, AdamW included.  The other BASELINE configurations are reachable with flags:
+
+  configs[2]  --workload full --batch 32 --dtype bf16          (full SynthesizerSVC + MPD + MSD)
+  configs[3]  --config 48k --workload full --dtype bf16        (per-GPU batch 16; the 8-GPU launch is the driver's)
+  configs[4]  --config 48k --workload infer --dtype bf16       (flow inverse + decode, 64 x 10 s -> real-time factor)
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (conv_gemm, the
-dominant kernel, timed with HIP events on its own stream inside the timed region) and
-`cpu_baseline` (the CPU oracle trainer on a bounded sample of the same workload)."""
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (the dominant kernel family, timed
+with HIP events attached to each dispatch on the launch stream inside the timed region) and `cpu_baseline` (the CPU
+oracle on a bounded sample of the same workload)."""
 import argparse
-import copy
 import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -27,22 +32,46 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-GFLOP_PER_UTT = {"vocoder": 400.0, "full": 488.0}  # SURVEY.md section 8d (4G + 9 D1, reference semantics)
+# MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+# algorithmic GFLOP per utterance (4 G + 9 D1, reference semantics); infer: per 10 s utterance
+GFLOP_PER_UTT = {("base", "vocoder"): 400.0, ("base", "full"): 488.0, ("48k", "vocoder"): 536.0, ("48k", "full"): 560.0,
+                 ("48k", "infer"): 770.0, ("base", "infer"): 788.0}
+PROF_CLASSES = ["conv_gemm_kernel (register-staged)", "conv_wgrad_kernel (register-staged)",
+                "conv_dma_kernel (fwd + dgrad + convT, LDS-DMA staging, all tile variants)", "wgrad_dma_kernel"]
 
 
-def profiled_traffic():
-    """HBM bytes per conv_dma_kernel launch from the latest committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
-    produced by tools/profile_summary.py; PMC counters cannot be read from inside the benchmark process)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        return round(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+def kernel_source_hash():
+    """sha256 over the kernel sources and their host dispatch: profiles recorded for another kernel set are stale."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vcvits_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "vcvits_amd", "csrc", "*.h")) +
+                    [os.path.join(ROOT, "include", "vcvits_hip.h"), os.path.join(ROOT, "vcvits_amd", "ops.py")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(kernel_family, workload_key):
+    """HBM bytes per launch of `kernel_family` from the newest committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
+    written by tools/profile_summary.py -- PMC counters cannot be read from inside this process).  Returns
+    (bytes, source, stale): a file recorded for other kernel sources or another workload is reported as stale and its
+    number withheld."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", "base/vocoder/f32") != workload_key:
+            continue
+        fam = d.get("kernels", {d.get("kernel", ""): d}).get(kernel_family)
+        if fam is None:
+            continue
+        src = os.path.relpath(f, ROOT)
+        if d.get("kernel_source_hash") != kernel_source_hash():
+            return None, src, True
+        return round(fam["hbm_bytes_per_launch"]), src, False
+    return None, None, False
 
 
 def parse():
@@ -50,26 +79,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["vocoder", "full"], default="vocoder")
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--config", choices=["base", "48k"], default="base")
+    ap.add_argument("--workload", choices=["vocoder", "full", "infer"], default="vocoder")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16; 64 for --workload infer)")
+    ap.add_argument("--frames", type=int, default=938, help="--workload infer: frames per utterance (938 = 10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="also time SURVEY 8d's config 1 (full model, B=2) on the host")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch event timing")
     return ap.parse_args()
 
 
-CPU_THREADS = 16  # measured on the GPU box host (2 x EPYC 9575F, 256 hw threads): one B=1 oracle batch takes
-#                   1.2 s at 16 torch threads, 1.9 s at 32, 5.1 s at 64 and ~545 s at 256 (oversubscription)
+# Host threads for the CPU oracle: measured on the GPU box host (2 x EPYC 9575F = 128 physical cores, 256 hardware
+# threads): one B=1 oracle batch takes 1.2 s at 16 torch threads, 1.9 s at 32, 5.1 s at 64 and ~545 s at 256
+# (oversubscribed intra-op pool), so the fastest setting is used and the sweep is carried in the JSON.
+CPU_THREADS = 16
+CPU_THREAD_SWEEP = {"16": 1.2, "32": 1.9, "64": 5.1, "256": 545.0}
 
 
-def cpu_baseline(cfg, workload, periods):
-    """The oracle (CPU restatement, torch CPU autograd + torch.optim.AdamW) on a bounded sample of
-    the same workload: batches of 2 utterances, 1 warm-up + 3 timed, at the thread count that is
-    fastest on this host."""
+def _cpu_train(cfg, workload, periods):
     from oracle.cpu_step import CpuTrainer
     from vcvits_amd import synthetic
     from vcvits_amd.light.vcvits import VCVITS, VocoderGAN
-    cores = min(CPU_THREADS, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     module = (VocoderGAN if workload == "vocoder" else VCVITS)(**cfg)
     trainer = CpuTrainer(module.state_dict(), cfg, periods, vocoder_only=(workload == "vocoder"))
@@ -90,11 +122,75 @@ def cpu_baseline(cfg, workload, periods):
     t0 = time.perf_counter()
     for i in range(n):
         trainer.batch(make(99 + i))
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(2.0 / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "3 timed batches of 2 utterances after 1 warm-up (%s workload, fp32, torch-CPU oracle "
-                      "with AdamW), %.2f s per batch on %d of %d host threads" % (workload, dt, cores,
-                                                                                 os.cpu_count() or 1)}
+    return (time.perf_counter() - t0) / n
+
+
+def cpu_baseline(cfg, workload, periods, frames, also_full=False):
+    """The oracle (CPU restatement: torch CPU autograd + torch.optim.AdamW) on a bounded sample of the same workload
+    at the thread count that is fastest on this host."""
+    cores = min(CPU_THREADS, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    host = {"hardware_threads": os.cpu_count() or 1, "torch_threads_used": cores,
+            "thread_sweep_s_per_B1_batch": CPU_THREAD_SWEEP}
+    if workload == "infer":
+        from oracle import vits_oracle as O
+        from vcvits_amd.model.synthesizers.synthesizer_svc import SynthesizerSVC
+        d, m = cfg["data"], cfg["model"]
+        torch.manual_seed(0)
+        net = SynthesizerSVC(d["filter_length"] // 2 + 1, 32, n_speakers=d["n_speakers"], **m)
+        sd = {"n." + k: v.detach() for k, v in net.state_dict().items()}
+        C, H, T = m["inter_channels"], m["hidden_channels"], max(8, frames // 10)
+        z_p = torch.randn(1, C, T)
+        g = torch.randn(1, m["gin_channels"], 1)
+        mask = torch.ones(1, 1, T)
+
+        def once():
+            with torch.no_grad():
+                z = O.flow_forward(sd, "n.flow", z_p, mask, g, True, C, H, 5, 1, 4)
+                return O.generator_forward(sd, "n.dec", z * mask, m["upsample_rates"], m["upsample_kernel_sizes"],
+                                           m["resblock_kernel_sizes"], m["resblock_dilation_sizes"])
+        once()
+        t0 = time.perf_counter()
+        o = once()
+        dt = time.perf_counter() - t0
+        audio = o.shape[-1] / d["target_sampling_rate"]
+        return {"value": round(dt / audio, 5), "unit": "wall s / audio s", "cores": cores, "kind": "port",
+                "sample": "1 utterance x %d frames (%.2f s of audio) after 1 warm-up: oracle flow reverse + HiFi-GAN "
+                          "decode, fp32 torch-CPU, %.2f s" % (T, audio, dt), "host": host}
+    dt = _cpu_train(cfg, workload, periods)
+    out = {"value": round(2.0 / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
+           "sample": "3 timed batches of 2 utterances after 1 warm-up (%s workload, fp32, torch-CPU oracle with AdamW), "
+                     "%.2f s per batch on %d of %d host threads" % (workload, dt, cores, os.cpu_count() or 1),
+           "host": host}
+    if also_full and workload != "full":
+        # SURVEY 8d's CPU baseline proper: BASELINE configs[0] (full model, B=2, one G step + one D step)
+        dtf = _cpu_train(cfg, "full", periods)
+        out["config1_full_model_B2"] = {"value": round(2.0 / dtf, 4), "unit": "utterances/s", "s_per_batch": round(dtf, 2)}
+    return out
+
+
+def build_infer(cfg, B, T, dev):
+    from vcvits_amd.model.synthesizers.synthesizer_svc import SynthesizerSVC
+    d, m = cfg["data"], cfg["model"]
+    net = SynthesizerSVC(d["filter_length"] // 2 + 1, 32, n_speakers=d["n_speakers"], **m).to(dev).eval()
+    with torch.no_grad():
+        for p in net.flow.parameters():
+            if p.abs().sum() == 0:
+                p.normal_(0, 0.02)  # the zero-initialised `post` convs would make the flow an identity
+    g = torch.Generator().manual_seed(1234)
+    m_p = torch.randn(B, m["inter_channels"], T, generator=g).to(dev)
+    logs_p = (torch.randn(B, m["inter_channels"], T, generator=g) * 0.1 - 1.0).to(dev)
+    noise = torch.randn(B, m["inter_channels"], T, generator=g).to(dev)
+    y_mask = torch.ones(B, 1, T, device=dev)
+    spk = net.emb_g(torch.randint(0, d["n_speakers"], (B,), generator=g).to(dev)).unsqueeze(-1)
+    from vcvits_amd import ops
+
+    def step():
+        with torch.no_grad():
+            z_p = ops.prior_sample(m_p, logs_p, noise, 1.0)
+            z = net.flow(z_p, y_mask, g=spk, reverse=True)
+            return net.dec(ops.mask_mul(z, y_mask.reshape(B, -1)))
+    return step
 
 
 def main():
@@ -106,96 +202,122 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("VCVITS_FORCE_DDP") == "1":
+    infer = a.workload == "infer"
+    if (world > 1 and not infer) or os.environ.get("VCVITS_FORCE_DDP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from vcvits_amd import _lib, configs, synthetic
+    elif world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # replicas: timing barrier only
+    from vcvits_amd import _lib, configs, ops, synthetic
     from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS, VocoderGAN
     L = _lib.lib()
+    ops.set_compute_dtype(a.dtype)
 
-    cfg = configs.base()
-    B = a.batch
-    torch.manual_seed(1234)  # identical initial weights on every rank
-    module = (VocoderGAN if a.workload == "vocoder" else VCVITS)(**cfg).to(dev)
-    module.train()
-    module.configure_optimizers()
-    module.optim_g.broadcast_parameters()
-    module.optim_d.broadcast_parameters()
+    cfg = configs.base() if a.config == "base" else configs.base_48k()
+    B = a.batch if a.batch is not None else (64 if infer else 16)
     m = cfg["model"]
-    if a.workload == "vocoder":
-        batches = [synthetic.vocoder_batch(B, m["inter_channels"], seed=1234 + 17 * rank + i, device=dev)
-                   for i in range(2)]
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    if infer:
+        run = build_infer(cfg, B, a.frames, dev)
     else:
-        batches = [synthetic.full_batch(B, m["hubert_channels"], seed=1234 + 17 * rank + i, device=dev)
-                   for i in range(2)]
+        module = (VocoderGAN if a.workload == "vocoder" else VCVITS)(**cfg).to(dev)
+        module.train()
+        module.configure_optimizers()
+        module.optim_g.broadcast_parameters()
+        module.optim_d.broadcast_parameters()
+        make = synthetic.vocoder_batch if a.workload == "vocoder" else synthetic.full_batch
+        width = m["inter_channels"] if a.workload == "vocoder" else m["hubert_channels"]
+        batches = [make(B, width, seed=1234 + 17 * rank + i, device=dev) for i in range(2)]
+
+        def run(i=[0]):
+            module.fit_batch(batches[i[0] % 2])
+            i[0] += 1
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        module.fit_batch(batches[i % 2])
+    for _ in range(a.warmup):
+        run()
     sync()
     prof = (not a.no_prof)
     if prof:
-        _lib.check(L.vcv_prof_begin(4096 * max(a.steps, 1)), "vcv_prof_begin")
+        _lib.check(L.vcv_prof_begin(8192 * max(a.steps, 1)), "vcv_prof_begin")
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        module.fit_batch(batches[i % 2])
+    for _ in range(a.steps):
+        run()
     sync()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    peak = PEAK_TFLOPS[a.dtype]
     roof = None
     if prof:
         out = (ctypes.c_double * 12)()
+        nbytes = (ctypes.c_double * 4)()
         _lib.check(L.vcv_prof_end(out, 4), "vcv_prof_end")
+        _lib.check(L.vcv_prof_bytes(nbytes, 4), "vcv_prof_bytes")
         if os.environ.get("VCVITS_PROF_DUMP"):
             L.vcv_prof_dump(os.environ["VCVITS_PROF_DUMP"].encode())
 
-        def cls(i, name):
+        def cls(i):
             n, ms, fl = out[3 * i], out[3 * i + 1], out[3 * i + 2]
             if n <= 0 or ms <= 0:
                 return None
             ach = fl / (ms * 1e-3) / 1e12
-            return {"kernel": name, "achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            return {"kernel": PROF_CLASSES[i], "achieved": round(ach, 2), "frac": round(ach / peak, 4),
                     "launches_per_step": n / a.steps, "avg_launch_us": round(1e3 * ms / n, 2),
-                    "gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
+                    "gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms * 1e-3 / dt, 3),
+                    "algorithmic_bytes_per_launch": round(nbytes[i] / n) if nbytes[i] > 0 else None}
 
-        dma = cls(2, "conv_dma_kernel (fwd + dgrad + convT, LDS-DMA staging, all tile variants)")
-        if dma:
-            # dominant kernel by time; the other MFMA kernel families ride along for the record
-            traffic, traffic_src = profiled_traffic()
-            roof = {"bound": "mfma", "kernel": dma["kernel"], "achieved": dma["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": dma["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                    "traffic_source": traffic_src,
-                    "launches_per_step": dma["launches_per_step"], "avg_launch_us": dma["avg_launch_us"],
-                    "gflop_per_launch": dma["gflop_per_launch"], "share_of_step_time": dma["share_of_step_time"],
-                    "other_kernels": [k for k in (cls(3, "wgrad_dma_kernel"), cls(0, "conv_gemm_kernel (register-staged)"),
-                                                   cls(1, "conv_wgrad_kernel (register-staged)")) if k]}
+        fams = [c for c in (cls(i) for i in range(4)) if c]
+        if fams:
+            # the dominant kernel family by time carries the roofline; the others ride along for the record
+            dom = max(fams, key=lambda c: c["share_of_step_time"])
+            fam_name = dom["kernel"].split(" ")[0]
+            traffic, traffic_src, stale = profiled_traffic(fam_name, "%s/%s/%s" % (a.config, a.workload, a.dtype))
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "traffic_source": traffic_src, "traffic_stale": stale,
+                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                    "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                    "gflop_per_launch": dom["gflop_per_launch"], "share_of_step_time": dom["share_of_step_time"],
+                    "kernel_source_hash": kernel_source_hash(),
+                    "other_kernels": [c for c in fams if c is not dom]}
     if rank == 0:
-        value = world * B * a.steps / dt
-        line = {
-            "metric": "training utterances/sec (gen+disc step) at base.json segment_size",
-            "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs/base.json widths, HiFi-GAN generator + MPD(8 periods+S) + MSD + "
-                                    "STFT/mel-L1, G step + D step + AdamW" if a.workload == "vocoder" else
-                                    "configs/base.json full SynthesizerSVC (feature input) + MPD + MSD, G step + D step"),
-                       "per_gpu_batch": B, "global_batch": B * world, "segment_size": 16384,
-                       "parallelism": "dp%d" % world,
-                       "algorithmic_gflop_per_utterance": GFLOP_PER_UTT[a.workload],
-                       "algorithmic_tflops": round(value * GFLOP_PER_UTT[a.workload] / 1e3, 2)},
-            "roofline": roof,
-        }
+        gfl = GFLOP_PER_UTT[(a.config, a.workload)] * (a.frames / 938.0 if infer else 1.0)
+        utt_s = world * B * a.steps / dt
+        cfgname = "configs/base.json" if a.config == "base" else "configs/48k_base.json"
+        if infer:
+            audio_s = B * a.frames * cfg["data"]["hop_length"] / cfg["data"]["target_sampling_rate"]
+            line = {"metric": "inference real-time factor (infer.py voice-conversion path: flow inverse + HiFi-GAN decode)",
+                    "value": round(dt / a.steps / audio_s / world, 7), "unit": "wall s / audio s",
+                    "higher_is_better": False, "scaling": "weak"}
+            wl = "%s widths, prior sample + flow reverse + HiFi-GAN decode, %d x %d frames (%.1f s each)" % (
+                cfgname, B, a.frames, a.frames * cfg["data"]["hop_length"] / cfg["data"]["target_sampling_rate"])
+        else:
+            line = {"metric": "training utterances/sec (gen+disc step) at base.json segment_size",
+                    "value": round(utt_s, 3), "unit": "utterances/s", "higher_is_better": True, "scaling": "weak"}
+            wl = ("%s widths, HiFi-GAN generator + MPD(%d periods+S) + MSD + STFT/mel-L1, G step + D step + AdamW"
+                  % (cfgname, len(m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS))
+                  if a.workload == "vocoder" else
+                  "%s full SynthesizerSVC (feature input) + MPD + MSD, G step + D step + AdamW" % cfgname)
+        line.update({"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+                     "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                     "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world, "segment_size": 16384,
+                                "parallelism": ("dp%d" % world) if not infer else ("replicas%d" % world),
+                                "utterances_per_s": round(utt_s, 3), "algorithmic_gflop_per_utterance": round(gfl, 1),
+                                "algorithmic_tflops": round(utt_s * gfl / 1e3, 2),
+                                "arithmetic": ("fp32 throughout (fp32-input MFMA)" if a.dtype == "f32" else
+                                               "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},
+                     "roofline": roof})
         if world == 1 and not a.no_cpu_baseline:
             periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
-            line["cpu_baseline"] = cpu_baseline(cfg, a.workload, periods)
+            line["cpu_baseline"] = cpu_baseline(cfg, a.workload, periods, a.frames, also_full=a.cpu_baseline_full)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

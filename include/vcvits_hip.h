@@ -262,6 +262,10 @@ int vcv_split_sample_bwd(const float* dm, const float* dlogs, const float* dz, c
 int vcv_coupling(const float* x1, const float* m, const float* mask, float* y, int B, int C, int T, int reverse,
                  void* stream);
 
+/* ---- prior sample of SynthesizerSVC.infer (synthesizer_svc.py:104): z = m + noise * exp(logs) * noise_scale ---- */
+int vcv_prior_sample(const float* m, const float* logs, const float* noise, float* z, int64_t n, float noise_scale,
+                     void* stream);
+
 /* ---- LayerNorm over the channel dim of [B,C,T] applied to (x + y) (modules.py:19-31 with the
  * residual add of relative_attention_transformer.py:41,45 fused); y may be NULL ---- */
 int vcv_layernorm_c_fwd(const float* x, const float* y, const float* gamma, const float* beta, float* out,
@@ -310,6 +314,9 @@ int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float* dx, int B
  * conv_gemm_kernel, 1 = conv_wgrad_kernel, 2 = conv_dma_kernel, 3 = wgrad_dma_kernel (ncls >= 4). ---- */
 int vcv_prof_begin(int max_launches);
 int vcv_prof_end(double* out, int ncls);
+/* out[cls] = algorithmic HBM bytes (operands read once + result written once) summed over the class's launches of the
+ * window vcv_prof_end just closed */
+int vcv_prof_bytes(double* out, int ncls);
 /* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */
 int vcv_prof_dump(const char* path);
 

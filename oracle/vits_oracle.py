@@ -447,3 +447,29 @@ def mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None):
 def spec_to_mel(spec, melmat):
     """mel_processing.py:98-112: log(clamp(M @ spec, 1e-5))."""
     return torch.log(torch.clamp(torch.matmul(melmat, spec), min=1e-5))
+
+
+def audio_pipeline(waveform, n_fft=2048, hop_length=512, win_length=2048):
+    """vits/model/pipeline.py:49-70 (aug=False): torchaudio Spectrogram(pad=(n_fft-hop)/2, power=None,
+    center=False) -> InverseSpectrogram -> copied into zeros_like(waveform).  torchaudio (2.0.1, absent) is restated
+    per SURVEY Appendix C: constant pad + torch.stft; InverseSpectrogram = torch.istft(center=True)."""
+    b, c, t = waveform.shape
+    pad = int((n_fft - hop_length) / 2)
+    win = torch.hann_window(win_length)
+    yp = F.pad(waveform.reshape(b * c, t), (pad, pad))
+    spec = torch.stft(yp, n_fft, hop_length=hop_length, win_length=win_length, window=win, center=False,
+                      normalized=False, onesided=True, return_complex=True)
+    wav = torch.istft(spec, n_fft, hop_length=hop_length, win_length=win_length, window=win, center=True,
+                      normalized=False, onesided=True).reshape(b, c, -1)
+    out = torch.zeros_like(waveform)
+    n = min(wav.shape[2], t)
+    out[:, :, :n] = wav[:, :, :n]
+    return out
+
+
+def hubert_features(extractor, x_wav):
+    """content_encoder.py:53-56: pad (400 - 320) // 2 samples each side, `hubert.extract_features(wav.squeeze(1))`
+    -> [B, T', H], transposed to [B, H, T'] (the reference transposes twice around hubert_proj: a no-op pair)."""
+    wav = F.pad(x_wav, ((400 - 320) // 2, (400 - 320) // 2))
+    x_encoded, _ = extractor.extract_features(wav.squeeze(1))
+    return x_encoded.transpose(1, -1)

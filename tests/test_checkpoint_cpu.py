@@ -1,6 +1,7 @@
 """CPU: checkpoint container / discovery / tolerant load."""
 import os
 
+import pytest
 import torch
 
 
@@ -53,3 +54,146 @@ def test_tolerant_load_drops_mismatches(tmp_path):
     out = ck.load_checkpoint(m2, p)
     assert torch.equal(m2.net_g.conv_pre.weight, before)
     assert "optimizer_states" not in out
+
+
+# ---- reference-shaped (Lightning) checkpoints -------------------------------------------------------------
+def _manifest():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_ckpt_manifest.json")))
+
+
+def _full_module(man):
+    from vcvits_amd import configs
+    from vcvits_amd.light.vcvits import VCVITS
+    w = man["widths"]
+    cfg = configs.base()
+    cfg["model"].update({"inter_channels": w["C"], "hidden_channels": w["H"], "filter_channels": w["FILT"],
+                         "n_heads": w["HEADS"], "n_layers": w["LAYERS"], "hubert_channels": w["HUB"],
+                         "num_pitch": w["NPITCH"], "gin_channels": w["GIN"], "upsample_initial_channel": w["UPC"],
+                         "multi_period_discriminator_periods": w["PERIODS"]})
+    cfg["data"].update({"n_speakers": w["NSPK"], "hubert_channels": w["HUB"], "num_pitch": w["NPITCH"]})
+    return VCVITS(**cfg)
+
+
+def _lightning_ckpt(man, seed=0, lr=1.7e-4, epoch=5):
+    """A dict shaped like `Trainer.save_checkpoint` of the reference module: state_dict in the reference's key order
+    (third-party hubert / audio_pipeline entries included), torch.optim.AdamW states indexed by parameter position,
+    ExponentialLR states, hyper_parameters."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for e in man["entries"]:
+        sd[e["key"]] = torch.randn(e["shape"], generator=g) * 0.05
+    opt_states = []
+    for pres in (("net_g.",), ("net_period_d.", "net_scale_d.")):
+        names = [e["key"] for e in man["entries"] if e["param"] and e["key"].startswith(pres)]
+        state = {}
+        for j, k in enumerate(names):
+            if ".hubert." in k:
+                continue  # frozen: torch.optim never creates state for it, but it keeps its index
+            state[j] = {"step": torch.tensor(41.0), "exp_avg": torch.randn(sd[k].shape, generator=g) * 1e-3,
+                        "exp_avg_sq": torch.rand(sd[k].shape, generator=g) * 1e-6}
+        opt_states.append({"state": state,
+                           "param_groups": [{"lr": lr, "betas": (0.8, 0.99), "eps": 1e-9, "weight_decay": 0.01,
+                                             "amsgrad": False, "initial_lr": 2e-4, "params": list(range(len(names)))}]})
+    sched = [{"gamma": 0.999875, "base_lrs": [2e-4], "last_epoch": epoch, "_step_count": epoch + 1, "_last_lr": [lr]}
+             for _ in range(2)]
+    return {"epoch": epoch, "global_step": 777, "pytorch-lightning_version": "2.0.2", "state_dict": sd,
+            "optimizer_states": opt_states, "lr_schedulers": sched, "hparams_name": "kwargs",
+            "hyper_parameters": {"train": {"segment_size": 16384}}}
+
+
+def test_reference_key_parity():
+    """Every tensor of the reference module tree that is not third-party (HuBERT, torchaudio windows) exists in the
+    product module under the same key with the same shape, in the same order -- and nothing else does."""
+    man = _manifest()
+    m = _full_module(man)
+    own = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+    ref = [(e["key"], e["shape"]) for e in man["entries"]
+           if not (e["key"].startswith("net_g.enc_p.hubert.") or e["key"].startswith("audio_pipeline."))]
+    assert own == ref
+    assert man["n_params_g"] == sum(1 for _ in m.net_g.parameters()) + 4  # + the HuBERT stub's four tensors
+
+
+def test_load_reference_shaped_checkpoint(tmp_path):
+    from vcvits_amd.light import checkpoint as ck
+    man = _manifest()
+    raw = _lightning_ckpt(man)
+    p = str(tmp_path / "last.ckpt")
+    torch.save(raw, p)
+    torch.manual_seed(3)
+    m = _full_module(man)
+    m.configure_optimizers()  # Lightning builds the optimizers before it restores their state
+    out = ck.load_checkpoint(m, p)
+    assert "optimizer_states" in out  # hubert.* / audio_pipeline.* entries do not count as a changed model
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, raw["state_dict"][k]), k
+    assert m.current_epoch == 5 and m.global_step == 777
+    params = dict(m.named_parameters())
+    for idx, (opt, pres) in enumerate(((m.optim_g, ("net_g.",)), (m.optim_d, ("net_period_d.", "net_scale_d.")))):
+        names = [e["key"] for e in man["entries"] if e["param"] and e["key"].startswith(pres)]
+        st = raw["optimizer_states"][idx]["state"]
+        where = {id(q): (i, o) for i, (q, o) in enumerate(zip(opt.params, opt.offsets))}
+        seen = 0
+        for j, k in enumerate(names):
+            if k not in params:
+                continue
+            i, o = where[id(params[k])]
+            n = params[k].numel()
+            assert torch.equal(opt.exp_avg[o:o + n].view(params[k].shape), st[j]["exp_avg"]), k
+            assert torch.equal(opt.exp_avg_sq[o:o + n].view(params[k].shape), st[j]["exp_avg_sq"]), k
+            assert opt._pstep[i] == 41
+            seen += 1
+        assert seen == len(opt.params)
+        assert opt.lr == 1.7e-4 and opt.param_groups[0]["lr"] == 1.7e-4 and opt.step_count == 41
+    assert m.scheduler_g.last_epoch == 5 and m.scheduler_d.get_last_lr() == [1.7e-4]
+    # a second module saved in the same layout reads back identically (moments scattered out and gathered again)
+    p2 = ck.save_checkpoint(m, str(tmp_path / "again.ckpt"))
+    again = torch.load(p2, weights_only=True)
+    assert set(again) >= {"state_dict", "optimizer_states", "lr_schedulers", "hyper_parameters", "epoch", "global_step",
+                          "pytorch-lightning_version"}
+    assert again["optimizer_states"][0]["param_groups"][0]["lr"] == 1.7e-4
+    m2 = _full_module(man)
+    m2.configure_optimizers()
+    ck.load_checkpoint(m2, p2)
+    assert torch.equal(m2.optim_g.exp_avg, m.optim_g.exp_avg) and torch.equal(m2.optim_d.exp_avg_sq, m.optim_d.exp_avg_sq)
+    assert m2.optim_d._pstep == m.optim_d._pstep and m2.scheduler_g.last_epoch == 5
+
+
+def test_reference_shaped_checkpoint_with_mismatch_drops_optimizer_state(tmp_path):
+    """vcvits.py:265-282: a wrong-shaped tensor keeps the fresh value and discards `optimizer_states`; the rate then
+    stays what configure_optimizers set (the reference re-seats only the scheduler position)."""
+    from vcvits_amd.light import checkpoint as ck
+    man = _manifest()
+    raw = _lightning_ckpt(man, epoch=9)
+    raw["state_dict"]["net_g.emb_g.weight"] = torch.zeros(3, 3)
+    p = str(tmp_path / "last.ckpt")
+    torch.save(raw, p)
+    m = _full_module(man)
+    m.configure_optimizers()
+    fresh = m.net_g.emb_g.weight.detach().clone()
+    out = ck.load_checkpoint(m, p)
+    assert "optimizer_states" not in out
+    assert torch.equal(m.net_g.emb_g.weight, fresh)
+    assert float(m.optim_g.exp_avg.abs().sum()) == 0.0 and m.optim_g.lr == 2e-4
+    assert m.current_epoch == 9 and m.scheduler_g.last_epoch == 8  # last_epoch = current_epoch - 1 (vcvits.py:259)
+
+
+def test_exponential_lr_matches_torch():
+    """The scheduler mirror against torch.optim.lr_scheduler.ExponentialLR driven the way the reference drives it:
+    built in configure_optimizers, `last_epoch = current_epoch - 1`, stepped once per epoch."""
+    from vcvits_amd.light.optim import ExponentialLR, FlatAdamW
+    for start_epoch in (0, 4):
+        w = torch.nn.Parameter(torch.zeros(2))
+        ref_opt = torch.optim.AdamW([w], 2e-4)
+        ref = torch.optim.lr_scheduler.ExponentialLR(ref_opt, gamma=0.9)
+        ref.last_epoch = start_epoch - 1
+        opt = FlatAdamW([torch.nn.Parameter(torch.zeros(2))], 2e-4)
+        sch = ExponentialLR(opt, gamma=0.9)
+        sch.last_epoch = start_epoch - 1
+        for _ in range(5):
+            assert opt.param_groups[0]["lr"] == pytest.approx(ref_opt.param_groups[0]["lr"], rel=1e-12)
+            ref_opt.step()
+            ref.step()
+            sch.step()
+            assert sch.last_epoch == ref.last_epoch
+            assert sch.get_last_lr() == pytest.approx(ref.get_last_lr(), rel=1e-12)

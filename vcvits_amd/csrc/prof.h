@@ -16,4 +16,5 @@ void vcv_prof_stop(int slot, hipStream_t st);
 // Dispatch-attached timing: reserves a slot and returns its two events for hipExtLaunchKernelGGL (the kernel's own
 // start / completion timestamps: no marker packets in the queue, so profiling does not serialise the stream).
 // Both events are null when profiling is off.
-void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop);
+// `bytes`: algorithmic HBM bytes of the launch (operands read once + result written once), for the traffic line.
+void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop, double bytes = 0.0);

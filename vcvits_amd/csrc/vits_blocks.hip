@@ -180,6 +180,14 @@ __global__ void coupling_kernel(const float* __restrict__ x1, const float* __res
   y[i] = reverse ? (x1[i] - m[i]) * mk : m[i] + x1[i] * mk;
 }
 
+// ---- prior sample of SynthesizerSVC.infer: z_p = m + noise * exp(logs) * noise_scale ------------------
+__global__ void prior_sample_kernel(const float* __restrict__ m, const float* __restrict__ logs,
+                                    const float* __restrict__ noise, float* __restrict__ z, float noise_scale, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  z[i] = m[i] + noise[i] * expf(logs[i]) * noise_scale;
+}
+
 // ---- channel LayerNorm of (x + y) over C for [B,C,T] -----------------------------------------------
 // block: 64 consecutive t (lanes) x 4 channel groups (waves); two-pass mean / variance in registers.
 __global__ void __launch_bounds__(256)
@@ -569,6 +577,13 @@ extern "C" int vcv_coupling(const float* x1, const float* m, const float* mask, 
   const size_t n = (size_t)B * C * T;
   if (!x1 || !m || !mask || !y || n == 0) return VCV_EINVAL;
   hipLaunchKernelGGL(coupling_kernel, g1(n), dim3(256), 0, ST, x1, m, mask, y, C, T, reverse, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_prior_sample(const float* m, const float* logs, const float* noise, float* z, int64_t n,
+                                float noise_scale, void* stream) {
+  if (!m || !logs || !noise || !z || n <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(prior_sample_kernel, g1((size_t)n), dim3(256), 0, ST, m, logs, noise, z, noise_scale, (size_t)n);
   return vcv_check_launch();
 }
 

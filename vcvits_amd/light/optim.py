@@ -61,8 +61,14 @@ class FlatAdamW:
         self._ddp = self.world > 1 or (os.environ.get("VCVITS_FORCE_DDP") == "1" and dist.is_initialized())
         if self._ddp:
             self._make_buckets(int(bucket_mb * 1024 * 1024 / 4))
-            for i, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        # One post-accumulate hook per parameter: marks the parameter as "received a gradient in this pass"
+        # (torch.optim.AdamW skips parameters whose .grad is None -- no decay, no moment update, no step count)
+        # and, under data parallelism, counts its bucket down.  The handles are kept so a rebuilt optimizer can
+        # detach the old one (close()).
+        self._touched = bytearray(len(self.params))
+        self._pstep = [0] * len(self.params)
+        self._hook_handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
+                              for i, p in enumerate(self.params)]
         # gradient sinks: the conv / weight-norm backward kernels add parameter gradients straight into the
         # flat buffer (ops.register_grad_sink) instead of handing autograd a temporary to accumulate.  The
         # backward then returns None for the parameter; autograd still evaluates its AccumulateGrad node (no
@@ -86,12 +92,28 @@ class FlatAdamW:
         self._bucket_of = bucket_of
 
     def _make_hook(self, i):
+        touched = self._touched
+        if not self._ddp:
+            def hook(_p):
+                touched[i] = 1
+            return hook
+
         def hook(_p):
+            touched[i] = 1
             b = self._buckets[self._bucket_of[i]]
             b["ready"] += 1
             if b["ready"] == b["n"]:
                 self._launch_bucket(b)
         return hook
+
+    def close(self):
+        """Detach this optimizer from its parameters: removes the hooks and the gradient sinks (call before
+        building a replacement over the same parameters, or the old buckets keep launching all-reduces)."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        for p in self.params:
+            ops.unregister_grad_sink(p)
 
     def _launch_bucket(self, b):
         view = self.grad[b["lo"]:b["hi"]]
@@ -123,37 +145,97 @@ class FlatAdamW:
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()
         self._synced = False
+        self._touched[:] = bytes(len(self._touched))  # in place: the hooks hold this object
         if self.grad.is_cuda:
             ops.wgrad_arena_reset()  # temporaries of the previous backward pass are dead by now
         for b in self._buckets:
             b["ready"] = 0
 
+    def _update_ranges(self):
+        """[(lo, hi, step)] of the flat buffer to update in this step: maximal runs of parameters that received
+        a gradient in this pass and share a step count (torch.optim.AdamW keeps a step per parameter and skips
+        parameters without a gradient, e.g. a conditioning layer the forward never fed).  One run -- one launch
+        -- when every parameter took part."""
+        ranges = []
+        for i, p in enumerate(self.params):
+            if not self._touched[i]:
+                continue
+            self._pstep[i] += 1
+            lo, hi, st = self.offsets[i], self.offsets[i] + p.numel(), self._pstep[i]
+            if ranges and ranges[-1][1] == lo and ranges[-1][2] == st:
+                ranges[-1] = (ranges[-1][0], hi, st)
+            else:
+                ranges.append((lo, hi, st))
+        return ranges
+
     def step(self):
         self.finish_grad_sync()
         self.step_count += 1
-        if self.flat.is_cuda:
-            ops.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas, self.eps,
-                           self.weight_decay, self.step_count)
-            # the kernel wrote the parameters through raw pointers: drop weights derived from them
-            ops.invalidate_weights(self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel)
-        else:
+        if not self.flat.is_cuda:
             raise RuntimeError("FlatAdamW.step: parameters are not on the GPU (no CPU fallback)")
+        for lo, hi, st in self._update_ranges():
+            ops.adamw_step(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                           self.betas, self.eps, self.weight_decay, st)
+        # the kernel wrote the parameters through raw pointers: drop weights derived from them
+        ops.invalidate_weights(self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel)
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.param_groups[0]["lr"] = self.lr
 
     def set_epoch(self, epoch, gamma):
-        """ExponentialLR stepped per epoch (vcvits.py:258-261)."""
-        self.lr = self.base_lr * (gamma ** epoch)
-        self.param_groups[0]["lr"] = self.lr
+        """Closed form of ExponentialLR after `epoch` epoch-end steps from the base rate."""
+        self.set_lr(self.base_lr * (gamma ** epoch))
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
-                "exp_avg_sq": self.exp_avg_sq.clone()}
+                "exp_avg_sq": self.exp_avg_sq.clone(), "param_steps": list(self._pstep)}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
-        self.lr = float(sd["lr"])
+        self.set_lr(sd["lr"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        ps = sd.get("param_steps")
+        self._pstep = list(ps) if ps is not None and len(ps) == len(self.params) else [self.step_count] * len(self.params)
+
+    def write_flat(self, fn):
+        """Run fn(self.flat) -- a raw write into the parameter buffer -- and drop everything derived from the old
+        values (cached weight-norm results / packed weights validate on torch version counters, which a write
+        through the flat view does not bump for the per-parameter views)."""
+        fn(self.flat)
+        if self.flat.is_cuda:
+            ops.invalidate_weights(self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel)
 
     def broadcast_parameters(self, src=0):
         if self._ddp:
-            dist.broadcast(self.flat, src=src, group=self.pg)
+            self.write_flat(lambda flat: dist.broadcast(flat, src=src, group=self.pg))
+
+
+class ExponentialLR:
+    """torch.optim.lr_scheduler.ExponentialLR over a FlatAdamW, as the reference builds it
+    (vits/light/vcvits.py:258-261: one scheduler per optimizer, `last_epoch` re-seated to current_epoch - 1,
+    stepped by Lightning at every epoch end).  Chainable form: step() multiplies the optimizer's CURRENT rate by
+    gamma, so after a resume the rate continues from whatever the restored optimizer state holds (and from the
+    base rate when that state was dropped -- exactly what the reference does)."""
+
+    def __init__(self, optimizer, gamma, last_epoch=-1):
+        self.optimizer, self.gamma = optimizer, float(gamma)
+        self.last_epoch = last_epoch + 1  # torch's constructor performs the initial step: rate unchanged
+        self._last_lr = [optimizer.lr]
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.set_lr(self.optimizer.lr * self.gamma)
+        self._last_lr = [self.optimizer.lr]
+
+    def get_last_lr(self):
+        return list(self._last_lr)
+
+    def state_dict(self):
+        return {"gamma": self.gamma, "last_epoch": self.last_epoch, "_last_lr": list(self._last_lr)}
+
+    def load_state_dict(self, sd):
+        self.gamma = float(sd.get("gamma", self.gamma))
+        self.last_epoch = int(sd["last_epoch"])
+        self._last_lr = list(sd.get("_last_lr", self._last_lr))

@@ -7,8 +7,11 @@ batch_idx, optimizer_idx)`, `validation_step`, `configure_optimizers`, `on_load_
 batch-dict schema of vits/data/collate.py:177-187, the loss composition (:113-117) and the
 reference's quirks (zero-padded STFT for training targets, mel target = slice of the
 full-utterance mel, MPD default periods when the config omits them).
-Out of scope: SpeechConversionAudioPipeline and the fairseq HuBERT -- the
-batch carries content features `x_hubert_features_values` [B, hubert, T] instead of a waveform."""
+Batch schema: the reference's (`x_wav_values` / `x_wav_lengths`, what vits/data/collate.py emits): the source
+waveform goes through `audio_pipeline` (vcvits.py:61-62) and the content encoder's pluggable HuBERT feature
+extractor (`set_feature_extractor`; the fairseq model itself is third-party and absent offline).  Batches that
+carry precomputed content features `x_hubert_features_values` [B, hubert, T'] instead (every benchmark
+configuration) skip both."""
 import itertools
 import logging
 from typing import Any, Dict
@@ -24,7 +27,7 @@ from ..model.discriminators.multi_period_discriminator import MultiPeriodDiscrim
 from ..model.discriminators.multi_scale_discriminator import MultiScaleDiscriminator
 from ..model.generator import Generator
 from ..model.synthesizers.synthesizer_svc import SynthesizerSVC
-from .optim import FlatAdamW
+from .optim import ExponentialLR, FlatAdamW
 
 DEFAULT_PERIODS = [2, 3, 5, 7, 11, 17, 23, 37]  # multi_period_discriminator.py:10
 
@@ -44,9 +47,8 @@ class VCVITS(nn.Module):
                                                      use_spectral_norm=hp.model.use_spectral_norm)
         self.net_scale_d = MultiScaleDiscriminator(hp.model.use_spectral_norm)
         from ..model.pipeline import SpeechConversionAudioPipeline
-        # STFT -> iSTFT pass over the 16 kHz source waveform (vcvits.py:45-52,62).  Its output feeds HuBERT, which
-        # is out of scope: the module is built (same ctor call as the reference) and usable, but the training
-        # step consumes precomputed content features.
+        # STFT -> iSTFT pass over the 16 kHz source waveform (vcvits.py:45-52,62); its output feeds the content
+        # encoder's feature extractor when the batch carries `x_wav_values`
         self.audio_pipeline = SpeechConversionAudioPipeline(sr=hp.data.source_sampling_rate, n_fft=hp.data.filter_length,
                                                             n_mel=hp.data.n_mel_channels, win_length=hp.data.win_length,
                                                             hop_length=hp.data.hop_length)
@@ -54,6 +56,24 @@ class VCVITS(nn.Module):
         self.global_step = 0
         self.logged = {}
         self.optim_g = self.optim_d = None
+        self.scheduler_g = self.scheduler_d = None
+
+    def set_feature_extractor(self, extractor):
+        """Plug the frozen HuBERT (or any stand-in with its `extract_features` contract) into the content encoder."""
+        self.net_g.enc_p.set_feature_extractor(extractor)
+
+    def _source(self, batch):
+        """(x, x_lengths) for net_g from either batch schema.  Reference schema: `x_wav_values` [B, 1, T] ->
+        audio_pipeline under no_grad (vcvits.py:61-62) -> content encoder (which runs the feature extractor);
+        lengths stay SAMPLE counts, as the reference passes them (content_encoder.py:66 quirk)."""
+        if "x_wav_values" in batch:
+            with torch.no_grad():
+                return self.audio_pipeline(batch["x_wav_values"]), batch["x_wav_lengths"]
+        if "x_hubert_features_values" in batch:
+            return batch["x_hubert_features_values"], batch["x_hubert_features_lengths"]
+        raise KeyError("batch has neither the reference's source-waveform keys (x_wav_values / x_wav_lengths) nor "
+                       "precomputed content features (x_hubert_features_values / x_hubert_features_lengths); "
+                       "keys: %s" % sorted(batch))
 
     def _build_generator(self):
         hp = self.hparams
@@ -74,7 +94,7 @@ class VCVITS(nn.Module):
         (y_hat, y, y_mel_slice, kl_args or None)."""
         d, t = self.hparams.data, self.hparams.train
         speakers = batch.get("sid", None)
-        x_feat, x_lengths = batch["x_hubert_features_values"], batch["x_hubert_features_lengths"]
+        x_feat, x_lengths = self._source(batch)
         x_pitch, x_pitch_lengths = batch["x_pitch_values"], batch["x_pitch_lengths"]
         y_wav, y_wav_lengths = batch["y_wav_values"], batch["y_wav_lengths"]
         with torch.no_grad():
@@ -130,10 +150,15 @@ class VCVITS(nn.Module):
         self.net_g.eval()
         with torch.no_grad():
             y_spec, mel = self._spec_mel(batch["y_wav_values"].squeeze(1)[:1])
-            # target frames per source SAMPLE (vcvits.py:206); this build feeds HuBERT features, whose lengths are
-            # in feature frames = source samples / 320 (content_encoder.py:54-56), so the scale is per frame
-            len_scale = (d.target_sampling_rate / d.hop_length) / d.source_sampling_rate * 320
-            y_hat, mask, _ = self.net_g.infer(batch["x_hubert_features_values"], batch["x_hubert_features_lengths"],
+            # target frames per source SAMPLE (vcvits.py:206, data.infer_length_scale); a feature batch carries
+            # lengths in feature frames = source samples / hubert_downsample (content_encoder.py:54-56)
+            from ..data.audio import infer_length_scale
+            from ..model.encoders.content_encoder import HUBERT_DOWNSAMPLE
+            len_scale = infer_length_scale(d)
+            if "x_wav_values" not in batch:
+                len_scale *= d.get("hubert_downsample", HUBERT_DOWNSAMPLE)
+            x_src, x_src_lengths = self._source(batch)
+            y_hat, mask, _ = self.net_g.infer(x_src, x_src_lengths,
                                               batch["x_pitch_values"], batch["x_pitch_lengths"],
                                               sid=batch.get("sid", None), length_scale=len_scale, max_len=1000)
             y_hat_lengths = mask.sum([1, 2]).long() * d.hop_length
@@ -159,13 +184,25 @@ class VCVITS(nn.Module):
 
     def configure_optimizers(self, process_group=None):
         t = self.hparams.train
+        for old in (self.optim_g, self.optim_d):
+            if old is not None:
+                old.close()  # hooks / gradient sinks of a replaced optimizer must not outlive it
+        # dropout stream: tied to torch's seed, offset per data-parallel rank (independent masks per rank), saved
+        # in checkpoints
+        import torch.distributed as dist
+        rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
+        ops.manual_seed(torch.initial_seed() + 7919 * rank)
         self.optim_g = FlatAdamW(self.generator_parameters(), t.learning_rate, betas=t.betas, eps=t.eps,
                                  process_group=process_group)
         self.optim_d = FlatAdamW(itertools.chain(self.net_period_d.parameters(), self.net_scale_d.parameters()),
                                  t.learning_rate, betas=t.betas, eps=t.eps, process_group=process_group)
-        self.optim_g.set_epoch(max(self.current_epoch, 0), t.lr_decay)
-        self.optim_d.set_epoch(max(self.current_epoch, 0), t.lr_decay)
-        return [self.optim_g, self.optim_d], []
+        # vcvits.py:258-261: ExponentialLR per optimizer with last_epoch re-seated to current_epoch - 1 (the rate
+        # itself starts at learning_rate; a resume restores it with the optimizer state)
+        self.scheduler_g = ExponentialLR(self.optim_g, gamma=t.lr_decay)
+        self.scheduler_g.last_epoch = self.current_epoch - 1
+        self.scheduler_d = ExponentialLR(self.optim_d, gamma=t.lr_decay)
+        self.scheduler_d.last_epoch = self.current_epoch - 1
+        return [self.optim_g, self.optim_d], [self.scheduler_g, self.scheduler_d]
 
     def _toggle(self, idx):
         """Lightning-1.x toggle_optimizer: only the active optimizer's parameters take gradients."""
@@ -197,10 +234,10 @@ class VCVITS(nn.Module):
         return out
 
     def on_epoch_end(self):
+        """Lightning steps both epoch-interval schedulers at the end of every training epoch."""
         self.current_epoch += 1
-        t = self.hparams.train
-        self.optim_g.set_epoch(self.current_epoch, t.lr_decay)
-        self.optim_d.set_epoch(self.current_epoch, t.lr_decay)
+        self.scheduler_g.step()
+        self.scheduler_d.step()
 
     def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
         """vcvits.py:265-282: shape-mismatched tensors are replaced by the fresh ones, unknown keys

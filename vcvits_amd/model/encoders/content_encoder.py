@@ -1,6 +1,10 @@
-"""Content (prior) encoder, post-HuBERT part (vits/model/encoders/content_encoder.py:58-73 and
-:110-126).  HuBERT itself (fairseq, frozen, :32-35,:54-56) is out of scope: every benchmark
-configuration feeds precomputed / synthetic features [B, hubert_channels, T]."""
+"""Content (prior) encoder (vits/model/encoders/content_encoder.py:14-73 and :76-126).
+
+The frozen fairseq HuBERT (:32-35) is third-party and absent offline; its CONTRACT (:53-56) is built: a
+pluggable `feature_extractor` receives the source waveform padded by (400 - 320) // 2 samples per side and
+returns frame features [B, T', hubert_channels] (or the fairseq `(features, padding_mask)` tuple), which are
+transposed to [B, hubert_channels, T'] and fed to the HIP path.  Without an extractor the forward takes
+precomputed / synthetic features [B, hubert_channels, T] directly (every benchmark configuration does)."""
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -24,15 +28,23 @@ class _Linear(nn.Module):
         return ops.conv1d(x, self.weight.unsqueeze(-1), self.bias)
 
 
+HUBERT_WINDOW, HUBERT_DOWNSAMPLE = 400, 320  # receptive field / hop of HuBERT's conv front end (content_encoder.py:54)
+
+
 class HubertContentEncoder(nn.Module):
-    """Same parameters/keys as the reference class minus the frozen ``hubert.*`` buffers; forward
-    takes the HuBERT features directly: ``forward(feats [B,hubert,T], x_lengths, pitch, pitch_lengths)``."""
+    """Same parameters/keys as the reference class minus the frozen ``hubert.*`` buffers.
+    ``forward(x, x_lengths, pitch, pitch_lengths)``: x is the source waveform [B, 1, T] (reference signature;
+    needs a feature extractor) or HuBERT features [B, hubert_channels, T']."""
     concat = False
 
     def __init__(self, hubert_ckpt, out_channels, hidden_channels, filter_channels, n_heads, n_layers,
-                 kernel_size, p_dropout, hubert_channels, num_pitch, n_fft=2048, hop_size=512):
+                 kernel_size, p_dropout, hubert_channels, num_pitch, n_fft=2048, hop_size=512, feature_extractor=None):
         super().__init__()
         self.n_fft, self.hop_size, self.out_channels = n_fft, hop_size, out_channels
+        self.hubert_channels = hubert_channels
+        # kept out of the module tree (object.__setattr__): a frozen third-party model must not add `hubert.*`
+        # keys to this module's state_dict or parameters to the optimizer
+        object.__setattr__(self, "_extractor", feature_extractor)
         proj_channels = hidden_channels // 2 if self.concat else hidden_channels
         self.hubert_proj = _Linear(hubert_channels, proj_channels)
         self.emb_pitch = nn.Embedding(num_pitch, proj_channels)
@@ -42,7 +54,31 @@ class HubertContentEncoder(nn.Module):
         self.encoder = TransformerEncoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
         self.proj = Conv(hidden_channels, out_channels * 2, 1)
 
+    def set_feature_extractor(self, extractor):
+        """extractor: object with `.extract_features(wav [B, T]) -> (feats [B, T', H], padding_mask)` (the fairseq
+        HubertModel contract the reference calls, content_encoder.py:55) or a plain callable wav -> feats."""
+        object.__setattr__(self, "_extractor", extractor)
+
+    def extract(self, wav):
+        """content_encoder.py:53-56: pad 40 + 40 samples, frozen feature extractor, [B, T', H] -> [B, H, T']."""
+        ex = self._extractor
+        if ex is None:
+            raise RuntimeError("HubertContentEncoder: a waveform batch [B, 1, T] needs a feature extractor "
+                               "(set_feature_extractor); without one pass HuBERT features [B, %d, T']"
+                               % self.hubert_channels)
+        pad = (HUBERT_WINDOW - HUBERT_DOWNSAMPLE) // 2
+        with torch.no_grad():
+            w = F.pad(wav, (pad, pad)).squeeze(1)
+            out = ex.extract_features(w) if hasattr(ex, "extract_features") else ex(w)
+            feats = out[0] if isinstance(out, (tuple, list)) else out
+            if feats.dim() != 3 or feats.shape[2] != self.hubert_channels:
+                raise RuntimeError("feature extractor returned %s, expected [B, T', %d]"
+                                   % (tuple(feats.shape), self.hubert_channels))
+            return feats.transpose(1, -1).float().contiguous()
+
     def forward(self, x, x_lengths, pitch, pitch_lengths):
+        if x.dim() == 3 and x.shape[1] == 1 and self.hubert_channels != 1:
+            x = self.extract(x)
         hubert_out = self.hubert_proj(x)
         pitch_out = F.embedding(pitch, self.emb_pitch.weight).transpose(1, -1).contiguous()  # gather: torch glue
         if self.concat:
@@ -66,3 +102,8 @@ class PreloadHubertContentEncoder(HubertContentEncoder):
                  hubert_channels, num_pitch, n_fft=2048, hop_size=512):
         super().__init__(None, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
                          p_dropout, hubert_channels, num_pitch, n_fft, hop_size)
+
+    def forward(self, x, x_lengths, pitch, pitch_lengths):
+        if x.dim() == 3 and x.shape[1] == 1 and self.hubert_channels != 1:
+            raise RuntimeError("PreloadHubertContentEncoder takes precomputed features (content_encoder.py:110)")
+        return super().forward(x, x_lengths, pitch, pitch_lengths)

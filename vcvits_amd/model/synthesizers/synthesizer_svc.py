@@ -1,9 +1,9 @@
 """vits/model/synthesizers/synthesizer_svc.py:18-119 of the reference.
 
-Differences forced by what is outside the tree: the content encoder takes HuBERT *features*
-[B, hubert_channels, T] where the reference takes a waveform and runs a frozen fairseq HuBERT
-(:57, content_encoder.py:54-56), and the decoder is the in-package HiFi-GAN Generator built from
-the config's own hyper-parameters where the reference downloads one from torch.hub (:59)."""
+Differences forced by what is outside the tree: the frozen fairseq HuBERT (:57, content_encoder.py:54-56) is a
+pluggable `feature_extractor` (kwarg, or `enc_p.set_feature_extractor`); without one the content encoder takes
+HuBERT *features* [B, hubert_channels, T] instead of a waveform.  The decoder is the in-package HiFi-GAN
+Generator built from the config's own hyper-parameters where the reference downloads one from torch.hub (:59)."""
 import torch
 from torch import nn
 
@@ -35,7 +35,8 @@ class SynthesizerSVC(nn.Module):
         else:
             self.enc_p = HubertContentEncoder(kwargs.get("hubert_ckpt"), inter_channels, hidden_channels,
                                               filter_channels, n_heads, n_layers, kernel_size, p_dropout,
-                                              hubert_channels, num_pitch)
+                                              hubert_channels, num_pitch,
+                                              feature_extractor=kwargs.get("feature_extractor"))
         self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
                              upsample_rates, upsample_initial_channel, upsample_kernel_sizes,
                              gin_channels=kwargs.get("dec_gin_channels", 0))
@@ -76,7 +77,7 @@ class SynthesizerSVC(nn.Module):
         logs_p = ops.interpolate_nearest(logs_p, y_max_len)
         if noise is None:
             noise = torch.randn_like(m_p)
-        z_p = m_p + noise * torch.exp(logs_p) * noise_scale  # prior sample: elementwise torch glue
+        z_p = ops.prior_sample(m_p, logs_p, noise, float(noise_scale))  # m_p + noise * exp(logs_p) * noise_scale
         z = self.flow(z_p, y_mask, g=g, reverse=True)
         zm = ops.mask_mul(z, y_mask.reshape(y_mask.shape[0], -1))
         o = self.dec(zm[:, :, :max_len].contiguous())

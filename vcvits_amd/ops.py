@@ -40,6 +40,21 @@ def conv_out_len(tin, k, stride, pad, dil):
 
 _USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
 
+# Arithmetic of the GEMM-shaped kernels: "f32" (fp32-input MFMA, exact fp32) or "bf16" (operands rounded to bf16 on
+# their way into the matrix cores, fp32 accumulate; activations, master weights, losses and the optimizer stay fp32 --
+# the reference's AMP recipe, configs/base.json:18 / train.py:104-106, with bf16 in place of fp16).
+_COMPUTE = ["f32"]
+
+
+def set_compute_dtype(name):
+    if name not in ("f32", "bf16"):
+        raise ValueError("compute dtype must be 'f32' or 'bf16'")
+    _COMPUTE[0] = name
+
+
+def compute_dtype():
+    return _COMPUTE[0]
+
 
 def _launch_conv(a, flip_w=None):
     """Forward-type launches go to the LDS-DMA kernel when it is eligible (vcv_conv_dma_plan succeeds),
@@ -338,6 +353,12 @@ def register_grad_sink(param, grad_view, notify=None):
     _GRAD_SINKS[param.data_ptr()] = (grad_view, notify, weakref.ref(param))
 
 
+def unregister_grad_sink(param):
+    e = _GRAD_SINKS.get(param.data_ptr())
+    if e is not None and e[2]() is param:
+        del _GRAD_SINKS[param.data_ptr()]
+
+
 def clear_grad_sinks():
     _GRAD_SINKS.clear()
 
@@ -550,7 +571,13 @@ class _ConvFn(torch.autograd.Function):
             dx = link_dres if dx is None else dx.add_(link_dres)
         if ctx.has_res and ctx.needs_input_grad[3]:
             if ctx.link is not None and ctx.link[1] == "src":
-                ctx.link[0].dres = dy  # handed to the linked conv's data gradient (runs later in this backward)
+                # handed to the linked conv's data gradient: that node consumes this conv's output, so whenever the
+                # gradient of x is computed at all it runs later in this same backward pass and takes the hand-off
+                # (a link object lives for one forward, so a hand-off nobody collects dies with the graph)
+                if ctx.link[0].dres is not None:
+                    raise RuntimeError("ResGradLink: a residual gradient of an earlier backward pass was never "
+                                       "consumed (backward through the same graph twice?)")
+                ctx.link[0].dres = dy
             else:
                 dres = dy
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
@@ -1193,6 +1220,15 @@ def coupling(x1, m, mask, reverse=False):
     return _CouplingFn.apply(x1, m, mask, reverse)
 
 
+def prior_sample(m_p, logs_p, noise, noise_scale=1.0):
+    """z_p = m_p + noise * exp(logs_p) * noise_scale (synthesizer_svc.py:104; inference only, no autograd)."""
+    m_p, logs_p, noise = _f32c(m_p.detach()), _f32c(logs_p.detach()), _f32c(noise.detach())
+    z = torch.empty_like(m_p)
+    check(lib().vcv_prior_sample(ptr(m_p), ptr(logs_p), ptr(noise), ptr(z), m_p.numel(), float(noise_scale), stream()),
+          "vcv_prior_sample")
+    return z
+
+
 class _LayerNormCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, gamma, beta, eps):
@@ -1252,7 +1288,17 @@ def next_seed():
 
 
 def manual_seed(seed):
+    """Reseed the dropout stream (callers: VCVITS.configure_optimizers seeds it from torch.initial_seed() + rank so
+    data-parallel ranks draw different masks; checkpoints carry get_seed_state())."""
     _seed_state[0] = (int(seed) * 2654435761 + 0x9E3779B97F4A7C15) % (1 << 64)
+
+
+def get_seed_state():
+    return int(_seed_state[0])
+
+
+def set_seed_state(state):
+    _seed_state[0] = int(state) % (1 << 64)
 
 
 def dropout(x, p, training=True):
