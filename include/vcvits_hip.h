@@ -108,6 +108,17 @@ int vcv_conv_dma_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws,
                      void* stream);
 
 /*
+ * bf16-operand variant of vcv_conv_dma_plan / vcv_conv_dma_run (same launch family, same argument meaning, same
+ * epilogue): operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16, sums are fp32, `x` / `y` and
+ * every epilogue operand stay fp32 in HBM -- the reference's AMP recipe (configs/base.json:18 `fp16_run`,
+ * train.py:104-106) with bf16 in place of fp16.  The packed-weight buffer holds bf16 slabs; out[0] of the plan is
+ * its size in 4-byte words.  A pack made by one family is never valid for the other (different out[2]).
+ */
+int vcv_conv_bf16_plan(const VcvConvArgs* args, int flip, int64_t* out);
+int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
+                      void* stream);
+
+/*
  * Weight gradient of the same family (torch autograd of the call sites above):
  *   dw[(g*Mg + m), c, k] (+)= alpha * sum_{b, q, p} tfa(dy[b, g*Mg+m, q, p]) *
  *                                               tfb(x[b, g*Cg+c, q*s + k*dj + off, p])
@@ -132,6 +143,16 @@ typedef struct VcvWgradArgs {
 } VcvWgradArgs;
 
 int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
+
+/*
+ * bf16-operand weight gradient (same VcvWgradArgs, G == 1, transforms NONE / LEAKY): operands rounded to bf16 on their
+ * way into v_mfma_f32_32x32x16_bf16, fp32 sums.  The reduction over (batch, positions) is split over workgroups that
+ * each write a partial tile to `scratch`; a finishing pass adds the partials in a fixed order onto dw -- no atomics,
+ * bit-reproducible.  vcv_wgrad_bf16_scratch: floats of scratch the launch wants (0 = not eligible: use
+ * vcv_conv_wgrad); any scratch of at least Mg*Cg*K floats is accepted (less scratch = coarser split).
+ */
+int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* args);
+int vcv_wgrad_bf16(const VcvWgradArgs* args, float* scratch, int64_t scratch_floats, void* stream);
 
 /* Thin convolutions (HBM-bound, no MFMA): a conv with ONE output channel (discriminator conv_post
  * 1024->1, discriminator.py:25,61; generator conv_post 32->1 + tanh) and the weight gradient of a

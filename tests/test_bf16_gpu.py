@@ -1,0 +1,203 @@
+"""GPU: the bf16-operand GEMM path (row g: BASELINE configs 3-5; north_star: "generated waveform RMS within 1e-3
+bf16").  Two kinds of checks:
+  * exactness of the kernels: a bf16-mode launch must equal the fp32 CPU convolution of the bf16-ROUNDED operands up
+    to fp32 summation order (1e-5) -- rounding happens exactly once, on the way into the matrix cores;
+  * the north_star tolerance: generator / inference waveforms in bf16 mode against the fp32 oracle, RMS <= 1e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import fill_state_dict, keys_shapes_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    from vcvits_amd import ops
+    ops.set_compute_dtype("bf16")
+    yield ops
+    ops.set_compute_dtype("f32")
+
+
+def rb(t):
+    """round to bf16 (nearest even) and back: what the kernels feed the matrix cores"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rel(a, b):
+    return (a.detach().cpu().double() - b.double()).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+CASES = [
+    # kind, B, C, M, T, K, s, pad, d, P, in_leaky
+    ("conv", 2, 256, 512, 384, 5, 1, 2, 1, 1, False),     # WN in_layer
+    ("conv", 2, 128, 128, 2048, 11, 1, 25, 5, 1, True),   # generator resblock, dilation 5
+    ("conv", 2, 64, 64, 4096, 3, 1, 3, 3, 1, True),
+    ("conv", 2, 32, 32, 8192, 7, 1, 3, 1, 1, True),
+    ("conv", 3, 1025, 256, 384, 1, 1, 0, 1, 1, False),    # posterior `pre` (ragged channel tail)
+    ("conv", 2, 256, 768, 204, 3, 1, 1, 1, 1, False),     # FFN
+    ("conv", 2, 130, 100, 333, 5, 1, 2, 1, 1, False),     # ragged everything
+    ("period", 2, 32, 128, 421, 5, 3, 2, 1, 13, False),
+    ("period", 2, 128, 512, 141, 5, 3, 2, 1, 13, False),
+    ("period", 2, 512, 1024, 47, 5, 3, 2, 1, 13, False),
+    ("period", 2, 1024, 1024, 16, 5, 1, 2, 1, 13, False),  # U = 208: the 224-wide tile
+    ("period", 2, 1024, 1024, 7, 5, 1, 2, 1, 37, False),   # U = 259: the 288-wide tile
+    ("period", 2, 512, 1024, 304, 5, 3, 2, 1, 2, False),
+    ("convT", 2, 256, 128, 256, 16, 8, 4, 1, 1, True),
+    ("convT", 2, 128, 64, 2048, 4, 4, 0, 1, 1, True),
+    ("convT", 2, 64, 32, 4096, 4, 2, 1, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-C%d-M%d-T%d-K%d-s%d-d%d-P%d" % (c[0], c[2], c[3], c[4], c[5], c[6], c[8], c[9]))
+def test_bf16_conv_is_exact_on_rounded_operands(gpu, bf16_mode, case):
+    ops = bf16_mode
+    kind, B, C, M, T, K, s, pad, d, P, in_leaky = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    t = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))
+    if kind == "convT":
+        x, w, b = t(B, C, T), t(C, M, K) * (C * K / s) ** -0.5, t(M) * 0.1
+    elif kind == "period":
+        x, w, b = t(B, C, T, P), t(M, C, K, 1) * (C * K) ** -0.5, t(M) * 0.1
+    else:
+        x, w, b = t(B, C, T), t(M, C, K) * (C * K) ** -0.5, t(M) * 0.1
+    # reference: fp32 CPU conv of the ROUNDED operands (leaky-ReLU of the input is applied before the rounding)
+    xr = x.clone().requires_grad_(True)
+    xin = rb(F.leaky_relu(x, 0.1)) if in_leaky else rb(x)
+    xin.requires_grad_(True)
+    wq = rb(w).requires_grad_(True)
+    if kind == "convT":
+        yr = F.conv_transpose1d(xin, wq, b, stride=s, padding=pad)
+    elif kind == "period":
+        yr = F.conv2d(xin, wq, b, stride=(s, 1), padding=(pad, 0))
+    else:
+        yr = F.conv1d(xin, wq, b, stride=s, padding=pad, dilation=d)
+    before = dict(ops.LAUNCH_COUNTS)
+    xg, wg, bg = (v.to(gpu).requires_grad_(True) for v in (x, w, b))
+    if kind == "convT":
+        yg = ops.conv_transpose1d(xg, wg, bg, stride=s, pad=pad, in_leaky=in_leaky, slope=0.1)
+    else:
+        yg = ops.conv1d(xg, wg, bg, stride=s, pad=pad, dil=d, in_leaky=in_leaky, slope=0.1)
+    assert ops.LAUNCH_COUNTS["bf16"] == before["bf16"] + 1, "forward did not run on the bf16 kernel"
+    assert rel(yg, yr.detach()) < 1e-5, ("y", rel(yg, yr.detach()))
+    # within bf16 rounding of the UN-rounded fp32 result (sanity of the tolerance story: ~2^-9 per operand)
+    with torch.no_grad():
+        xf = F.leaky_relu(x, 0.1) if in_leaky else x
+        yf = (F.conv_transpose1d(xf, w, b, stride=s, padding=pad) if kind == "convT" else
+              F.conv2d(xf, w, b, stride=(s, 1), padding=(pad, 0)) if kind == "period" else
+              F.conv1d(xf, w, b, stride=s, padding=pad, dilation=d))
+    assert rel(yg, yf) < 2e-2
+    # data gradient: dy and w rounded, fp32 sums; the input leaky-ReLU derivative is applied in fp32 afterwards
+    gy = t(*yr.shape)
+    gq = rb(gy)
+    if kind == "convT":
+        dxin = F.conv1d(gq, wq.detach(), stride=s, padding=pad)
+    elif kind == "period":
+        dxin = torch.autograd.grad(F.conv2d(xin, wq.detach(), None, stride=(s, 1), padding=(pad, 0)), xin, gq)[0]
+    else:
+        dxin = torch.autograd.grad(F.conv1d(xin, wq.detach(), None, stride=s, padding=pad, dilation=d), xin, gq)[0]
+    if in_leaky:
+        dxin = dxin * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, 0.1))
+    before = dict(ops.LAUNCH_COUNTS)
+    yg.backward(gy.to(gpu))
+    if kind == "convT" and s > 3:
+        # the data gradient of a ConvTranspose with stride > 3 (the two first generator stages) stays on the fp32 kernel
+        dxin = F.conv1d(gy, w, stride=s, padding=pad)
+        if in_leaky:
+            dxin = dxin * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, 0.1))
+    else:
+        assert ops.LAUNCH_COUNTS["bf16"] > before["bf16"], "data gradient did not run on the bf16 kernel"
+    assert rel(xg.grad, dxin) < 1e-5, ("dx", rel(xg.grad, dxin))
+    # weight gradient: both activations rounded, fp32 sums (the leaky-ReLU of the input is applied before rounding)
+    if kind == "convT":
+        dwr = torch.autograd.grad(F.conv_transpose1d(xin, wq, None, stride=s, padding=pad), wq, gq)[0]
+    elif kind == "period":
+        dwr = torch.autograd.grad(F.conv2d(xin, wq, None, stride=(s, 1), padding=(pad, 0)), wq, gq)[0]
+    else:
+        dwr = torch.autograd.grad(F.conv1d(xin, wq, None, stride=s, padding=pad, dilation=d), wq, gq)[0]
+    if not (kind == "convT" and s > 3):
+        assert ops.LAUNCH_COUNTS["wgrad_bf16"] == before["wgrad_bf16"] + 1, "weight gradient did not run on the bf16 kernel"
+        assert rel(wg.grad, dwr) < 2e-5, ("dw", rel(wg.grad, dwr))
+    assert rel(bg.grad, gy.sum(dim=[i for i in range(gy.dim()) if i != 1])) < 1e-5
+    # bit-reproducible: the split reduction is combined in a fixed order
+    wg2 = w.to(gpu).requires_grad_(True)
+    xg2 = x.to(gpu)
+    y2 = (ops.conv_transpose1d(xg2, wg2, None, stride=s, pad=pad, in_leaky=in_leaky, slope=0.1) if kind == "convT" else
+          ops.conv1d(xg2, wg2, None, stride=s, pad=pad, dil=d, in_leaky=in_leaky, slope=0.1))
+    y2.backward(gy.to(gpu))
+    if not (kind == "convT" and s > 3):
+        assert torch.equal(wg2.grad, wg.grad), "weight gradient differs between two identical launches"
+
+
+def _rms(a, b):
+    return ((a.detach().cpu().double() - b.double()) ** 2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize("widths", ["reduced", "base", "48k"])
+def test_generator_waveform_rms_bf16(gpu, bf16_mode, widths):
+    """north_star: generated waveform RMS within 1e-3 (bf16) of the fp32 reference path.  HiFi-GAN Generator forward in
+    bf16 mode against the fp32 CPU oracle, at reduced widths and at the two configs' real widths (32-frame segment)."""
+    from oracle import vits_oracle as O
+    from vcvits_amd.model.generator import Generator
+    ops = bf16_mode
+    C, up = {"reduced": (16, 32), "base": (256, 512), "48k": (128, 512)}[widths]
+    gen = Generator(C, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 4, 2], up, [16, 16, 4, 4])
+    torch.manual_seed(5)
+    gen = Generator(C, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 4, 2], up, [16, 16, 4, 4])  # reference init (N(0, 0.01) ups)
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    rng = np.random.default_rng(7)
+    z = torch.from_numpy(rng.standard_normal((2, C, 32)).astype(np.float32))
+    with torch.no_grad():
+        o_ref = O.generator_forward({"g." + k: v for k, v in sd.items()}, "g", z)
+        before = ops.LAUNCH_COUNTS["bf16"]
+        o = gen.to(gpu)(z.to(gpu))
+        used = ops.LAUNCH_COUNTS["bf16"] - before
+    assert o.shape == o_ref.shape == (2, 1, 16384)
+    if widths != "reduced":
+        assert used >= 60, "only %d launches of the generator ran on the bf16 kernel" % used
+    r = _rms(o, o_ref)
+    assert r <= 1e-3, "waveform RMS error %.3e (signal RMS %.3e)" % (r, o_ref.pow(2).mean().sqrt().item())
+    # and it IS a different arithmetic: not bit-equal to the fp32 path at real widths
+    if widths != "reduced":
+        ops.set_compute_dtype("f32")
+        with torch.no_grad():
+            o32 = gen(z.to(gpu))
+        ops.set_compute_dtype("bf16")
+        assert _rms(o32, o_ref) < r
+
+
+def test_infer_waveform_rms_bf16_48k(gpu, bf16_mode):
+    """BASELINE configs[4] arithmetic: 48k widths, flow reverse + decoder in bf16 mode vs the fp32 oracle, 938 frames."""
+    from oracle import vits_oracle as O
+    from vcvits_amd import configs
+    from vcvits_amd.model.synthesizers.synthesizer_svc import SynthesizerSVC
+    ops = bf16_mode
+    cfg = configs.base_48k()
+    d, m = cfg["data"], cfg["model"]
+    torch.manual_seed(6)
+    net = SynthesizerSVC(d["filter_length"] // 2 + 1, 32, n_speakers=d["n_speakers"], **m).eval()
+    with torch.no_grad():
+        for n, p in net.flow.named_parameters():
+            if ".post." in n:
+                p.normal_(0, 0.02)
+    sd = {"n." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(gpu)
+    C, H, T = m["inter_channels"], m["hidden_channels"], 938
+    rng = np.random.default_rng(8)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    m_p, logs_p, noise = t(1, C, T), t(1, C, T) * 0.1 - 1.0, t(1, C, T)
+    sid = torch.tensor([3])
+    mask = torch.ones(1, 1, T)
+    with torch.no_grad():
+        spk = net.emb_g(sid.to(gpu)).unsqueeze(-1)
+        z_p = ops.prior_sample(m_p.to(gpu), logs_p.to(gpu), noise.to(gpu), 1.0)
+        z = net.flow(z_p, mask.to(gpu), g=spk, reverse=True)
+        o = net.dec(ops.mask_mul(z, mask.to(gpu).reshape(1, -1)))
+        g = F.embedding(sid, sd["n.emb_g.weight"]).unsqueeze(-1)
+        z_o = O.flow_forward(sd, "n.flow", m_p + noise * torch.exp(logs_p), mask, g, True, C, H, 5, 1, 4)
+        o_o = O.generator_forward(sd, "n.dec", z_o * mask)
+    assert _rms(z, z_o) <= 2e-2 * z_o.pow(2).mean().sqrt().item()  # flow output within bf16 rounding of the fp32 path
+    r = _rms(o, o_o)
+    assert r <= 1e-3, "waveform RMS error %.3e (signal RMS %.3e)" % (r, o_o.pow(2).mean().sqrt().item())

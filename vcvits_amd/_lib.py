@@ -64,7 +64,7 @@ def lib():
         for name in EXPORTS:
             fn = getattr(L, name)
             if name != "vcv_version":
-                fn.restype = ctypes.c_int64 if name == "vcv_conv_dma_workspace" else ctypes.c_int
+                fn.restype = ctypes.c_int64 if name in ("vcv_conv_dma_workspace", "vcv_wgrad_bf16_scratch") else ctypes.c_int
                 fn.argtypes = _ARGTYPES[name]
         _lib = L
     return _lib
@@ -82,7 +82,7 @@ EXPORTS = [
     "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
     "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_conv_c1_fwd", "vcv_conv_c1_dgrad", "vcv_linear_t1_fwd", "vcv_linear_t1_dgrad", "vcv_linear_t1_wgrad", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
     "vcv_act_grad", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_loss_many_sum", "vcv_loss_many_grad", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_dgrad", "vcv_grouped41_wgrad",
-    "vcv_prior_sample", "vcv_prof_bytes",
+    "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16",
 ]
 
 
@@ -148,6 +148,10 @@ _ARGTYPES = {
     "vcv_conv_dma_plan": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(ctypes.c_int64)],
     "vcv_conv_dma_run": [ctypes.POINTER(VcvConvArgs), _P, _P, _I, _I, _P],
     "vcv_prior_sample": [_P, _P, _P, _P, _L, _F, _P],
+    "vcv_conv_bf16_plan": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(ctypes.c_int64)],
+    "vcv_conv_bf16_run": [ctypes.POINTER(VcvConvArgs), _P, _P, _I, _I, _P],
+    "vcv_wgrad_bf16_scratch": [ctypes.POINTER(VcvWgradArgs)],
+    "vcv_wgrad_bf16": [ctypes.POINTER(VcvWgradArgs), _P, _L, _P],
     "vcv_prof_begin": [_I],
     "vcv_prof_end": [ctypes.POINTER(ctypes.c_double), _I],
     "vcv_prof_dump": [ctypes.c_char_p],

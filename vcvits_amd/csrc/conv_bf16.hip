@@ -1,0 +1,451 @@
+// conv_bf16.hip -- bf16-operand variant of the implicit-GEMM convolution (forward-type and phased launches, the
+// same launch family conv_dma.hip covers): v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM.
+//
+// The reference trains under AMP (configs/base.json:18, train.py:104-106: fp16 autocast of the convs, fp32 master
+// weights, fp32 losses).  Here the same recipe with bf16: operands are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) on their way into the matrix cores, products are exact, sums are fp32, and everything outside
+// the GEMMs (activations in HBM, epilogue, losses, optimizer) stays fp32.
+//
+// MFMA mapping: one instruction = 32 output channels x 32 positions x 16 REDUCTION CHANNELS of one tap.  Lane
+// (r = lane & 31, h = lane >> 5) holds A[m = r][c = 8h .. 8h+7] and B[c = 8h .. 8h+7][position r]: 8 consecutive
+// channels = one 16-byte LDS read, so both images are channel-innermost:
+//   As  [tap j][16-channel group cg][h][m (BM)][8 ch]   bf16   (packed in HBM in exactly this order: one chunk of one
+//                                                              tile is a contiguous slab, copied by global_load_lds
+//                                                              1 KiB per wave-instruction, as conv_dma.hip does)
+//   Xs  [cg][h][position (span)][8 ch]                  bf16   (register-staged: each lane loads 8 channels of ONE
+//                                                              position -- 8 coalesced 256-byte wave loads -- applies
+//                                                              the input leaky-ReLU, converts and writes 16 bytes;
+//                                                              the transpose [c][t] -> [t][c] costs nothing extra)
+// A tap shift is a position offset of the B read: every tap re-reads the same staged span (an input element is
+// fetched once per workgroup, not once per tap).  Reads: lanes r = 0..31 of one half read 512 contiguous bytes
+// (stride-1 layers) or 16-byte slots 3 apart (the period discriminators' stride 3: coprime with the 16 slots of a
+// bank row) -> conflict-free ds_read_b128.
+// Two LDS buffers: the weight DMA and the input loads of chunk c+1 are issued before the MFMA loop of chunk c, the
+// converted inputs are written after it, one barrier per chunk.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+struct BfGeom {
+  int BKC;      // reduction channels per chunk (multiple of 16)
+  int ncg;      // BKC / 16
+  int nch;      // chunks
+  int ntu;      // position tiles per batch element
+  int nmt;      // M tiles
+  int xw;       // staged span (positions, a multiple of 64)
+  int a_bytes;  // JA * BKC * BM * 2
+  int buf_bytes;  // a_bytes + BKC * xw * 2
+  int JA;         // taps stored per channel in a weight slab (K, or ceil(K/phases) for a phased launch)
+  int phases;     // > 1: transposed / strided-data-gradient launch, one residue per blockIdx.z
+  int ks;         // > 1: the chunks are split over ks blocks per tile, partial sums go to a scratch slab each
+};
+
+// ---- weight pack: fp32 w -> bf16 slabs wp[phase][m-tile][chunk][j][cg][h][m][8] -------------------------------
+// mode 0: w is [M, C, K] (forward);  mode 1: w is [C, M, K], A(m, c, j) = w[c, m, K-1-j] (stride-1 data gradient);
+// mode 2: w is [C, M, K], residue r = phase keeps taps k = r + j*phases (ConvTranspose forward / strided dgrad)
+__global__ void __launch_bounds__(256)
+pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M, int C, int K, int BM, int BKC, int JA,
+                 int nch, int nmt, int phases, int mode, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ncg = BKC >> 4;
+  size_t t = i;
+  const int ml = (int)(t % BM); t /= BM;
+  const int hh = (int)(t & 1); t >>= 1;
+  const int cg = (int)(t % ncg); t /= ncg;
+  const int j = (int)(t % JA); t /= JA;
+  const int ch = (int)(t % nch); t /= nch;
+  const int mt = (int)(t % nmt); t /= nmt;
+  const int r = (int)t;
+  const int m = mt * BM + ml;
+  const int c0 = ch * BKC + cg * 16 + hh * 8;
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    float f = 0.f;
+    if (m < M && c < C) {
+      if (mode == 0) { if (j < K) f = w[((size_t)m * C + c) * K + j]; }
+      else if (mode == 1) { if (j < K) f = w[((size_t)c * M + m) * K + (K - 1 - j)]; }
+      else { const int k = r + j * phases; if (k < K) f = w[((size_t)c * M + m) * K + k]; }
+    }
+    v[e] = (__bf16)f;
+  }
+  wp[i] = v;
+}
+
+template <int TM, int TN, int WM, int WN, bool LEAKY, int MAXT>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict__ wp, float* __restrict__ part) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int kz = blockIdx.x % tg.ks;
+  const int bx = blockIdx.x / tg.ks;
+  const int b = bx / tg.ntu, ut = bx % tg.ntu;
+  const int mt = blockIdx.y;
+  const int r = blockIdx.z;  // output residue of a phased launch (0 otherwise)
+  const int JA = tg.JA, P = p.P, U = p.Q * P, Cg = p.Cg, Mg = p.Mg;
+  const int K = tg.phases > 1 ? (r < p.K ? (p.K - r + tg.phases - 1) / tg.phases : 0) : p.K;
+  const int oo = p.oo + (tg.phases > 1 ? r : 0);
+  const int u0 = ut * BN, m0 = mt * BM;
+  const int qa = u0 / P;
+  const int jspan = (JA - 1) * p.dj;
+  const int jmin = jspan < 0 ? jspan : 0;
+  const int f0 = (qa * p.s + p.off + jmin) * P;  // first staged input position (flattened [row][P]); may be < 0
+  const int BKC = tg.BKC, ncg = tg.ncg, XW = tg.xw;
+
+  int laneoff[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    int u = u0 + (wn * TN + tn) * 32 + l31;
+    if (u > U - 1) u = U - 1;
+    const int q = u / P, pc = u - q * P;
+    laneoff[tn] = (((q - qa) * p.s - jmin) * P + pc + h * XW) * 16;  // byte offset in the Xs image (h plane included)
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+
+  const long long TinP = (long long)p.Tin * P;
+  const float* xb = p.x + (size_t)b * Cg * (size_t)TinP;
+  const char* wtile = (const char*)wp + ((size_t)r * gridDim.y + mt) * tg.nch * (size_t)tg.a_bytes;
+  const int nA = tg.a_bytes >> 10;  // 1 KiB wave-instructions per weight slab
+  const int npb = XW >> 6;          // 64-position blocks per span
+  const int ntask = (BKC >> 3) * npb;  // (8-channel group, position block) staging tasks per chunk
+
+  auto issueA = [&](int ch, int buf) {
+    char* As = smem + buf * tg.buf_bytes;
+    const char* slab = wtile + (size_t)ch * tg.a_bytes;
+    for (int i = wave; i < nA; i += NW)
+      __builtin_amdgcn_global_load_lds((const void*)(slab + i * 1024 + lane * 16), (lds_ptr)(As + i * 1024), 16, 0, 0);
+  };
+  // registers of the input loads in flight: task t of this wave = staging task wave + t * NW
+  float xr[MAXT][8];
+  auto loadX = [&](int ch) {
+    const int c0 = ch * BKC;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int task = wave + t * NW;
+      if (task < ntask) {
+        const int g8 = task / npb, pb = task - g8 * npb;
+        const unsigned voff = (unsigned)(f0 + pb * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c0 + g8 * 8 + e;
+          const unsigned rec = c < Cg ? (unsigned)(TinP * 4) : 0u;
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * (size_t)TinP), 0, (int)rec, 0x00020000);
+          xr[t][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+        }
+      }
+    }
+  };
+  auto storeX = [&](int buf) {
+    char* Xs = smem + buf * tg.buf_bytes + tg.a_bytes;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int task = wave + t * NW;
+      if (task < ntask) {
+        const int g8 = task / npb, pb = task - g8 * npb;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = xr[t][e];
+          if (LEAKY) f = fmaxf(f, f * p.slope);  // slope in [0, 1)
+          v[e] = (__bf16)f;
+        }
+        *reinterpret_cast<bf16x8*>(Xs + ((size_t)(g8 * XW + pb * 64 + lane)) * 16) = v;
+      }
+    }
+  };
+
+  const int ch_begin = (int)((long long)kz * tg.nch / tg.ks), ch_end = (int)((long long)(kz + 1) * tg.nch / tg.ks);
+  issueA(ch_begin, 0);
+  loadX(ch_begin);
+  storeX(0);
+  __syncthreads();
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int cb = (ch - ch_begin) & 1;
+    const bool more = ch + 1 < ch_end;
+    if (more) {
+      issueA(ch + 1, cb ^ 1);
+      loadX(ch + 1);
+    }
+    const char* As = smem + cb * tg.buf_bytes;
+    const char* Xs = As + tg.a_bytes;
+    for (int cg = 0; cg < ncg; ++cg) {
+      const char* Ab = As + ((size_t)(cg * 2 + h) * BM + wm * TM * 32 + l31) * 16;
+      const char* Xb = Xs + (size_t)cg * 2 * XW * 16;
+      for (int j = 0; j < K; ++j) {
+        bf16x8 a[TM], bb[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const bf16x8*>(Ab + ((size_t)j * ncg * 2 * BM + tm * 32) * 16);
+        const int xo = j * p.dj * P * 16;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bb[tn] = *reinterpret_cast<const bf16x8*>(Xb + laneoff[tn] + xo);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+    if (more) storeX(cb ^ 1);
+    __syncthreads();  // publishes chunk ch+1 (LDS writes + the weight DMA) and retires the reads of chunk ch
+  }
+
+  const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
+  const bool mtail = m0 + BM > Mg;
+  if (tg.ks > 1) {
+    float* pb = part + (((size_t)kz * p.B + b) * Mg + m0) * (size_t)U;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int u = u0 + (wn * TN + tn) * 32 + l31;
+      if (u >= U) continue;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (mtail && ml >= rows_valid) continue;
+          pb[(size_t)ml * U + u] = acc[tm][tn][e];
+        }
+    }
+    return;
+  }
+  // ---- epilogue (as conv_gemm_kernel / conv_dma_kernel) ----
+  const unsigned rowstride = (unsigned)(p.Tout * P);
+  const size_t ybase = ((size_t)b * Mg + m0) * rowstride;
+  const float* bias = p.bias ? p.bias + m0 : nullptr;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int u = u0 + (wn * TN + tn) * 32 + l31;
+    if (u >= U) continue;
+    const int q = u / P, pc = u - q * P;
+    const int trow = q * p.os + oo;
+    if (trow < 0 || trow >= p.Tout) continue;
+    const float mk = p.mask ? p.mask[(size_t)b * p.Tout + trow] : 1.f;
+    const size_t colbase = ybase + (size_t)trow * P + pc;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (mtail && ml >= rows_valid) continue;
+        const size_t idx = colbase + (size_t)((unsigned)ml * rowstride);
+        float v = p.alpha * acc[tm][tn][e];
+        if (bias) v += bias[ml];
+        v = vcv_act(v, p.out_act, p.slope);
+        if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
+        else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
+        else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
+        if (p.res) v += p.res[idx];
+        v *= mk;
+        if (p.accumulate) v += p.y[idx];
+        p.y[idx] = v;
+      }
+    }
+  }
+}
+
+// Adds the ks partial slabs of a split launch and applies the epilogue.
+__global__ void __launch_bounds__(256) conv_bf16_finish_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
+  const int U = p.Q * p.P;
+  const size_t n = (size_t)p.B * p.Mg * U;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int u = (int)(i % U);
+  const size_t bm = i / U;
+  const int m = (int)(bm % p.Mg), b = (int)(bm / p.Mg);
+  const int q = u / p.P, pc = u - q * p.P;
+  const int trow = q * p.os + p.oo;
+  if (trow < 0 || trow >= p.Tout) return;
+  float v = 0.f;
+  for (int k = 0; k < ks; ++k) v += part[(size_t)k * n + i];
+  v *= p.alpha;
+  if (p.bias) v += p.bias[m];
+  v = vcv_act(v, p.out_act, p.slope);
+  const size_t idx = (bm * p.Tout + trow) * p.P + pc;
+  if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
+  else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
+  else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
+  if (p.res) v += p.res[idx];
+  if (p.mask) v *= p.mask[(size_t)b * p.Tout + trow];
+  if (p.accumulate) v += p.y[idx];
+  p.y[idx] = v;
+}
+
+struct Plan {
+  int variant;
+  int BM, BN, NW;
+  BfGeom g;
+  size_t scratch_floats, pack_bytes, lds_bytes;
+};
+
+constexpr int MAXT = 4;  // staging tasks (8 loads each) a wave keeps in flight
+
+bool eligible(const VcvConvArgs& a) {
+  const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
+  const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1;
+  return (fwd_type || phased) && a.G == 1 &&
+         (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) && a.Mg >= 32 &&
+         a.Cg >= 16 && a.K <= 16 && a.s >= 1 && a.s <= 3 && (long long)a.Tin * a.P * 4 < (1ll << 31) &&
+         (long long)a.Mg * a.Tout * a.P < (1ll << 31);
+}
+
+bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
+  pl.BM = BM; pl.BN = BN; pl.NW = NW;
+  BfGeom& g = pl.g;
+  const int qspan = (BN - 1) / a.P + 1;
+  const int adj = a.dj < 0 ? -a.dj : a.dj;
+  g.phases = a.phases > 1 ? a.phases : 1;
+  g.JA = vcv_cdiv(a.K, g.phases);
+  const int rowmax = (qspan * a.s + (g.JA - 1) * adj + 1) * a.P;
+  g.xw = (rowmax + 63) & ~63;
+  // chunk depth: 16-channel groups per chunk.  Candidates must fit two LDS buffers (one when a single chunk covers the
+  // reduction) and MAXT staging tasks per wave; among them the least zero-padded channel count wins, then the deeper.
+  const int cmax = ((a.Cg + 15) & ~15);
+  const size_t lds_cap = 156 * 1024;
+  int bkc = 0;
+  long long best_pad = 1ll << 60;
+  for (int cand = 64; cand >= 16; cand -= 16) {
+    if (cand > cmax) continue;
+    const int nch = vcv_cdiv(a.Cg, cand);
+    const size_t buf = (size_t)g.JA * cand * BM * 2 + (size_t)cand * g.xw * 2;
+    if ((nch > 1 ? 2 : 1) * buf > lds_cap || (cand >> 3) * (g.xw >> 6) > MAXT * NW) continue;
+    const long long padded = (long long)nch * cand;
+    if (padded < best_pad) best_pad = padded, bkc = cand;
+  }
+  if (bkc == 0) return false;
+  g.BKC = bkc;
+  g.ncg = bkc >> 4;
+  g.nch = vcv_cdiv(a.Cg, bkc);
+  g.ntu = vcv_cdiv(a.Q * a.P, BN);
+  g.nmt = vcv_cdiv(a.Mg, BM);
+  g.a_bytes = g.JA * bkc * BM * 2;
+  g.buf_bytes = g.a_bytes + bkc * g.xw * 2;
+  pl.lds_bytes = (g.nch > 1 ? 2ull : 1ull) * g.buf_bytes;  // one chunk: no second buffer, more workgroups per CU
+  if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
+  g.ks = 1;
+  pl.pack_bytes = (size_t)g.phases * g.nmt * g.nch * g.a_bytes;
+  pl.scratch_floats = 0;
+  return true;
+}
+
+// variants: 0: 128x256 / 8 waves (2x2 per wave)   1: 128x128 / 8 waves (2x1)   2: 128x224 / 14 waves (2x1)
+//           3: 64x256 / 8 waves (1x2... 2x4 waves of 1x2)   4: 64x128 / 8 waves (1x1)   5: 32x256 / 8 waves (1x1)
+//           6: 64x224 / 14 waves (1x1)   7: 128x288 / 9 waves (4x1)
+bool choose(const VcvConvArgs& a, Plan& pl) {
+  const int U = a.Q * a.P;
+  if (U < 96) return false;
+  const int nph = a.phases > 1 ? a.phases : 1;
+  auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
+  bool ok = false;
+  if (a.Mg >= 128) {
+    if (U > 160 && U <= 224 && make_plan(a, 128, 224, 14, pl)) pl.variant = 2, ok = true;
+    else if (U > 256 && U <= 288 && make_plan(a, 128, 288, 9, pl)) pl.variant = 7, ok = true;
+    else if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
+    else if (make_plan(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
+  } else if (a.Mg >= 64) {
+    if (U > 160 && U <= 224 && make_plan(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
+    else if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
+    else if (make_plan(a, 64, 128, 8, pl)) pl.variant = 4, ok = true;
+  } else {
+    if (make_plan(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
+  }
+  if (!ok) return false;
+  // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass)
+  const long long nb = blocks(pl.BM, pl.BN);
+  if (nph == 1 && nb < 192 && pl.g.nch >= 4) {
+    long long ks = (384 + nb - 1) / nb;
+    if (ks > pl.g.nch / 2) ks = pl.g.nch / 2;
+    if (ks >= 2) {
+      pl.g.ks = (int)ks;
+      pl.scratch_floats = (size_t)ks * a.B * a.Mg * U;
+    }
+  }
+  return true;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch(const VcvConvArgs& a, const Plan& pl, bf16x8* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, NT = 64 * WM * WN;
+  const BfGeom& g = pl.g;
+  if (!pack_valid) {
+    const size_t total = pl.pack_bytes / 16;
+    const int mode = g.phases > 1 ? 2 : (flip ? 1 : 0);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Mg, a.Cg, a.K,
+                       BM, g.BKC, g.JA, g.nch, g.nmt, g.phases, mode, total);
+  }
+  void (*kern)(const VcvConvArgs, const BfGeom, const bf16x8*, float*) =
+      a.in_tf == VCV_TF_LEAKY ? conv_bf16_kernel<TM, TN, WM, WN, true, MAXT> : conv_bf16_kernel<TM, TN, WM, WN, false, MAXT>;
+  if (pl.lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
+    return VCV_EHIP;
+  dim3 grid(a.B * g.ntu * g.ks, g.nmt, g.phases), block(NT);
+  const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
+  const int tag[12] = {a.B, 2, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
+  const double abytes = 4.0 * ((double)a.B * a.Cg * a.Tin * a.P + (double)a.Mg * a.Cg * a.K +
+                               (double)a.B * a.Mg * a.Tout * a.P * (1 + (a.res ? 1 : 0) + (a.oaux ? 1 : 0)));
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, a, g, (const bf16x8*)wp, part);
+  if (g.ks > 1) {
+    const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
+    hipLaunchKernelGGL(conv_bf16_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
+  }
+  return vcv_check_launch();
+}
+
+}  // namespace
+
+// Same calling convention as vcv_conv_dma_plan / vcv_conv_dma_run (include/vcvits_hip.h): out[0] = BYTES / 4 of the
+// packed-weight buffer (so callers allocate it as out[0] fp32 words), out[1] = floats of per-launch scratch, out[2] =
+// signature of the pack layout.
+extern "C" int vcv_conv_bf16_plan(const VcvConvArgs* args, int flip, int64_t* out) {
+  if (!args || !out || !eligible(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose(*args, pl)) return VCV_EINVAL;
+  out[0] = (int64_t)((pl.pack_bytes + 3) / 4);
+  out[1] = (int64_t)pl.scratch_floats;
+  const BfGeom& g = pl.g;
+  out[2] = (1ll << 62) | ((int64_t)pl.BM << 40) | ((int64_t)g.BKC << 28) | ((int64_t)g.JA << 20) | ((int64_t)g.phases << 8) |
+           (flip ? 1 : 0);
+  return 0;
+}
+
+extern "C" int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
+                                 void* stream) {
+  if (!args || !pack_ws || !eligible(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose(*args, pl)) return VCV_EINVAL;
+  if (pl.g.ks > 1 && !scratch_ws) return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  bf16x8* wp = reinterpret_cast<bf16x8*>(pack_ws);
+  const bool pv = pack_valid != 0;
+  switch (pl.variant) {
+    case 0: return launch<2, 2, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 1: return launch<2, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 2: return launch<2, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 3: return launch<1, 2, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 4: return launch<1, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 5: return launch<1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 6: return launch<1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
+    default: return launch<4, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);
+  }
+}

@@ -1,0 +1,386 @@
+// wgrad_bf16.hip -- bf16-operand weight gradient (v_mfma_f32_32x32x16_bf16, fp32 accumulate) of the conv family:
+//   dw[m, c, k] += alpha * sum_{b, u = (q, p)} tfa(a[b, m, u]) * tfb(x[b, c, xrow(u) + k * dj * P])
+// (VcvWgradArgs of include/vcvits_hip.h; `a` = un-shifted operand, `x` = shifted operand, both fp32 activations).
+//
+// GEMM mapping: D[m][c] per tap, reduction over positions: one MFMA = 32 m x 32 c x 16 consecutive positions of ONE
+// tap.  Both operands want "8 consecutive reduction elements per lane", i.e. 8 consecutive POSITIONS of one channel,
+// while memory (and the staging loads) are position-contiguous per channel.  Both are therefore staged into
+// channel-innermost bf16 LDS images (rows = positions, columns = channels) and read back COLUMN-major with
+// ds_read_b64_tr_b16, the hardware transpose read: a tap is a ROW offset of the x image, so tap shifts, strides and
+// the [row][P] layout of the period discriminators never touch alignment.
+//   Ya [u (BU)][m (BM)]      row pitch BM*2 (+64 B pad)      Xb [x row (span)][c (BC)]    row pitch BC*2 (+64 B pad)
+// Pitch = 64 (mod 256) bytes: the 4 rows of a transpose-read block (consecutive, or 3 apart for the stride-3 period
+// convs) fall into different 64-byte quarters of the 256-byte bank row -> conflict-free, with plain linear addressing
+// (per-tap offsets are added to a per-lane base; no swizzle arithmetic in the loop).
+// Staging: a wave-instruction covers 16 positions x 32 channels (lane: position = lane >> 2, 8-channel group = lane & 3),
+// so the 8 lanes of a ds_write_b128 group write 8 distinct 16-byte slots; global reads are 64-byte runs.
+// Reduction split over grid.z; every block writes its partial tile to its own slab and wgrad_bf16_finish_kernel adds
+// the slabs in a fixed order: deterministic, no atomics.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+constexpr int BU = 64;
+
+struct WbGeom {
+  int nmt, nct, ntg;   // m tiles, c tiles, tap groups
+  int Z;               // reduction split (grid.z)
+  int nchunk_u;        // stages per batch element
+  int XR;              // staged x rows per stage (multiple of 16)
+  int pa, pb;          // row pitches (bytes) of the two images
+  int a_bytes, buf_bytes;
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+  // two transposed reads = the 8 reduction elements of one MFMA operand (rows 0-3 and 4-7 of the lane's half)
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(__attribute__((address_space(3))) void*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(__attribute__((address_space(3))) void*)p1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// WM x WC waves tile the (m, c) block, WU waves split the 16-position steps of a stage; each wave owns TM x 1 MFMA
+// tiles per tap and KT tap accumulators.
+template <int WM, int WC, int WU, int KT, int MAXT>
+__global__ void __launch_bounds__(64 * WM * WC * WU)
+wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ slab) {
+  constexpr int BM = 32 * WM, BC = 32 * WC, NW = WM * WC * WU;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wu = wave / (WM * WC), wmc = wave % (WM * WC);
+  const int wm = wmc / WC, wc = wmc % WC;
+  const int h = lane >> 5;
+
+  const int ct = blockIdx.x % tg.nct, tgi = blockIdx.x / tg.nct;
+  const int mt = blockIdx.y, z = blockIdx.z;
+  const int K = p.K, Cg = p.Cg, Mg = p.Mg, P = p.P;
+  const int k0 = tgi * KT;
+  const int kn = K - k0 < KT ? K - k0 : KT;  // taps of this block
+  const int m0 = mt * BM, c0 = ct * BC;
+  const int PA = tg.pa, PB = tg.pb;
+  // x rows staged per stage: taps k0 .. k0+kn-1 of positions uc0 .. uc0+BU-1
+  const int tap_lo = p.dj >= 0 ? k0 * p.dj : (k0 + kn - 1) * p.dj;  // smallest row offset of the block's taps
+
+  const long long U = (long long)p.Ta * P;
+  const long long TbP = (long long)p.Tb * P;
+  const int total = p.B * tg.nchunk_u;
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+
+  // staging tasks: (32-channel quad, 64-position block); A tasks first, then X tasks.  Lane: 8-channel group lane & 3,
+  // positions 4 * (lane >> 2) .. + 3 -> 8 x 16-byte loads (256-byte runs per 16 lanes), 4 x 16-byte LDS writes
+  const int nqa = BM / 32, nqb = BC / 32;
+  const int ntA = nqa * (BU / 64), ntB = nqb * (tg.XR / 64);
+  const int ntask = ntA + ntB;
+  const int lpq = lane >> 2, lg8 = lane & 3;
+  f32x4 xr[MAXT][8];
+
+  auto load = [&](int ch) {
+    const int b = ch / tg.nchunk_u;
+    const int uc0 = (ch - b * tg.nchunk_u) * BU;
+    const int qa = uc0 / P;
+    // first staged x position, rounded DOWN to a multiple of 4 so that a lane's 4-position vector is never partly
+    // negative (a negative offset puts the whole vector out of range); tab[] carries the remainder
+    const int f0 = ((qa * p.s + p.off + tap_lo) * P) & ~3;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int task = wave + t * NW;
+      if (task < ntask) {
+        const bool isA = task < ntA;
+        const int tt = isA ? task : task - ntA;
+        const int nq = isA ? nqa : nqb;
+        const int quad = tt % nq, pblk = tt / nq;
+        const int chan0 = (isA ? m0 : c0) + quad * 32;
+        const int climit = isA ? Mg : Cg;
+        const long long rowlen = isA ? U : TbP;
+        const float* base = isA ? p.a + (size_t)b * Mg * (size_t)U : p.b + (size_t)b * Cg * (size_t)TbP;
+        // one descriptor per task over the quad's 32 channel rows (wave-uniform); the lane's channel row goes into its
+        // offset.  Rows past the channel count fall outside the descriptor (-> 0); positions outside [0, rowlen) would
+        // read the neighbouring row, so they are masked per element.
+        const int pos0 = (isA ? uc0 : f0) + pblk * 64 + lpq * 4;
+        const int rows = climit - chan0 < 32 ? climit - chan0 : 32;
+        const unsigned rec = rows > 0 ? (unsigned)((long long)rows * rowlen * 4) : 0u;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)chan0 * (size_t)rowlen), 0, (int)rec, 0x00020000);
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ok[j] = pos0 + j >= 0 && pos0 + j < rowlen;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned voff = (unsigned)(((long long)(lg8 * 8 + e) * rowlen + pos0) * 4);
+          f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ok[j] ? v[j] : 0.f;
+          xr[t][e] = v;
+        }
+      }
+    }
+  };
+  auto store = [&](int buf) {
+    char* Ya = smem + buf * tg.buf_bytes;
+    char* Xb = Ya + tg.a_bytes;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int task = wave + t * NW;
+      if (task < ntask) {
+        const bool isA = task < ntA;
+        const int tt = isA ? task : task - ntA;
+        const int nq = isA ? nqa : nqb;
+        const int quad = tt % nq, pblk = tt / nq;
+        const bool lk = isA ? p.a_tf == VCV_TF_LEAKY : p.b_tf == VCV_TF_LEAKY;
+        char* img = isA ? Ya : Xb;
+        const int pitch = isA ? PA : PB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = xr[t][e][j];
+            if (lk) f = fmaxf(f, f * p.slope);
+            v[e] = (__bf16)f;
+          }
+          *reinterpret_cast<bf16x8*>(img + (size_t)(pblk * 64 + lpq * 4 + j) * pitch + (quad * 4 + lg8) * 16) = v;
+        }
+      }
+    }
+  };
+  // tab[u] = x row (relative to the staged span) that tap offset tap_lo of position u reads
+  auto build_tab = [&](int ch, int buf) {
+    int* tab = (int*)(smem + buf * tg.buf_bytes + tg.a_bytes + tg.XR * PB);
+    if (tid < BU) {
+      const int b = ch / tg.nchunk_u;
+      const int uc0 = (ch - b * tg.nchunk_u) * BU;
+      const int qa = uc0 / P;
+      const long long u = (long long)uc0 + tid;
+      const int fs = (qa * p.s + p.off + tap_lo) * P;
+      int t = fs - (fs & ~3);  // the span starts at a multiple of 4 (see load)
+      if (u < U) {
+        const int q = (int)(u / P), pc = (int)(u - (long long)q * P);
+        t += (q - qa) * p.s * P + pc;
+      }
+      tab[tid] = t * PB;
+    }
+  };
+
+  // per-lane constants of the transposed reads: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
+  const int li = lane & 15, lq = li >> 2, lp = li & 3, g1 = (lane >> 4) & 1;
+  const int colA = ((wm * 32 + 16 * g1 + 4 * lp) * 2);
+  const int colB = ((wc * 32 + 16 * g1 + 4 * lp) * 2);
+  const int rowl = 8 * h + lq;  // the lane's row inside a 16-position step (second read: + 4)
+
+  if (z < total) {
+    load(z);
+    store(0);
+    build_tab(z, 0);
+    __syncthreads();
+    int bufi = 0;
+    for (int ch = z; ch < total; ch += tg.Z) {
+      const bool more = ch + tg.Z < total;
+      if (more) load(ch + tg.Z);
+      const char* Ya = smem + bufi * tg.buf_bytes;
+      const char* Xb = Ya + tg.a_bytes;
+      const int* tab = (const int*)(Xb + tg.XR * PB);
+      for (int i16 = wu; i16 < BU / 16; i16 += WU) {
+        const int ur = i16 * 16 + rowl;
+        const bf16x8 a = tr_pair(Ya + (size_t)ur * PA + colA, Ya + (size_t)(ur + 4) * PA + colA);
+        const char* x0 = Xb + tab[ur] + colB;
+        const char* x1 = Xb + tab[ur + 4] + colB;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (k < kn) {
+            const int ro = ((k0 + k) * p.dj - tap_lo) * P * PB;
+            const bf16x8 bb = tr_pair(x0 + ro, x1 + ro);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[k], 0, 0, 0);
+          }
+        }
+      }
+      if (more) {
+        store(bufi ^ 1);
+        build_tab(ch + tg.Z, bufi ^ 1);
+      }
+      __syncthreads();
+      bufi ^= 1;
+    }
+  }
+
+  // cross-wave reduction over the WU position-split waves (through LDS, one round per extra wave)
+  if (WU > 1) {
+    float* red = (float*)smem;  // [WM*WC][KT][16][64]
+    for (int r = 1; r < WU; ++r) {
+      __syncthreads();
+      if (wu == r) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[((wmc * KT + k) * 16 + e) * 64 + lane] = acc[k][e];
+      }
+      __syncthreads();
+      if (wu == 0) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[k][e] += red[((wmc * KT + k) * 16 + e) * 64 + lane];
+      }
+    }
+    if (wu != 0) return;
+  }
+
+  // partial tile -> slab z:  slab[z][m][c][k]  (the dw layout)
+  const int N = Cg * K;
+  float* out = slab + (size_t)z * ((size_t)Mg * N);
+  const int c = c0 + wc * 32 + (lane & 31);
+  if (c < Cg) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k < kn) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ml = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (ml < Mg) out[(size_t)ml * N + (size_t)c * K + (k0 + k)] = acc[k][e];
+        }
+      }
+    }
+  }
+}
+
+// dw[i] += alpha * sum_z slab[z][i]   (fixed order: deterministic)
+__global__ void __launch_bounds__(256) wgrad_bf16_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                size_t n, int Z, float alpha) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = slab[i];
+  for (int z = 1; z < Z; ++z) s += slab[(size_t)z * n + i];
+  dw[i] += alpha * s;
+}
+
+constexpr int MAXT = 2;
+
+struct Cfg { int WM, WC, WU, KT; };
+
+bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds) {
+  const int BM = 32 * c.WM, BC = 32 * c.WC, NW = c.WM * c.WC * c.WU;
+  g.nmt = vcv_cdiv(a.Mg, BM);
+  g.nct = vcv_cdiv(a.Cg, BC);
+  g.ntg = vcv_cdiv(a.K, c.KT);
+  const int adj = a.dj < 0 ? -a.dj : a.dj;
+  const int qspan = (BU - 1) / a.P + 1;
+  const int kspan = (c.KT < a.K ? c.KT : a.K) - 1;
+  const int rowmax = (qspan * a.s + kspan * adj + 1) * a.P;
+  g.XR = (rowmax + 3 + 63) & ~63;  // + 3: the span start is rounded down to a multiple of 4
+  auto pitch = [](int w) { const int b = w * 2; return b >= 128 ? b + 64 : b; };
+  g.pa = pitch(BM);
+  g.pb = pitch(BC);
+  g.a_bytes = BU * g.pa;
+  g.buf_bytes = g.a_bytes + g.XR * g.pb + BU * 4;
+  lds = 2ull * g.buf_bytes;
+  const size_t red = c.WU > 1 ? (size_t)c.WM * c.WC * c.KT * 16 * 64 * 4 : 0;
+  if (red > lds) lds = red;
+  if (lds > VCV_LDS_LIMIT) return false;
+  const int ntask = (BM / 32) * (BU / 64) + (BC / 32) * (g.XR / 64);
+  if (ntask > MAXT * NW) return false;
+  const long long Uu = (long long)a.Ta * a.P;
+  g.nchunk_u = (int)((Uu + BU - 1) / BU);
+  return true;
+}
+
+template <int WM, int WC, int WU, int KT>
+int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, int64_t scratch_floats, hipStream_t st) {
+  WbGeom g = g0;
+  const long long total = (long long)a.B * g.nchunk_u;
+  const long long tiles = (long long)g.nmt * g.nct * g.ntg;
+  const long long occ = lds * 2 <= VCV_LDS_LIMIT ? 2 : 1;
+  const long long slots = 256 * occ;
+  const size_t n = (size_t)a.Mg * a.Cg * a.K;
+  long long Z = 1;
+  double best = 1e30;
+  for (long long z = 1; z <= total && z <= 512; ++z) {
+    if ((size_t)z * n > (size_t)scratch_floats) break;
+    const double rounds = (double)((tiles * z + slots - 1) / slots);
+    const double cost = rounds * ((double)((total + z - 1) / z) + 2.0) / (double)occ + 0.02 * z;  // + slab traffic
+    if (cost < best - 1e-9) best = cost, Z = z;
+  }
+  g.Z = (int)Z;
+  auto kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  dim3 grid(g.nct * g.ntg, g.nmt, g.Z), block(64 * WM * WC * WU);
+  const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
+  const int tag[12] = {a.B, 2, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, WM * 32 * 1000 + WC * 32, KT};
+  const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g, scratch);
+  hipLaunchKernelGGL(wgrad_bf16_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)scratch,
+                     a.dw, n, g.Z, a.alpha);
+  return vcv_check_launch();
+}
+
+bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds) {
+  const bool tf_ok = (a.a_tf == VCV_TF_NONE || a.a_tf == VCV_TF_LEAKY) && (a.b_tf == VCV_TF_NONE || a.b_tf == VCV_TF_LEAKY) &&
+                     a.slope >= 0.f && a.slope < 1.f;
+  const long long U = (long long)a.Ta * a.P;
+  if (a.G != 1 || !tf_ok || a.transpose_out || a.Mg < 32 || a.Cg < 16 || a.K > 16 || U * a.B < 256 || a.s < 1 || a.s > 3)
+    return false;
+  if (U * 4 >= (1ll << 31) || (long long)a.Tb * a.P * 4 >= (1ll << 31)) return false;
+  c.KT = a.K == 1 ? 1 : a.K <= 3 ? 3 : a.K <= 5 ? 5 : (a.K == 7 || a.K == 8 || a.K >= 15) ? 8 : 6;
+  // (WM, WC, WU) candidates, widest tile first; a candidate that does not fit the LDS / staging budget (long x spans of
+  // the wide-period layouts) falls through to a narrower channel tile
+  static const int cand[6][3] = {{4, 2, 1}, {4, 1, 2}, {2, 2, 2}, {2, 1, 4}, {1, 2, 4}, {1, 1, 8}};
+  for (int i = 0; i < 6; ++i) {
+    const int bm = 32 * cand[i][0], bc = 32 * cand[i][1];
+    if (bm > 32 && bm > a.Mg) continue;
+    if (bc > 32 && bc > ((a.Cg + 31) & ~31)) continue;
+    c.WM = cand[i][0]; c.WC = cand[i][1]; c.WU = cand[i][2];
+    if (geometry(a, c, g, lds)) return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+// Scratch floats the launch wants (0: not eligible -> the caller uses vcv_conv_wgrad).  The kernel takes any scratch
+// >= Mg*Cg*K floats and splits the reduction as far as the scratch allows.
+extern "C" int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* a) {
+  Cfg c;
+  WbGeom g;
+  size_t lds;
+  if (!a || !pick(*a, c, g, lds)) return 0;
+  const long long total = (long long)a->B * g.nchunk_u;
+  const long long tiles = (long long)g.nmt * g.nct * g.ntg;
+  long long z = (512 + tiles - 1) / tiles;
+  if (z > total) z = total;
+  if (z < 1) z = 1;
+  if (z > 64) z = 64;
+  return (int64_t)z * a->Mg * a->Cg * a->K;
+}
+
+#define WB_CASE(wm, wc, wu, kt) \
+  if (c.WM == wm && c.WC == wc && c.WU == wu && c.KT == kt) return launch<wm, wc, wu, kt>(*a, g, lds, scratch, scratch_floats, st)
+#define WB_KT(wm, wc, wu) WB_CASE(wm, wc, wu, 1); WB_CASE(wm, wc, wu, 3); WB_CASE(wm, wc, wu, 5); WB_CASE(wm, wc, wu, 6); WB_CASE(wm, wc, wu, 8)
+
+extern "C" int vcv_wgrad_bf16(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* stream) {
+  Cfg c;
+  WbGeom g;
+  size_t lds;
+  if (!a || !scratch || !pick(*a, c, g, lds)) return VCV_EINVAL;
+  if (scratch_floats < (int64_t)a->Mg * a->Cg * a->K) return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  WB_KT(4, 2, 1);
+  WB_KT(4, 1, 2);
+  WB_KT(2, 2, 2);
+  WB_KT(2, 1, 4);
+  WB_KT(1, 2, 4);
+  WB_KT(1, 1, 8);
+  return VCV_EINVAL;
+}

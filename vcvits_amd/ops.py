@@ -46,6 +46,10 @@ _USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
 _COMPUTE = ["f32"]
 
 
+# which kernel family each GEMM-shaped launch went to (tests assert that the bf16 path really ran)
+LAUNCH_COUNTS = {"bf16": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad": 0}
+
+
 def set_compute_dtype(name):
     if name not in ("f32", "bf16"):
         raise ValueError("compute dtype must be 'f32' or 'bf16'")
@@ -57,11 +61,11 @@ def compute_dtype():
 
 
 def _launch_conv(a, flip_w=None):
-    """Forward-type launches go to the LDS-DMA kernel when it is eligible (vcv_conv_dma_plan succeeds),
-    everything else to the register-staged kernel.  flip_w: original [C, M, K] weight of a stride-1 data
-    gradient (the DMA pack flips it; the register path needs the explicit flipped copy in a.w).
-    Packed weights of tensors inside a cached weight-norm buffer (see _WeightNormManyFn) are kept with that
-    buffer and reused until its parameters change."""
+    """Forward-type launches go to the packed-weight kernels when one is eligible -- the bf16-operand kernel
+    (vcv_conv_bf16_*) under set_compute_dtype("bf16"), else the fp32 LDS-DMA kernel (vcv_conv_dma_*) -- everything else to
+    the register-staged fp32 kernel.  flip_w: original [C, M, K] weight of a stride-1 data gradient (the pack flips it;
+    the register path needs the explicit flipped copy in a.w).  Packed weights of tensors inside a cached weight-norm
+    buffer (see _WeightNormManyFn) are kept with that buffer and reused until its parameters change."""
     if _USE_DMA[0] and (a.a_mode == 0 or (a.a_mode == 1 and a.phases > 1)):
         L = lib()
         if flip_w is not None:
@@ -69,7 +73,11 @@ def _launch_conv(a, flip_w=None):
             a.w = ptr(flip_w)
         flip = 1 if flip_w is not None else 0
         plan = (ctypes.c_int64 * 3)()
-        if L.vcv_conv_dma_plan(ctypes.byref(a), flip, plan) == 0:
+        families = ((L.vcv_conv_bf16_plan, L.vcv_conv_bf16_run, "vcv_conv_bf16_run"),) if _COMPUTE[0] == "bf16" else ()
+        families += ((L.vcv_conv_dma_plan, L.vcv_conv_dma_run, "vcv_conv_dma_run"),)
+        for plan_fn, run_fn, name in families:
+            if plan_fn(ctypes.byref(a), flip, plan) != 0:
+                continue
             dev = torch.device("cuda", torch.cuda.current_device())
             packs = _stable_packs(a.w)
             key = (a.w, plan[0], plan[2])
@@ -80,14 +88,25 @@ def _launch_conv(a, flip_w=None):
                 if packs is not None:
                     packs[key] = pack
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
-            check(L.vcv_conv_dma_run(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), "vcv_conv_dma_run")
+            check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
+            LAUNCH_COUNTS["bf16" if name == "vcv_conv_bf16_run" else "dma"] += 1
             return
         if flip_w is not None:
             a.w = saved
+    LAUNCH_COUNTS["gemm"] += 1
     check(lib().vcv_conv_gemm(ctypes.byref(a), stream()), "vcv_conv_gemm")
 
 
 def _launch_wgrad(a):
+    if _COMPUTE[0] == "bf16":
+        L = lib()
+        n = L.vcv_wgrad_bf16_scratch(ctypes.byref(a))
+        if n > 0:
+            scratch = torch.empty((n,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+            check(L.vcv_wgrad_bf16(ctypes.byref(a), ptr(scratch), n, stream()), "vcv_wgrad_bf16")
+            LAUNCH_COUNTS["wgrad_bf16"] += 1
+            return
+    LAUNCH_COUNTS["wgrad"] += 1
     check(lib().vcv_conv_wgrad(ctypes.byref(a), stream()), "vcv_conv_wgrad")
 
 
@@ -175,7 +194,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = 1, dil, pad - (K - 1) * dil, 1, 0, 1, Tin, 0
         _common(a, **kw)
         a.w = ptr(w)
-        if _USE_DMA[0] and lib().vcv_conv_dma_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0:
+        if _USE_DMA[0] and ((_COMPUTE[0] == "bf16" and lib().vcv_conv_bf16_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0)
+                            or lib().vcv_conv_dma_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0):
             _launch_conv(a, flip_w=w)
             return out
         wt = torch.empty((C, M, K), device=dy.device, dtype=torch.float32)
