@@ -140,6 +140,9 @@ typedef struct VcvWgradArgs {
   int32_t a_tf, b_tf;
   int32_t transpose_out; /* 1: write dw[(g*Cg + c), m, k] instead (Conv weight from ConvT roles) */
   float alpha, slope;
+  float* dbias;       /* [G*Mg] or NULL: db[m] += sum_{b, q, p} a[b, m, q, p] -- the bias gradient of a Conv, whose
+                         un-shifted operand IS dy: the row sums are collected while the kernel stages `a` (needs a_tf ==
+                         NONE); replaces a separate vcv_bias_grad pass over dy */
 } VcvWgradArgs;
 
 int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
@@ -214,6 +217,9 @@ int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, vo
 /* out = dy * act'(y) for tf in {DLEAKY, DRELU, DTANH, DLOGCLAMP}: one pass that the data-, weight- and
  * bias-gradient kernels of a fused conv+activation then share */
 int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream);
+/* the same pass over [B, C, T] tensors that also collects the bias gradient: dbias[c] += sum_{b, t} out[b, c, t] */
+int vcv_act_grad_bias(const float* dy, const float* y, float* out, float* dbias, int B, int C, int T, int tf, float slope,
+                      void* stream);
 
 /* ---- streaming helpers ---- */
 /* y = (a + b + c) / 3 : mean of the three ResBlock1 branches of a HiFi-GAN stage */

@@ -370,9 +370,15 @@ extern "C" int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int N = a.Cg * a.K;
   static const bool use_dma = !(getenv("VCVITS_WGRAD_DMA") && getenv("VCVITS_WGRAD_DMA")[0] == '0');
+  if (a.dbias && (a.a_tf != VCV_TF_NONE || a.G != 1)) return VCV_EINVAL;
   if (use_dma) {
     const int rcd = vcv_wgrad_dma_try(a, st);
     if (rcd != VCV_ENOFIT) return rcd;
+  }
+  if (a.dbias) {
+    // the register-staged kernel does not collect the row sums: one streaming pass over `a`
+    const int rb = vcv_bias_grad(a.a, nullptr, a.dbias, a.B, a.Mg, a.Ta * a.P, VCV_TF_NONE, a.slope, 1, stream);
+    if (rb != VCV_OK) return rb;
   }
   int rc = VCV_ENOFIT;
   if (a.Mg > 64) {

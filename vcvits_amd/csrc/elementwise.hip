@@ -130,6 +130,38 @@ __global__ void act_grad_kernel(const float* __restrict__ dy, const float* __res
   if (i < n) out[i] = vcv_tf(dy[i], tf, y, i, slope);
 }
 
+// act_grad over [B, C, T] rows that also collects db[c] += sum_{b, t} out[b, c, t]: work units are 1024-float pieces of
+// the contiguous (b, c) rows (as bias_grad_kernel in conv_wgrad.hip); one atomic per (channel, segment)
+__global__ void __launch_bounds__(256)
+act_grad_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                     float* __restrict__ db, int B, int C, int T, int tf, float slope, int nseg) {
+  const int c = blockIdx.x, seg = blockIdx.y;
+  const int nchunk = (T + 1023) >> 10;
+  const int units = B * nchunk;
+  const int per = (units + nseg - 1) / nseg;
+  const int lo = seg * per;
+  const int hi = lo + per < units ? lo + per : units;
+  float s = 0.f;
+  for (int unit = lo; unit < hi; ++unit) {
+    const int b = unit / nchunk, ch = unit - b * nchunk;
+    const size_t row = ((size_t)b * C + c) * (size_t)T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = (ch << 10) + k * 256 + threadIdx.x;
+      if (t < T) {
+        const float v = vcv_tf(dy[row + t], tf, y, row + t, slope);
+        out[row + t] = v;
+        s += v;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(db + c, red[0] + red[1] + red[2] + red[3]);
+}
+
 // y[b, c, t] = x[b, c, t] * mask[b, t]
 __global__ void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                 float* __restrict__ y, int C, int T, size_t n) {
@@ -348,6 +380,18 @@ extern "C" int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C
 extern "C" int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream) {
   if (!dy || !y || !out || n <= 0 || tf < VCV_TF_DLEAKY) return VCV_EINVAL;
   hipLaunchKernelGGL(act_grad_kernel, grid1d(n), dim3(256), 0, ST, dy, y, out, tf, slope, (size_t)n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_act_grad_bias(const float* dy, const float* y, float* out, float* dbias, int B, int C, int T, int tf,
+                                 float slope, void* stream) {
+  if (!dy || !y || !out || !dbias || B <= 0 || C <= 0 || T <= 0 || tf < VCV_TF_DLEAKY) return VCV_EINVAL;
+  const long long units = (long long)B * ((T + 1023) / 1024);
+  long long nseg = (2048 + C - 1) / C;
+  if (nseg > units) nseg = units;
+  if (nseg < 1) nseg = 1;
+  hipLaunchKernelGGL(act_grad_bias_kernel, dim3(C, (unsigned)nseg), dim3(256), 0, ST, dy, y, out, dbias, B, C, T, tf, slope,
+                     (int)nseg);
   return vcv_check_launch();
 }
 

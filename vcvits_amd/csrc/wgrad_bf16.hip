@@ -127,9 +127,19 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
       }
     }
   };
+  // bias gradient (p.dbias): row sums of `a`, taken from the fp32 staging registers of the A tasks by the blocks of the
+  // first (channel tile, tap group); an A task = one 32-channel quad, always staged by the same wave (t == 0)
+  const bool do_bias = p.dbias != nullptr && blockIdx.x == 0 && wave < ntA;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
   auto store = [&](int buf) {
     char* Ya = smem + buf * tg.buf_bytes;
     char* Xb = Ya + tg.a_bytes;
+    if (do_bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum[e] += (xr[0][e][0] + xr[0][e][1]) + (xr[0][e][2] + xr[0][e][3]);
+    }
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int task = wave + t * NW;
@@ -211,6 +221,17 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
       }
       __syncthreads();
       bufi ^= 1;
+    }
+  }
+
+  if (do_bias) {
+    // lanes with the same lane & 3 hold the same 8 channels (different positions): reduce over lane bits 2..5
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = bsum[e];
+      v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      const int ml = m0 + wave * 32 + lg8 * 8 + e;
+      if (lpq == 0 && ml < Mg) unsafeAtomicAdd(p.dbias + ml, v);
     }
   }
 

@@ -21,7 +21,7 @@ struct WgGeom {
   int NCH, nXrow, XP, nmt, nnt, Z, nchunk_u, buf_floats, a_floats;
 };
 
-template <int TM, int TN, int WM, int WN, bool LA, bool LB>
+template <int TM, int TN, int WM, int WN, bool LA, bool LB, bool BIAS>
 __global__ void __launch_bounds__(64 * WM * WN)
 wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
@@ -59,6 +59,12 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+  // bias gradient = row sums of the un-shifted operand: collected by the first column tile's first wave column from
+  // the A fragments it reads anyway (p.dbias, see include/vcvits_hip.h)
+  const bool do_bias = BIAS && nt == 0 && wn == 0;
+  float bsum[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) bsum[tm] = 0.f;
 
   auto issue = [&](int ch, int buf) {
     float* As = smem + buf * tg.buf_floats;
@@ -114,6 +120,7 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
           float v = As[((wm * TM + tm) * 32 + l31) * AP + ul];
           if (LA) v = fmaxf(v, v * p.slope);
           a[tm] = v;
+          if (BIAS && do_bias) bsum[tm] += v;
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -131,6 +138,14 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
     }
   }
 
+  if (do_bias) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float s2 = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);  // the two position parities of the lane halves
+      const int ml = m0 + (wm * TM + tm) * 32 + l31;
+      if (h == 0 && ml < Mg) unsafeAtomicAdd(p.dbias + ml, s2);
+    }
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + (wn * TN + tn) * 32 + l31;
@@ -183,9 +198,11 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
   }
   g.Z = (int)Z;
   const bool la = a.a_tf == VCV_TF_LEAKY, lb = a.b_tf == VCV_TF_LEAKY;
+  // the bias-collecting variant exists for the transform-free `a` operand only (a Conv's dy)
   void (*kern)(const VcvWgradArgs, const WgGeom) =
-      la ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, true, true> : wgrad_dma_kernel<TM, TN, WM, WN, true, false>)
-         : (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true> : wgrad_dma_kernel<TM, TN, WM, WN, false, false>);
+      la ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, true, true, false> : wgrad_dma_kernel<TM, TN, WM, WN, true, false, false>)
+         : (a.dbias ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, true> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, true>)
+                    : (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, false> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, false>));
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VCV_EHIP;
   dim3 grid(g.nnt, g.nmt, g.Z), block(NT);

@@ -255,13 +255,18 @@ def _wgrad_zeros(shape, dev, arena):
 
 
 def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=TF_NONE, aaux=None,
-               b_tf=TF_NONE, baux=None, alpha=1.0, slope=0.1, arena=False):
-    """Weight gradient of conv_forward (accumulates onto `out` when given, else onto zeros)."""
+               b_tf=TF_NONE, baux=None, alpha=1.0, slope=0.1, arena=False, dbias=None):
+    """Weight gradient of conv_forward (accumulates onto `out` when given, else onto zeros).  dbias [M]: the bias
+    gradient sum(dy) is ADDED onto it -- inside the weight-gradient launch where the kernel supports it (the MFMA
+    kernels collect the row sums of dy while staging it), by one extra streaming pass otherwise."""
     B, M, Tout, P = _rows(dy)
     _, C, Tin, _ = _rows(x)
     Cg, K = w_shape[1], w_shape[2]
     if out is None:
         out = _wgrad_zeros(w_shape, dy.device, arena)
+    if dbias is not None and (a_tf != TF_NONE or groups != 1 or min(M, C) == 1):
+        bias_grad(dy, aux=aaux, tf=a_tf, slope=slope, out=dbias)
+        dbias = None
     if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
             and M // groups in (4, 16) and b_tf == TF_NONE and a_tf in (TF_NONE, TF_DLEAKY) and alpha == 1.0):
         check(lib().vcv_grouped41_wgrad(ptr(dy), ptr(aaux), ptr(x), ptr(out), B, groups, M // groups, Tin, Tout, a_tf,
@@ -277,6 +282,7 @@ def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=
     a.Ta, a.Tb, a.P, a.K = Tout, Tin, P, K
     a.s, a.dj, a.off = stride, dil, -pad
     a.a_tf, a.b_tf, a.transpose_out, a.alpha, a.slope = a_tf, b_tf, 0, alpha, slope
+    a.dbias = ptr(dbias)
     _launch_wgrad(a)
     return out
 
@@ -521,13 +527,22 @@ class _ConvFn(torch.autograd.Function):
             link_dres, ctx.link[0].dres = ctx.link[0].dres, None
         dtf = _ACT_TO_DTF[out_act]
         dx = dw = db = dres = None
+        db_done = None  # the bias gradient, once some launch has produced it
         w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
         if dtf != TF_NONE:
             # apply the activation-derivative mask once; dgrad / wgrad / bias-grad then stream dye
             b0 = ctx.b0 if (0 < ctx.b0 < x.shape[0] and not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])) else 0
             dye = torch.empty_like(dy)
-            check(lib().vcv_act_grad(ptr(dy[b0:]), ptr(y[b0:]), ptr(dye[b0:]), dtf, slope, dy[b0:].numel(), stream()),
-                  "vcv_act_grad")
+            if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.bt:
+                # the same pass collects the bias gradient (sum of the masked gradient per channel)
+                db_done = ctx.b_sink[0] if ctx.b_sink is not None else torch.zeros((dy.shape[1],), device=dy.device,
+                                                                                    dtype=torch.float32)
+                check(lib().vcv_act_grad_bias(ptr(dy), ptr(y), ptr(dye), ptr(db_done), dy.shape[0], dy.shape[1],
+                                              dy.numel() // (dy.shape[0] * dy.shape[1]), dtf, slope, stream()),
+                      "vcv_act_grad_bias")
+            else:
+                check(lib().vcv_act_grad(ptr(dy[b0:]), ptr(y[b0:]), ptr(dye[b0:]), dtf, slope, dy[b0:].numel(), stream()),
+                      "vcv_act_grad")
             dy, y, dtf = dye, None, TF_NONE
         if ctx.bt:
             # x was saved in the folded layout; fold dy the same way, unfold dx
@@ -581,12 +596,22 @@ class _ConvFn(torch.autograd.Function):
                 dw = convT_wgrad(dy, x, w3.shape, stride=stride, pad=pad, a_tf=b_tf, b_tf=dtf,
                                  baux=y, slope=slope, out=wout, arena=ctx.w_tmp)
             else:
-                dw = conv_wgrad(dy, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
-                                a_tf=dtf, aaux=y, b_tf=b_tf, slope=slope, out=wout, arena=ctx.w_tmp)
+                if ctx.has_bias and ctx.needs_input_grad[2] and db_done is None:
+                    # the weight-gradient launch collects sum(dy) while it stages dy
+                    db_done = ctx.b_sink[0] if ctx.b_sink is not None else torch.zeros((dy.shape[1],), device=dy.device,
+                                                                                        dtype=torch.float32)
+                    dw = conv_wgrad(dy, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups, a_tf=dtf, aaux=y,
+                                    b_tf=b_tf, slope=slope, out=wout, arena=ctx.w_tmp, dbias=db_done)
+                else:
+                    dw = conv_wgrad(dy, x, w3.shape, stride=stride, pad=pad, dil=dil, groups=groups,
+                                    a_tf=dtf, aaux=y, b_tf=b_tf, slope=slope, out=wout, arena=ctx.w_tmp)
             dw = _sunk(ctx.w_sink, dw.view(w.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _sunk(ctx.b_sink, bias_grad(dy, aux=y, tf=dtf, slope=slope,
-                                             out=ctx.b_sink[0] if ctx.b_sink is not None else None))
+            if db_done is not None:
+                db = _sunk(ctx.b_sink, db_done)
+            else:
+                db = _sunk(ctx.b_sink, bias_grad(dy, aux=y, tf=dtf, slope=slope,
+                                                 out=ctx.b_sink[0] if ctx.b_sink is not None else None))
         if link_dres is not None:  # not consumed by a fused launch above (no data gradient wanted / transposed)
             dx = link_dres if dx is None else dx.add_(link_dres)
         if ctx.has_res and ctx.needs_input_grad[3]:
