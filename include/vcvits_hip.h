@@ -143,6 +143,10 @@ typedef struct VcvWgradArgs {
   float* dbias;       /* [G*Mg] or NULL: db[m] += sum_{b, q, p} a[b, m, q, p] -- the bias gradient of a Conv, whose
                          un-shifted operand IS dy: the row sums are collected while the kernel stages `a` (needs a_tf ==
                          NONE); replaces a separate vcv_bias_grad pass over dy */
+  float* slab;        /* NULL: the workgroups that split the (batch, position) reduction combine with fp32 atomics
+                         (summation order varies from run to run).  Non-NULL: each writes its partial tile to its own
+                         slab of Mg*Cg*K floats and a finishing pass adds the slabs in a fixed order -- bit-reproducible */
+  int64_t slab_floats; /* capacity of `slab`; the split is limited to slab_floats / (Mg*Cg*K) ways */
 } VcvWgradArgs;
 
 int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);

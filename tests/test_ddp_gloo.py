@@ -65,3 +65,117 @@ def test_bucketed_allreduce_matches_global_batch_gradient():
     loss.backward()
     ref = torch.cat([p.grad.reshape(-1) for p in reversed(list(net.parameters()))])
     assert torch.allclose(g0, ref, atol=1e-6, rtol=1e-5)
+
+
+# ---- model-level path: gradient sinks (kernels add into the flat buffer and hand autograd None), frozen parameters,
+# ---- buckets that never complete, per-parameter "touched" tracking -- on 2 ranks ---------------------------------------
+class _SinkLinear(torch.autograd.Function):
+    """y = x @ w.T + b the way the HIP conv ops treat parameters: when the optimizer registered a gradient sink the
+    backward ADDS the parameter gradient into it and returns None (ops._sink / ops._sunk), else it returns the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from vcvits_amd import ops
+        ctx.save_for_backward(x, w)
+        ctx.w_sink, ctx.b_sink = ops._sink(w), ops._sink(b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        from vcvits_amd import ops
+        x, w = ctx.saved_tensors
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = dy.t() @ x
+            if ctx.w_sink is not None:
+                ctx.w_sink[0].add_(dw)
+            dw = ops._sunk(ctx.w_sink, dw)
+        if ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+            if ctx.b_sink is not None:
+                ctx.b_sink[0].add_(db)
+            db = ops._sunk(ctx.b_sink, db)
+        return dx, dw, db
+
+
+def _make_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(16, 8), (16,), (12, 16), (12,), (4, 12), (4,), (5, 4), (5,)]  # last pair = an unused head
+    return [torch.nn.Parameter(torch.randn(s, generator=g) * 0.3) for s in shapes]
+
+
+def _forward(ps, x):
+    h = torch.tanh(_SinkLinear.apply(x, ps[0], ps[1]))
+    h = torch.tanh(_SinkLinear.apply(h, ps[2], ps[3]))
+    return _SinkLinear.apply(h, ps[4], ps[5])  # ps[6], ps[7] never take part (cf. Generator.cond on the SVC path)
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcvits_amd import ops
+    from vcvits_amd.light.optim import FlatAdamW
+    ps = _make_params(0)
+    opt = FlatAdamW(ps, 1e-2, bucket_mb=0.0003)
+    for p in opt.params:  # FlatAdamW registers sinks for GPU parameters; same mechanism on CPU tensors here
+        ops.register_grad_sink(p, p.grad)
+    assert len(opt._buckets) >= 3
+    order = []
+    orig = opt._launch_bucket
+
+    def rec(b):
+        order.append(b["lo"])
+        return orig(b)
+    opt._launch_bucket = rec
+    g = torch.Generator().manual_seed(200 + rank)
+    x, y = torch.randn(6, 8, generator=g), torch.randn(6, 4, generator=g)
+    results = []
+    for frozen in (False, True):  # second pass: the first layer is frozen (toggle_optimizer-style)
+        ps[0].requires_grad_(not frozen)
+        ps[1].requires_grad_(not frozen)
+        opt.zero_grad()
+        ((_forward(ps, x) - y) ** 2).mean().backward()
+        opt.finish_grad_sync()  # buckets holding untouched parameters are reduced here, in the same order on every rank
+        results.append((opt.grad.clone(), bytes(opt._touched)))
+    ps[0].requires_grad_(True)
+    ps[1].requires_grad_(True)
+    out[rank] = (results, order)
+    dist.barrier()
+    ops.clear_grad_sinks()
+    dist.destroy_process_group()
+
+
+def test_sinks_frozen_and_unused_parameters_two_ranks():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sink_worker, args=(world, port, out), nprocs=world, join=True)
+    (res0, order0), (res1, order1) = out[0], out[1]
+    assert order0 == order1 and len(order0) >= 6  # identical collective sequence on both ranks, every bucket in every pass
+    for (g0, t0), (g1, t1) in zip(res0, res1):
+        assert torch.equal(g0, g1) and t0 == t1
+    # reference: plain autograd on the union batch
+    for pass_idx, frozen in enumerate((False, True)):
+        ps = _make_params(0)
+        xs, ys = [], []
+        for rank in range(world):
+            g = torch.Generator().manual_seed(200 + rank)
+            xs.append(torch.randn(6, 8, generator=g))
+            ys.append(torch.randn(6, 4, generator=g))
+        x, y = torch.cat(xs), torch.cat(ys)
+        h = torch.tanh(x @ ps[0].t() + ps[1])
+        h = torch.tanh(h @ ps[2].t() + ps[3])
+        ((h @ ps[4].t() + ps[5] - y) ** 2).mean().backward()
+        ref = []
+        for i, p in enumerate(reversed(ps)):  # FlatAdamW lays parameters out in reverse registration order
+            idx = len(ps) - 1 - i
+            dead = idx >= 6 or (frozen and idx < 2)
+            ref.append(torch.zeros(p.numel()) if dead or p.grad is None else p.grad.reshape(-1))
+        ref = torch.cat(ref)
+        assert torch.allclose(res0[pass_idx][0], ref, atol=1e-6, rtol=1e-5), pass_idx
+        touched = res0[pass_idx][1]
+        # reversed order: [unused b, unused w, b3, w3, b2, w2, b1, w1]
+        assert list(touched) == [0, 0, 1, 1, 1, 1, 0 if frozen else 1, 0 if frozen else 1]

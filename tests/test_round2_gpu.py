@@ -97,3 +97,26 @@ def test_prior_sample(gpu):
     from vcvits_amd import ops
     m, l, n = (torch.randn(2, 8, 50, device=gpu) for _ in range(3))
     close("prior", ops.prior_sample(m, l, n, 0.667), m + n * torch.exp(l) * 0.667, tol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(8, 1024, 1024, 16, 13, 5, 1), (8, 128, 512, 141, 13, 5, 3), (4, 64, 64, 4096, 1, 11, 1)])
+def test_weight_gradient_is_bit_reproducible(gpu, shape):
+    """the split (batch, position) reduction of the MFMA weight-gradient kernel is combined through
+    per-workgroup slabs added in a fixed order (VcvWgradArgs.slab), not fp32 atomics: two identical launches give
+    identical bits -- and the atomics mode still gives the same numbers up to summation order."""
+    from vcvits_amd import ops
+    B, C, M, T, P, K, s = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((B, C, T, P) if P > 1 else (B, C, T), generator=g).to(gpu)
+    Tout = (T + 4 - K) // s + 1 if P > 1 else T
+    dy = torch.randn((B, M, Tout, P) if P > 1 else (B, M, Tout), generator=g).to(gpu)
+    pad = 2 if P > 1 else (K - 1) // 2
+    runs = []
+    for det in (True, True, False):
+        ops.set_deterministic(det)
+        try:
+            runs.append(ops.conv_wgrad(dy, x, (M, C, K), stride=s, pad=pad).clone())
+        finally:
+            ops.set_deterministic(True)
+    assert torch.equal(runs[0], runs[1])
+    close("atomics vs slabs", runs[2], runs[0], tol=2e-5)

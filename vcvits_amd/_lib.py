@@ -46,6 +46,7 @@ class VcvWgradArgs(ctypes.Structure):
         ("transpose_out", _i32),
         ("alpha", ctypes.c_float), ("slope", ctypes.c_float),
         ("dbias", _f32p),
+        ("slab", _f32p), ("slab_floats", ctypes.c_int64),
     ]
 
 

@@ -156,10 +156,21 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
       for (int e = 0; e < 16; ++e) {
         const int ml = m0 + (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (ml >= Mg) continue;
-        unsafeAtomicAdd(p.dw + (size_t)ml * N + n, p.alpha * acc[tm][tn][e]);
+        if (p.slab) p.slab[(size_t)z * Mg * N + (size_t)ml * N + n] = acc[tm][tn][e];
+        else unsafeAtomicAdd(p.dw + (size_t)ml * N + n, p.alpha * acc[tm][tn][e]);
       }
     }
   }
+}
+
+// dw[i] += alpha * sum_z slab[z][i] in a fixed order (the deterministic combine of a split reduction)
+__global__ void __launch_bounds__(256) wgrad_slab_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                size_t n, int Z, float alpha) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = slab[i];
+  for (int z = 1; z < Z; ++z) s += slab[(size_t)z * n + i];
+  dw[i] += alpha * s;
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -191,7 +202,10 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
   const long long slots = 256 * occ;
   long long Z = 1;
   double best = 1e30;
-  for (long long z = 1; z <= total && z <= 1024; ++z) {
+  const size_t nw = (size_t)a.Mg * N;
+  const long long zcap = a.slab ? (long long)(a.slab_floats / (int64_t)nw) : 1024;
+  if (a.slab && zcap < 1) return VCV_EINVAL;
+  for (long long z = 1; z <= total && z <= 1024 && z <= zcap; ++z) {
     const double rounds = (double)((tiles * z + slots - 1) / slots);
     const double cost = rounds * ((double)((total + z - 1) / z) + 2.0) / (double)occ;
     if (cost < best - 1e-9) best = cost, Z = z;
@@ -212,6 +226,9 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g);
+  if (a.slab)
+    hipLaunchKernelGGL(wgrad_slab_finish_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)a.slab, a.dw,
+                       nw, g.Z, a.alpha);
   return vcv_check_launch();
 }
 

@@ -33,16 +33,53 @@ def prepare_weight_norm(root, skip=()):
         excluded = set()
         for sm in skip:
             excluded.update(id(m) for m in sm.modules())
-        mods = [m for m in root.modules() if isinstance(m, (Conv, ConvT)) and m.is_wn and id(m) not in excluded]
+        named = [(n, m) for n, m in root.named_modules() if isinstance(m, (Conv, ConvT)) and m.is_wn and id(m) not in excluded]
+        mods = [m for _, m in named]
         root.__dict__[key] = mods
+        # backward granularity: consecutive layers of one sub-block ("discriminators.3", "resblocks.7", "ups.1") share
+        # an autograd node, so their parameter gradients -- and the data-parallel buckets they fill -- are final as
+        # soon as THAT block's backward is done (ops._WeightNormManyFn)
+        sizes, last = [], None
+        for n, _ in named:
+            parts = n.split(".")
+            k = ".".join(parts[:2]) if parts[0] in ("discriminators", "resblocks", "ups") else ""
+            if k == last:
+                sizes[-1] += 1
+            else:
+                sizes.append(1)
+                last = k
+        root.__dict__[key + "_groups"] = sizes
     if len(mods) < 2 or not mods[0].weight_v.is_cuda:
         return
-    ws = ops.weight_norm_many([m.weight_v for m in mods], [m.weight_g for m in mods])
-    for m, w in zip(mods, ws):
-        m._w_pre = (w, m.weight_v._version, m.weight_g._version, m.weight_v.data_ptr())
+    # one forward launch for the whole tree now; the autograd node of each group is created when the group's first
+    # layer runs (_take_prepared), i.e. at that sub-block's place in the backward schedule
+    holder = ops.weight_norm_forward([m.weight_v for m in mods], [m.weight_g for m in mods])
+    i0 = 0
+    for k in root.__dict__[key + "_groups"]:
+        group = mods[i0:i0 + k]
+        lazy = (holder, i0, i0 + k, group, [(m.weight_v._version, m.weight_g._version, m.weight_v.data_ptr()) for m in group],
+                ops.WEIGHT_EPOCH[0])
+        for m in group:
+            m.__dict__.pop("_w_pre", None)
+            m._w_lazy = lazy
+        i0 += k
+
+
+def _materialise_group(lazy):
+    holder, i0, i1, group, stamps, epoch = lazy
+    fresh = epoch == ops.WEIGHT_EPOCH[0]  # no raw write into parameter storage since the forward launch
+    ws = ops.weight_norm_group(holder, i0, i1, [m.weight_v for m in group], [m.weight_g for m in group]) if fresh else None
+    for i, m in enumerate(group):
+        if m.__dict__.get("_w_lazy") is lazy:
+            del m.__dict__["_w_lazy"]
+            if fresh:
+                m._w_pre = (ws[i],) + stamps[i]  # validated against the parameter versions of the forward launch
 
 
 def _take_prepared(m):
+    lazy = m.__dict__.get("_w_lazy")
+    if lazy is not None:
+        _materialise_group(lazy)
     pre = m.__dict__.pop("_w_pre", None)
     if pre is not None and pre[1] == m.weight_v._version and pre[2] == m.weight_g._version \
             and pre[3] == m.weight_v.data_ptr():

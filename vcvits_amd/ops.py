@@ -97,7 +97,21 @@ def _launch_conv(a, flip_w=None):
     check(lib().vcv_conv_gemm(ctypes.byref(a), stream()), "vcv_conv_gemm")
 
 
+# Combine of the split weight-gradient reductions: True = per-workgroup slabs added in a fixed order (bit-reproducible),
+# False (default: ~2 % faster per step) = fp32 atomics (order varies from run to run).  The bf16 kernel always uses slabs.
+_DETERMINISTIC = [__import__("os").environ.get("VCVITS_DETERMINISTIC", "0") == "1"]
+
+
+def set_deterministic(on):
+    _DETERMINISTIC[0] = bool(on)
+
+
 def _launch_wgrad(a):
+    if _DETERMINISTIC[0] and a.G == 1:
+        nw = a.Mg * a.Cg * a.K
+        n = min(nw * 512, max(nw * 4, 24 << 20))
+        slab = torch.empty((n,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+        a.slab, a.slab_floats = ptr(slab), n
     if _COMPUTE[0] == "bf16":
         L = lib()
         n = L.vcv_wgrad_bf16_scratch(ctypes.byref(a))
@@ -728,8 +742,14 @@ _WN_CACHE = {}
 _WN_CACHE_ON = [__import__("os").environ.get("VCVITS_WEIGHT_CACHE", "1") == "1"]
 
 
+# bumped by every raw write into parameter storage: weights handed to layers before it (modules._w_pre / _w_lazy) are
+# stale afterwards even though no torch version counter moved
+WEIGHT_EPOCH = [0]
+
+
 def invalidate_weights(lo=None, hi=None):
     """Parameters stored in [lo, hi) (all parameters when None) were modified behind torch's back."""
+    WEIGHT_EPOCH[0] += 1
     if lo is None:
         _WN_CACHE.clear()
         return
@@ -747,61 +767,83 @@ def _stable_packs(w_ptr):
     return None
 
 
+class _WnHolder:
+    """Result of one batched weight-norm forward launch: the buffer all effective weights live in, the row norms and the
+    host copy of the launch table (one row per (v, g) pair: v, g, w offset, first row, rows, row length, ...)."""
+    __slots__ = ("wbuf", "norm", "tab", "total", "rows")
+
+
+def _wn_forward_all(vg, n):
+    """Batched forward (no autograd), cached per parameter set until a parameter changes."""
+    vs, gs = vg[:n], vg[n:]
+    for t in vg:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("weight_norm_many: parameters must be contiguous fp32")
+    dev = vs[0].device
+    key = tuple(t.data_ptr() for t in vg)
+    ent = _WN_TABLES.get(key)
+    if ent is None:
+        import numpy as np
+        tab = np.zeros((n, 10), dtype=np.int64)
+        woff = row0 = 0
+        for i, (v, g) in enumerate(zip(vs, gs)):
+            R = v.shape[0]
+            C = v.numel() // R
+            tab[i, :6] = (v.data_ptr(), g.data_ptr(), woff, row0, R, C)
+            woff += R * C
+            row0 += R
+        ent = (tab, torch.from_numpy(tab).to(dev), woff, row0)
+        if len(_WN_TABLES) > 256:
+            _WN_TABLES.clear()
+        _WN_TABLES[key] = ent
+    tab, tab_dev, total, rows = ent
+    versions = tuple(t._version for t in vg)
+    hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
+    if hit is not None and hit["versions"] == versions and all(r() is t for r, t in zip(hit["refs"], vg)):
+        wbuf, norm = hit["wbuf"], hit["norm"]  # (identity: a recycled address is not the same parameter)
+    else:
+        wbuf = torch.empty((total,), device=dev, dtype=torch.float32)
+        norm = torch.empty((rows,), device=dev, dtype=torch.float32)
+        check(lib().vcv_weight_norm_many_fwd(ptr(tab_dev), n, rows, ptr(wbuf), ptr(norm), stream()),
+              "vcv_weight_norm_many_fwd")
+        if _WN_CACHE_ON[0]:
+            if len(_WN_CACHE) > 64:
+                _WN_CACHE.clear()
+            import weakref
+            _WN_CACHE[key] = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
+                                  lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={})
+    h = _WnHolder()
+    h.wbuf, h.norm, h.tab, h.total, h.rows = wbuf, norm, tab, total, rows
+    return h
+
+
 class _WeightNormManyFn(torch.autograd.Function):
-    """weight_norm of a list of (v, g) pairs in one launch (and one launch for all their gradients)."""
+    """Autograd node of layers [i0, i1) of one batched weight-norm launch.  The forward launch covers the whole module
+    tree (`holder`); the BACKWARD is one launch per node, so a tree split into several nodes (one per
+    sub-discriminator / generator block) hands its parameter gradients to the optimizer -- and its gradient buckets to
+    the all-reduce -- as soon as that part of the backward pass is done, not at the very end."""
 
     @staticmethod
-    def forward(ctx, *vg):
-        n = len(vg) // 2
+    def forward(ctx, holder, i0, i1, *vg):
+        n = i1 - i0
         vs, gs = vg[:n], vg[n:]
-        for t in vg:
-            if t.dtype != torch.float32 or not t.is_contiguous():
-                raise RuntimeError("weight_norm_many: parameters must be contiguous fp32")
-        dev = vs[0].device
-        key = tuple(t.data_ptr() for t in vg)
-        ent = _WN_TABLES.get(key)
-        if ent is None:
-            import numpy as np
-            tab = np.zeros((n, 10), dtype=np.int64)
-            woff = row0 = 0
-            for i, (v, g) in enumerate(zip(vs, gs)):
-                R = v.shape[0]
-                C = v.numel() // R
-                tab[i, :6] = (v.data_ptr(), g.data_ptr(), woff, row0, R, C)
-                woff += R * C
-                row0 += R
-            ent = (tab, torch.from_numpy(tab).to(dev), woff, row0)
-            if len(_WN_TABLES) > 256:
-                _WN_TABLES.clear()
-            _WN_TABLES[key] = ent
-        tab, tab_dev, total, rows = ent
-        versions = tuple(t._version for t in vg)
-        hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
-        if hit is not None and hit["versions"] == versions and all(r() is t for r, t in zip(hit["refs"], vg)):
-            wbuf, norm = hit["wbuf"], hit["norm"]  # (identity: a recycled address is not the same parameter)
-        else:
-            wbuf = torch.empty((total,), device=dev, dtype=torch.float32)
-            norm = torch.empty((rows,), device=dev, dtype=torch.float32)
-            check(lib().vcv_weight_norm_many_fwd(ptr(tab_dev), n, rows, ptr(wbuf), ptr(norm), stream()),
-                  "vcv_weight_norm_many_fwd")
-            if _WN_CACHE_ON[0]:
-                if len(_WN_CACHE) > 64:
-                    _WN_CACHE.clear()
-                import weakref
-                _WN_CACHE[key] = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
-                                      lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={})
-        ctx.n, ctx.tab, ctx.total, ctx.rows = n, tab, total, rows
+        tab = holder.tab
+        ctx.holder, ctx.i0, ctx.i1 = holder, i0, i1
         ctx.shapes = [(v.shape, g.shape) for v, g in zip(vs, gs)]
         ctx.sinks = [(_sink(v), _sink(g)) for v, g in zip(vs, gs)]
-        ctx.save_for_backward(norm, *vg)  # keeps v / g alive; the table holds their addresses
-        return tuple(wbuf[int(tab[i, 2]):int(tab[i, 2]) + vs[i].numel()].view(vs[i].shape) for i in range(n))
+        ctx.save_for_backward(*vg)  # keeps v / g alive; the table holds their addresses
+        wbuf = holder.wbuf
+        return tuple(wbuf[int(tab[i0 + i, 2]):int(tab[i0 + i, 2]) + vs[i].numel()].view(vs[i].shape) for i in range(n))
 
     @staticmethod
     def backward(ctx, *dws):
-        norm = ctx.saved_tensors[0]
-        n, dev = ctx.n, norm.device
+        holder, i0, i1 = ctx.holder, ctx.i0, ctx.i1
+        n, dev = i1 - i0, holder.norm.device
         dws = [_f32c(d) for d in dws]
-        tab = ctx.tab.copy()
+        tab = holder.tab[i0:i1].copy()
+        first_row = int(tab[0, 3])
+        rows = int(tab[-1, 3] + tab[-1, 4]) - first_row
+        tab[:, 3] -= first_row  # the launch covers this node's rows only
         loose = [i for i in range(n) if ctx.sinks[i][0] is None or ctx.sinks[i][1] is None]
         dvbuf = dg = None
         if loose:
@@ -822,19 +864,41 @@ class _WeightNormManyFn(torch.autograd.Function):
                 o += R * C
                 r0 += R
         tab_dev = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
-        check(lib().vcv_weight_norm_many_bwd(ptr(tab_dev), n, ctx.rows, ptr(norm), stream()),
+        check(lib().vcv_weight_norm_many_bwd(ptr(tab_dev), n, rows, ptr(holder.norm[first_row:first_row + rows]), stream()),
               "vcv_weight_norm_many_bwd")
         for sv, sg in ctx.sinks:
             if sv is not None and sg is not None:
                 for e in (sv, sg):
                     if e[1] is not None:
                         e[1]()
-        return tuple(dvs) + tuple(dgs)
+        return (None, None, None) + tuple(dvs) + tuple(dgs)
 
 
-def weight_norm_many(vs, gs):
-    """[weight_norm(v, g) for v, g in zip(vs, gs)] in one launch."""
-    return _WeightNormManyFn.apply(*vs, *gs)
+def weight_norm_forward(vs, gs):
+    """The batched forward launch alone (cached); autograd nodes are attached later with weight_norm_group."""
+    return _wn_forward_all(tuple(vs) + tuple(gs), len(vs))
+
+
+def weight_norm_group(holder, i0, i1, vs, gs):
+    """Effective weights of layers [i0, i1) of a weight_norm_forward result, as ONE autograd node created NOW: a node
+    created when its sub-block's forward starts sits right behind that block's conv nodes in autograd's (reverse
+    creation order) schedule, so its backward -- and the parameter gradients it finalises -- run as soon as the block's
+    backward is done, not after every other block's."""
+    return _WeightNormManyFn.apply(holder, i0, i1, *vs, *gs)
+
+
+def weight_norm_many(vs, gs, group_sizes=None):
+    """[weight_norm(v, g) for v, g in zip(vs, gs)]: ONE forward launch; one autograd node (= one backward launch) per
+    consecutive group of `group_sizes` layers (default: a single node)."""
+    n = len(vs)
+    holder = _wn_forward_all(tuple(vs) + tuple(gs), n)
+    out = []
+    i0 = 0
+    for k in (group_sizes or [n]):
+        out.extend(_WeightNormManyFn.apply(holder, i0, i0 + k, *vs[i0:i0 + k], *gs[i0:i0 + k]))
+        i0 += k
+    assert i0 == n
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
