@@ -382,8 +382,10 @@ extern "C" int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* a) {
   long long z = (512 + tiles - 1) / tiles;
   if (z > total) z = total;
   if (z < 1) z = 1;
-  if (z > 64) z = 64;
-  return (int64_t)z * a->Mg * a->Cg * a->K;
+  const long long n = (long long)a->Mg * a->Cg * a->K;
+  while (z > 1 && z * n > (64ll << 20)) --z;  // at most 256 MB of slabs
+  if (z > 512) z = 512;
+  return (int64_t)(z * n);
 }
 
 #define WB_CASE(wm, wc, wu, kt) \
