@@ -120,3 +120,30 @@ def test_weight_gradient_is_bit_reproducible(gpu, shape):
             ops.set_deterministic(True)
     assert torch.equal(runs[0], runs[1])
     close("atomics vs slabs", runs[2], runs[0], tol=2e-5)
+
+
+def test_stft_backward_is_bit_reproducible_and_exact(gpu):
+    """Zero-pad STFT backward: every sample is owned by one workgroup that gathers its overlapping frames (no atomics):
+    identical bits on repeated runs; values against torch CPU autograd, including ragged lengths (tail ownership)."""
+    import torch.nn.functional as F
+    from vcvits_amd import ops
+    for T in (16384, 9000, 2048 + 512 * 5 + 77):
+        g = torch.Generator().manual_seed(T)
+        y = torch.rand(3, T, generator=g) * 1.8 - 0.9
+        r = None
+        outs = []
+        for rep in range(2):
+            yg = y.to(gpu).requires_grad_(True)
+            mg = ops.stft_mag(yg, 2048, 512, 768, False, 1e-6)
+            if r is None:
+                r = torch.randn(mg.shape, generator=g)
+            (mg * r.to(gpu)).sum().backward()
+            outs.append(yg.grad.clone())
+        assert torch.equal(outs[0], outs[1])
+        yc = y.clone().requires_grad_(True)
+        spec = torch.stft(F.pad(yc, (768, 768)), 2048, hop_length=512, win_length=2048, window=torch.hann_window(2048),
+                          center=False, normalized=False, onesided=True, return_complex=True)
+        mag = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-6)
+        close("mag T=%d" % T, mg, mag, tol=1e-5)
+        (mag * r).sum().backward()
+        close("dy T=%d" % T, outs[0], yc.grad, tol=2e-5)

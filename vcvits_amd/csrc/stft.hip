@@ -4,14 +4,23 @@
 // vits/mel_processing.py:54-96 of the reference (zero-pad variant :76-96 used in training,
 // reflect-pad variant :54-74 / :115-142 used in validation).
 //
-// One workgroup transforms NF consecutive frames of one utterance: a frame is windowed into LDS
-// straight from the un-padded waveform (the pad is folded into the index map -- no padded copy),
-// run through an 11-stage Stockham radix-2 FFT ping-ponging between two LDS buffers (twiddles
-// from a host-built fp64-accurate table staged in LDS), and its 1025 magnitudes are parked in an
-// LDS tile [bin][frame] so the [B, 1025, F] output is written in frame-contiguous runs.
-// Backward recomputes the frame spectrum (cheaper than saving re/im: the kernel is HBM-bound),
-// forms G_k = dmag_k * X_k / mag_k, runs the conjugate-twiddle FFT (the adjoint of the one-sided
-// real DFT) and overlap-adds window * Re(g) into the waveform gradient with fp32 atomics.
+// One workgroup (4 wavefronts) transforms NF consecutive frames of one utterance.  The 2048-point FFT is a radix-2
+// decimation-in-frequency transform over 11 index bits held as  [wave : 2][lane : 6][register : 3]:
+//   * stages of bits 10, 9, 8: every thread holds the 8 elements n = t + 256 r, so these butterflies are register-local;
+//   * ONE exchange through LDS re-deals the elements so that bits 7..2 are the LANE index;
+//   * stages of bits 7..2: wavefront shuffles (lane ^ 32, 16, 8, 4, 2, 1) -- the twiddle products are reduced across
+//     the wavefront without touching LDS or a barrier (north_star: "wavefront shuffles for the STFT twiddle
+//     reductions");
+//   * stages of bits 1, 0: register-local again (twiddles 1 and -i).
+// Two barriers per transform instead of the eleven of a Stockham pass through LDS.  The result is in bit-reversed
+// order (element n holds X[rev11(n)]), which the consumers absorb in their index maps.  Twiddles come from a
+// host-built fp64-accurate table staged in LDS.
+// Frames are windowed straight from the un-padded waveform (the pad is folded into the index map -- no padded copy).
+// Backward recomputes the frame spectrum (cheaper than saving re/im: the kernel is HBM-bound), forms
+// G_k = dmag_k * X_k / mag_k, runs the conjugate-twiddle transform (the adjoint of the one-sided real DFT) and
+// overlap-adds window * Re(g).  Zero-pad mode (the only one the training step differentiates): every workgroup OWNS the
+// samples of its NF hops and gathers all frames that overlap them (3 halo frames per side are recomputed), so the
+// gradient is written with plain stores -- no atomics, bit-reproducible.  Reflect mode keeps fp32 atomics.
 #include "common.h"
 
 namespace {
@@ -21,29 +30,94 @@ constexpr int N = 2048, HALF = 1024, NBIN = 1025, NF = 8, NT = 256;
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-// result lands in B (11 stages: A->B->A->...->B)
+// position of register r of this thread after the LDS re-deal:  n = wave*512 + (r>>2)*256 + lane*4 + (r&3)
+__device__ __forceinline__ int pos2(int r) {
+  const int t = threadIdx.x;
+  return ((t >> 6) << 9) | ((r >> 2) << 8) | ((t & 63) << 2) | (r & 3);
+}
+// frequency index held at position n after the transform
+__device__ __forceinline__ int rev11(int n) { return (int)(__brev((unsigned)n) >> 21); }
+
+// In: x[r] = element n = t + 256 r (natural order).  Out: x[r] = X[rev11(pos2(r))].  `xch` = 2048 float2 of LDS scratch
+// (the caller guarantees nobody still reads it), `tw` = LDS table exp(-2 pi i k / 2048), k < 1024.
 template <bool INV>
-__device__ __forceinline__ void fft2048(float2* A, float2* Bf, const float2* tw) {
-  float2* in = A;
-  float2* out = Bf;
-  const int tid = threadIdx.x;
-  for (int Ns = 1; Ns < N; Ns <<= 1) {
-    const int tstep = HALF / Ns;
+__device__ __forceinline__ void fft2048_ws(float2 (&x)[8], float2* xch, const float2* tw) {
+  const int t = threadIdx.x, lane = t & 63;
+  auto W = [&](int idx) {
+    float2 w = tw[idx];
+    if (INV) w.y = -w.y;
+    return w;
+  };
+  // ---- bits 10, 9, 8: register-local ----
 #pragma unroll
-    for (int i = 0; i < HALF / NT; ++i) {
-      const int j = tid + NT * i;
-      const int k = j & (Ns - 1);
-      float2 w = tw[k * tstep];
-      if (INV) w.y = -w.y;
-      const float2 v0 = in[j];
-      const float2 v1 = cmul(in[j + HALF], w);
-      const int j0 = ((j - k) << 1) + k;
-      out[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
-      out[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+  for (int r = 0; r < 4; ++r) {  // D = 1024: pairs (r, r+4), twiddle index n mod 1024 = t + 256 r
+    const float2 a = x[r], b = x[r + 4];
+    x[r] = cadd(a, b);
+    x[r + 4] = cmul(csub(a, b), W(t + 256 * r));
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {  // D = 512: pairs (4g + r, 4g + r + 2), index (n mod 512) * 2
+      const float2 a = x[4 * g + r], b = x[4 * g + r + 2];
+      x[4 * g + r] = cadd(a, b);
+      x[4 * g + r + 2] = cmul(csub(a, b), W((t + 256 * r) * 2));
     }
-    __syncthreads();
-    float2* t = in; in = out; out = t;
+  {
+    const float2 w = W(t * 4);  // D = 256: pairs (2g, 2g + 1), index (n mod 256) * 4
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float2 a = x[2 * g], b = x[2 * g + 1];
+      x[2 * g] = cadd(a, b);
+      x[2 * g + 1] = cmul(csub(a, b), w);
+    }
+  }
+  // ---- re-deal through LDS: bits 7..2 become the lane ----
+#pragma unroll
+  for (int r = 0; r < 8; ++r) xch[t + 256 * r] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) x[r] = xch[pos2(r)];
+  // ---- bits 7..2: wavefront shuffles.  Stage of bit b = lane bit b - 2: the lane with that bit clear keeps a + b, its
+  // partner (bit set) keeps (a - b) * W[(n mod 2^b) << (10 - b)] ----
+#pragma unroll
+  for (int lb = 5; lb >= 0; --lb) {
+    const int m = 1 << lb, b = lb + 2;
+    const bool upper = (lane & m) != 0;
+    const int low = (lane & (m - 1)) << 2;  // bits of n below b that come from the lane
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float2 mine = x[r];
+      const float2 other = make_float2(__shfl_xor(mine.x, m, 64), __shfl_xor(mine.y, m, 64));
+      const float2 w = W((low | (r & 3)) << (10 - b));
+      const float2 lo = cadd(mine, other);            // what the lower lane keeps (mine = a, other = b)
+      const float2 hi = cmul(csub(other, mine), w);   // what the upper lane keeps (other = a, mine = b)
+      x[r] = upper ? hi : lo;
+    }
+  }
+  // ---- bits 1, 0: register-local.  D = 2: pairs (r, r+2) within a group of 4, twiddle 1 for even n, W[512] = -+i for odd ----
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    {
+      const float2 a = x[4 * g], b = x[4 * g + 2];
+      x[4 * g] = cadd(a, b);
+      x[4 * g + 2] = csub(a, b);
+    }
+    {
+      const float2 a = x[4 * g + 1], b = x[4 * g + 3];
+      const float2 d = csub(a, b);
+      x[4 * g + 1] = cadd(a, b);
+      x[4 * g + 3] = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);  // d * (+i) / d * (-i)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {  // D = 1
+      const float2 a = x[4 * g + r], b = x[4 * g + r + 1];
+      x[4 * g + r] = cadd(a, b);
+      x[4 * g + r + 1] = csub(a, b);
+    }
   }
 }
 
@@ -57,12 +131,22 @@ __device__ __forceinline__ int src_index(int pi, int pad, int T, int reflect) {
   return (o >= 0 && o < T) ? o : -1;
 }
 
+// windowed frame starting at padded position `start`, in the transform's input layout (x[r] = element t + 256 r)
+__device__ __forceinline__ void load_frame(float2 (&x)[8], const float* yb, const float* window, int start, int pad, int T,
+                                           int reflect) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int n = threadIdx.x + 256 * r;
+    const int o = src_index(start + n, pad, T, reflect);
+    x[r] = make_float2(o >= 0 ? yb[o] * window[n] : 0.f, 0.f);
+  }
+}
+
 __global__ void __launch_bounds__(NT)
 stft_mag_fwd_kernel(const float* __restrict__ y, const float* __restrict__ window,
                     const float2* __restrict__ twg, float* __restrict__ mag, int T, int F, int hop,
                     int pad, int reflect, float eps) {
-  __shared__ float2 A[N];
-  __shared__ float2 Bf[N];
+  __shared__ float2 xch[N];
   __shared__ float2 tw[HALF];
   __shared__ float tile[NBIN * NF];
   const int tid = threadIdx.x;
@@ -72,17 +156,14 @@ stft_mag_fwd_kernel(const float* __restrict__ y, const float* __restrict__ windo
   int nf = F - f0;
   if (nf > NF) nf = NF;
   for (int fi = 0; fi < nf; ++fi) {
-    const int start = (f0 + fi) * hop;
-    __syncthreads();
-    for (int n = tid; n < N; n += NT) {
-      const int o = src_index(start + n, pad, T, reflect);
-      A[n] = make_float2(o >= 0 ? yb[o] * window[n] : 0.f, 0.f);
-    }
-    __syncthreads();
-    fft2048<false>(A, Bf, tw);
-    for (int k = tid; k < NBIN; k += NT) {
-      const float2 X = Bf[k];
-      tile[k * NF + fi] = sqrtf(X.x * X.x + X.y * X.y + eps);
+    float2 x[8];
+    load_frame(x, yb, window, (f0 + fi) * hop, pad, T, reflect);
+    __syncthreads();  // the previous frame's re-deal reads are done (and, first time round, tw is staged)
+    fft2048_ws<false>(x, xch, tw);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = rev11(pos2(r));
+      if (k < NBIN) tile[k * NF + fi] = sqrtf(x[r].x * x[r].x + x[r].y * x[r].y + eps);
     }
   }
   __syncthreads();
@@ -93,46 +174,80 @@ stft_mag_fwd_kernel(const float* __restrict__ y, const float* __restrict__ windo
   }
 }
 
+// Backward.  OWN = true (zero pad): the block owns the padded positions [f0*hop, (f0+NF)*hop) (the last block also the
+// tail), gathers every frame that overlaps them into an LDS accumulator and writes dy with plain stores.
+// OWN = false (reflect pad): each block scatters its NF frames with atomics.
+template <bool OWN>
 __global__ void __launch_bounds__(NT)
 stft_mag_bwd_kernel(const float* __restrict__ y, const float* __restrict__ window,
                     const float2* __restrict__ twg, const float* __restrict__ dmag,
                     float* __restrict__ dy, int T, int F, int hop, int pad, int reflect, float eps) {
-  __shared__ float2 A[N];
-  __shared__ float2 Bf[N];
+  __shared__ float2 xch[N];
   __shared__ float2 tw[HALF];
+  __shared__ float accs[OWN ? NF * 512 + N : 1];  // hop <= 512 (checked by the launcher)
   const int tid = threadIdx.x;
   const int b = blockIdx.y, f0 = blockIdx.x * NF;
   const float* yb = y + (size_t)b * T;
   float* dyb = dy + (size_t)b * T;
   const float* db = dmag + (size_t)b * NBIN * F;
   for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
-  int nf = F - f0;
-  if (nf > NF) nf = NF;
-  for (int fi = 0; fi < nf; ++fi) {
-    const int f = f0 + fi;
+  const bool last = (int)blockIdx.x == (int)gridDim.x - 1;
+  const int own_lo = f0 * hop;
+  const int own_hi = last ? T + 2 * pad : (f0 + NF) * hop;  // padded positions [own_lo, own_hi)
+  int fa = f0, fb = f0 + NF;
+  if (OWN) {
+    for (int i = tid; i < NF * 512 + N; i += NT) accs[i] = 0.f;
+    const int halo = (N + hop - 1) / hop - 1;  // frames starting up to N - 1 positions earlier still reach own_lo
+    fa = f0 - halo < 0 ? 0 : f0 - halo;
+  }
+  if (fb > F) fb = F;
+  for (int f = fa; f < fb; ++f) {
     const int start = f * hop;
+    float2 x[8];
+    load_frame(x, yb, window, start, pad, T, reflect);
     __syncthreads();
-    for (int n = tid; n < N; n += NT) {
-      const int o = src_index(start + n, pad, T, reflect);
-      A[n] = make_float2(o >= 0 ? yb[o] * window[n] : 0.f, 0.f);
-    }
-    __syncthreads();
-    fft2048<false>(A, Bf, tw);  // spectrum in Bf
-    for (int k = tid; k < N; k += NT) {
-      float2 G = make_float2(0.f, 0.f);
+    fft2048_ws<false>(x, xch, tw);  // spectrum, bit-reversed
+    float2 G[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = rev11(pos2(r));
+      G[r] = make_float2(0.f, 0.f);
       if (k < NBIN) {
-        const float2 X = Bf[k];
-        const float m = sqrtf(X.x * X.x + X.y * X.y + eps);
+        const float m = sqrtf(x[r].x * x[r].x + x[r].y * x[r].y + eps);
         const float s = db[(size_t)k * F + f] / m;
-        G = make_float2(s * X.x, s * X.y);
+        G[r] = make_float2(s * x[r].x, s * x[r].y);
       }
-      A[k] = G;
     }
+    __syncthreads();  // every thread is past its re-deal reads of xch
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r))] = G[r];  // natural order for the second transform
     __syncthreads();
-    fft2048<true>(A, Bf, tw);  // g in Bf
-    for (int n = tid; n < N; n += NT) {
-      const int o = src_index(start + n, pad, T, reflect);
-      if (o >= 0) unsafeAtomicAdd(dyb + o, Bf[n].x * window[n]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = xch[tid + 256 * r];
+    __syncthreads();
+    fft2048_ws<true>(x, xch, tw);  // g, bit-reversed
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r))].x = x[r].x;  // natural order for the coalesced overlap-add
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = tid + 256 * r;
+      const float v = xch[n].x * window[n];
+      if (OWN) {
+        const int pi = start + n;
+        if (pi >= own_lo && pi < own_hi) accs[pi - own_lo] += v;  // one thread per position and frame: no conflict
+      } else {
+        const int o = src_index(start + n, pad, T, reflect);
+        if (o >= 0) unsafeAtomicAdd(dyb + o, v);
+      }
+    }
+  }
+  if (OWN) {
+    __syncthreads();
+    for (int pi = own_lo + tid; pi < own_hi; pi += NT) {
+      const int o = pi - pad;
+      if (o >= 0 && o < T) dyb[o] = pi - own_lo < NF * 512 + N ? accs[pi - own_lo] : 0.f;
     }
   }
 }
@@ -142,22 +257,22 @@ __global__ void __launch_bounds__(NT)
 stft_complex_fwd_kernel(const float* __restrict__ y, const float* __restrict__ window,
                         const float2* __restrict__ twg, float2* __restrict__ out, int T, int F, int hop, int pad,
                         int reflect) {
-  __shared__ float2 A[N];
-  __shared__ float2 Bf[N];
+  __shared__ float2 xch[N];
   __shared__ float2 tw[HALF];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, f = blockIdx.x;
   const float* yb = y + (size_t)b * T;
   for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
-  const int start = f * hop;
-  for (int n = tid; n < N; n += NT) {
-    const int o = src_index(start + n, pad, T, reflect);
-    A[n] = make_float2(o >= 0 ? yb[o] * window[n] : 0.f, 0.f);
-  }
+  float2 x[8];
+  load_frame(x, yb, window, f * hop, pad, T, reflect);
   __syncthreads();
-  fft2048<false>(A, Bf, tw);
+  fft2048_ws<false>(x, xch, tw);
   float2* ob = out + (size_t)b * NBIN * F;
-  for (int k = tid; k < NBIN; k += NT) ob[(size_t)k * F + f] = Bf[k];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int k = rev11(pos2(r));
+    if (k < NBIN) ob[(size_t)k * F + f] = x[r];
+  }
 }
 
 // inverse STFT, stage 1 (torch.istft as used by torchaudio InverseSpectrogram, pipeline.py:28,66): per
@@ -166,14 +281,16 @@ stft_complex_fwd_kernel(const float* __restrict__ y, const float* __restrict__ w
 __global__ void __launch_bounds__(NT)
 istft_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ window, const float2* __restrict__ twg,
                  float* __restrict__ ola, int F, int hop, int L) {
-  __shared__ float2 A[N];
-  __shared__ float2 Bf[N];
+  __shared__ float2 xch[N];
   __shared__ float2 tw[HALF];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, f = blockIdx.x;
   const float2* sb = spec + (size_t)b * NBIN * F;
   for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
-  for (int k = tid; k < N; k += NT) {
+  float2 x[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int k = tid + 256 * r;
     float2 v;
     if (k <= HALF) {
       v = sb[(size_t)k * F + f];
@@ -182,13 +299,21 @@ istft_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ wind
       v = sb[(size_t)(N - k) * F + f];
       v.y = -v.y;
     }
-    A[k] = v;
+    x[r] = v;
   }
   __syncthreads();
-  fft2048<true>(A, Bf, tw);
+  fft2048_ws<true>(x, xch, tw);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) xch[rev11(pos2(r))].x = x[r].x;
+  __syncthreads();
   float* ob = ola + (size_t)b * L;
   const float inv = 1.f / N;
-  for (int n = tid; n < N; n += NT) unsafeAtomicAdd(ob + (size_t)f * hop + n, Bf[n].x * inv * window[n]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int n = tid + 256 * r;
+    unsafeAtomicAdd(ob + (size_t)f * hop + n, xch[n].x * inv * window[n]);
+  }
 }
 
 // stage 2: divide by the window envelope sum_f w^2[i - f*hop] and trim `trim` samples on the left (center=True)
@@ -262,8 +387,14 @@ extern "C" int vcv_stft_mag_bwd(const float* y, const float* window, const float
   if (reflect && pad > T - 1) return VCV_EINVAL;
   const int F = (T + 2 * pad - n_fft) / hop + 1;
   if (F <= 0) return VCV_EINVAL;
+  if (!reflect && hop <= 512 && T + 2 * pad - ((vcv_cdiv(F, NF) - 1) * NF) * hop <= NF * 512 + N) {
+    // zero pad: every sample is owned by one workgroup -> plain stores, no memset, bit-reproducible
+    hipLaunchKernelGGL(stft_mag_bwd_kernel<true>, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, (hipStream_t)stream, y,
+                       window, (const float2*)twiddle, dmag, dy, T, F, hop, pad, reflect, eps);
+    return vcv_check_launch();
+  }
   if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * T, (hipStream_t)stream) != hipSuccess) return VCV_EHIP;
-  hipLaunchKernelGGL(stft_mag_bwd_kernel, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, (hipStream_t)stream, y,
+  hipLaunchKernelGGL(stft_mag_bwd_kernel<false>, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, (hipStream_t)stream, y,
                      window, (const float2*)twiddle, dmag, dy, T, F, hop, pad, reflect, eps);
   return vcv_check_launch();
 }
