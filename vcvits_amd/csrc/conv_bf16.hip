@@ -297,7 +297,7 @@ struct Plan {
   size_t scratch_floats, pack_bytes, lds_bytes;
 };
 
-constexpr int MAXT = 4;  // staging tasks (8 loads each) a wave keeps in flight
+constexpr int MAXT = 5;  // staging tasks (8 loads each) a wave keeps in flight
 
 bool eligible(const VcvConvArgs& a) {
   const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
@@ -368,11 +368,15 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     else if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
     else if (make_plan(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
   } else if (a.Mg >= 64) {
-    if (U > 160 && U <= 224 && make_plan(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
+    static const int wide64 = getenv("VCVITS_BF16_WIDE64") ? atoi(getenv("VCVITS_BF16_WIDE64")) : 0;
+    if (wide64 && U >= 2048 && blocks(64, 512) >= 256 && make_plan(a, 64, 512, 8, pl)) pl.variant = 9, ok = true;
+    else if (U > 160 && U <= 224 && make_plan(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
     else if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
     else if (make_plan(a, 64, 128, 8, pl)) pl.variant = 4, ok = true;
   } else {
-    if (make_plan(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
+    static const int wide32 = getenv("VCVITS_BF16_WIDE32") ? atoi(getenv("VCVITS_BF16_WIDE32")) : 1;
+    if (wide32 && U >= 2048 && blocks(32, 512) >= 256 && make_plan(a, 32, 512, 8, pl)) pl.variant = 8, ok = true;
+    else if (make_plan(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
   }
   if (!ok) return false;
   // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass)
@@ -452,6 +456,8 @@ extern "C" int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float*
     case 4: return launch<1, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 5: return launch<1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 6: return launch<1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 8: return launch<1, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 32 x 512
+    case 9: return launch<2, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 64 x 512
     default: return launch<4, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);
   }
 }
