@@ -85,8 +85,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16; 64 for --workload infer)")
     ap.add_argument("--frames", type=int, default=938, help="--workload infer: frames per utterance (938 = 10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="also time SURVEY 8d's config 1 (full model, B=2) on the host")
+    ap.add_argument("--no-cpu-baseline-full", action="store_true",
+                    help="skip the second CPU leg (SURVEY 8d's config 1: full model, B=2)")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch event timing")
     return ap.parse_args()
 
@@ -317,7 +317,7 @@ def main():
                      "roofline": roof})
         if world == 1 and not a.no_cpu_baseline:
             periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
-            line["cpu_baseline"] = cpu_baseline(cfg, a.workload, periods, a.frames, also_full=a.cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(cfg, a.workload, periods, a.frames, also_full=not a.no_cpu_baseline_full)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

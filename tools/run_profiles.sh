@@ -17,7 +17,7 @@ mkdir -p gpurun_out
 run ${TAG}_f32
 run ${TAG}_bf16 --dtype bf16
 run ${TAG}_full_f32 --workload full
-python3 bench.py --steps 10 --warmup 3 --cpu-baseline-full > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
+python3 bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_bf16.json 2>/dev/null
 python3 bench.py --dtype bf16 --workload full --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_cfg3.json 2>/dev/null
 python3 bench.py --dtype bf16 --config 48k --workload full --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_cfg4_1gpu.json 2>/dev/null
