@@ -275,14 +275,33 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
   }
 }
 
-// dw[i] += alpha * sum_z slab[z][i]   (fixed order: deterministic)
+// dw[i] += alpha * sum_z slab[z][i] in a fixed order (deterministic).  ZL z-lanes per element (a power of two <= 16)
+// take every ZL-th slab with four independent partial sums each -- a single thread walking hundreds of slabs is a
+// latency-bound dependent chain -- and the lanes' partials are combined through LDS in lane order.
 __global__ void __launch_bounds__(256) wgrad_bf16_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                size_t n, int Z, float alpha) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = slab[i];
-  for (int z = 1; z < Z; ++z) s += slab[(size_t)z * n + i];
-  dw[i] += alpha * s;
+                                                                size_t n, int Z, float alpha, int ZL) {
+  __shared__ float red[256];
+  const int E = 256 / ZL;
+  const int e = threadIdx.x % E, zl = threadIdx.x / E;
+  const size_t i = (size_t)blockIdx.x * E + e;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < n) {
+    int z = zl;
+    for (; z + 3 * ZL < Z; z += 4 * ZL) {
+      a0 += slab[(size_t)z * n + i];
+      a1 += slab[(size_t)(z + ZL) * n + i];
+      a2 += slab[(size_t)(z + 2 * ZL) * n + i];
+      a3 += slab[(size_t)(z + 3 * ZL) * n + i];
+    }
+    for (; z < Z; z += ZL) a0 += slab[(size_t)z * n + i];
+  }
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (zl == 0 && i < n) {
+    float s = red[e];
+    for (int k = 1; k < ZL; ++k) s += red[k * E + e];
+    dw[i] += alpha * s;
+  }
 }
 
 constexpr int MAXT = 2;
@@ -342,8 +361,11 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g, scratch);
-  hipLaunchKernelGGL(wgrad_bf16_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)scratch,
-                     a.dw, n, g.Z, a.alpha);
+  int ZL = 1;
+  while (ZL < 16 && ZL * 4 <= g.Z) ZL *= 2;  // enough z-lanes that a thread walks at most ~Z/16 slabs, 4 at a time
+  const int E = 256 / ZL;
+  hipLaunchKernelGGL(wgrad_bf16_finish_kernel, dim3((unsigned)((n + E - 1) / E)), dim3(256), 0, st, (const float*)scratch,
+                     a.dw, n, g.Z, a.alpha, ZL);
   return vcv_check_launch();
 }
 
