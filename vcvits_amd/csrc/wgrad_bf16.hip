@@ -37,10 +37,12 @@ struct WbGeom {
   int a_bytes, buf_bytes;
 };
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+typedef __attribute__((address_space(3))) char lds_char;
+
+__device__ __forceinline__ bf16x8 tr_pair(const lds_char* p0, const lds_char* p1) {
   // two transposed reads = the 8 reduction elements of one MFMA operand (rows 0-3 and 4-7 of the lane's half)
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(__attribute__((address_space(3))) void*)p0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(__attribute__((address_space(3))) void*)p1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p1);
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
@@ -198,14 +200,14 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
     for (int ch = z; ch < total; ch += tg.Z) {
       const bool more = ch + tg.Z < total;
       if (more) load(ch + tg.Z);
-      const char* Ya = smem + bufi * tg.buf_bytes;
-      const char* Xb = Ya + tg.a_bytes;
-      const int* tab = (const int*)(Xb + tg.XR * PB);
+      const lds_char* Ya = (const lds_char*)smem + bufi * tg.buf_bytes;  // 32-bit LDS addresses from here on
+      const lds_char* Xb = Ya + tg.a_bytes;
+      const int* tab = (const int*)(smem + bufi * tg.buf_bytes + tg.a_bytes + tg.XR * PB);
       for (int i16 = wu; i16 < BU / 16; i16 += WU) {
         const int ur = i16 * 16 + rowl;
-        const bf16x8 a = tr_pair(Ya + (size_t)ur * PA + colA, Ya + (size_t)(ur + 4) * PA + colA);
-        const char* x0 = Xb + tab[ur] + colB;
-        const char* x1 = Xb + tab[ur + 4] + colB;
+        const bf16x8 a = tr_pair(Ya + ur * PA + colA, Ya + (ur + 4) * PA + colA);
+        const lds_char* x0 = Xb + tab[ur] + colB;
+        const lds_char* x1 = Xb + tab[ur + 4] + colB;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           if (k < kn) {
@@ -257,9 +259,10 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
     if (wu != 0) return;
   }
 
-  // partial tile -> slab z:  slab[z][m][c][k]  (the dw layout)
-  const int N = Cg * K;
-  float* out = slab + (size_t)z * ((size_t)Mg * N);
+  // partial tile -> slab z, laid out [k][m][c]: the 32 lanes of an accumulator register hold 32 consecutive c of one
+  // (k, m) row, so every store instruction writes two 128-byte runs (the dw order [m][c][k] would scatter 64 lanes over
+  // 64 cache lines); wgrad_bf16_finish_kernel transposes back through LDS
+  float* out = slab + (size_t)z * ((size_t)Mg * Cg * K);
   const int c = c0 + wc * 32 + (lane & 31);
   if (c < Cg) {
 #pragma unroll
@@ -268,39 +271,57 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int ml = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (ml < Mg) out[(size_t)ml * N + (size_t)c * K + (k0 + k)] = acc[k][e];
+          if (ml < Mg) out[((size_t)(k0 + k) * Mg + ml) * Cg + c] = acc[k][e];
         }
       }
     }
   }
 }
 
-// dw[i] += alpha * sum_z slab[z][i] in a fixed order (deterministic).  ZL z-lanes per element (a power of two <= 16)
-// take every ZL-th slab with four independent partial sums each -- a single thread walking hundreds of slabs is a
-// latency-bound dependent chain -- and the lanes' partials are combined through LDS in lane order.
+// dw[m][c][k] += alpha * sum_z slab[z][k][m][c], slabs added in a fixed order (deterministic).  A workgroup is 8 groups
+// of 32 lanes over a block of 32 c (slab reads in 128-byte runs, the 32 x K block of dw written as one contiguous run
+// after a transpose through LDS).  Many slabs (ROWS == false): the 8 groups are z-lanes of ONE m row and meet in LDS.
+// Few slabs (ROWS == true): each group owns its own m row and walks all Z slabs.
+template <bool ROWS>
 __global__ void __launch_bounds__(256) wgrad_bf16_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                size_t n, int Z, float alpha, int ZL) {
-  __shared__ float red[256];
-  const int E = 256 / ZL;
-  const int e = threadIdx.x % E, zl = threadIdx.x / E;
-  const size_t i = (size_t)blockIdx.x * E + e;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (i < n) {
-    int z = zl;
-    for (; z + 3 * ZL < Z; z += 4 * ZL) {
-      a0 += slab[(size_t)z * n + i];
-      a1 += slab[(size_t)(z + ZL) * n + i];
-      a2 += slab[(size_t)(z + 2 * ZL) * n + i];
-      a3 += slab[(size_t)(z + 3 * ZL) * n + i];
+                                                                int M, int C, int K, int Z, float alpha) {
+  __shared__ float red[8][16][33];
+  const int cb = blockIdx.x * 32;
+  const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int m = ROWS ? blockIdx.y * 8 + zl : blockIdx.y;
+  const size_t n = (size_t)M * C * K;
+  const bool ok = cb + cl < C && m < M;
+  for (int k = 0; k < K; ++k) {
+    const size_t off = ((size_t)k * M + m) * C + cb + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (ok) {
+      const int step = ROWS ? 1 : 8;
+      int z = ROWS ? 0 : zl;
+      for (; z + step < Z; z += 2 * step) {
+        a0 += slab[(size_t)z * n + off];
+        a1 += slab[(size_t)(z + step) * n + off];
+      }
+      if (z < Z) a0 += slab[(size_t)z * n + off];
     }
-    for (; z < Z; z += ZL) a0 += slab[(size_t)z * n + i];
+    red[zl][k][cl] = a0 + a1;
   }
-  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (zl == 0 && i < n) {
-    float s = red[e];
-    for (int k = 1; k < ZL; ++k) s += red[k * E + e];
-    dw[i] += alpha * s;
+  if (ROWS) {
+    if (m < M)
+      for (int idx = cl; idx < 32 * K; idx += 32) {
+        const int c = idx / K, k = idx - c * K;
+        if (cb + c < C) dw[((size_t)m * C + cb + c) * K + k] += alpha * red[zl][k][c];
+      }
+  } else {
+    for (int idx = threadIdx.x; idx < 32 * K; idx += 256) {
+      const int c = idx / K, k = idx - c * K;
+      if (cb + c < C) {
+        float sum = red[0][k][c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) sum += red[q][k][c];
+        dw[((size_t)m * C + cb + c) * K + k] += alpha * sum;
+      }
+    }
   }
 }
 
@@ -361,11 +382,12 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g, scratch);
-  int ZL = 1;
-  while (ZL < 16 && ZL * 4 <= g.Z) ZL *= 2;  // enough z-lanes that a thread walks at most ~Z/16 slabs, 4 at a time
-  const int E = 256 / ZL;
-  hipLaunchKernelGGL(wgrad_bf16_finish_kernel, dim3((unsigned)((n + E - 1) / E)), dim3(256), 0, st, (const float*)scratch,
-                     a.dw, n, g.Z, a.alpha, ZL);
+  if (g.Z <= 12)
+    hipLaunchKernelGGL(wgrad_bf16_finish_kernel<true>, dim3((unsigned)vcv_cdiv(a.Cg, 32), (unsigned)vcv_cdiv(a.Mg, 8)), dim3(256), 0,
+                       st, (const float*)scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha);
+  else
+    hipLaunchKernelGGL(wgrad_bf16_finish_kernel<false>, dim3((unsigned)vcv_cdiv(a.Cg, 32), (unsigned)a.Mg), dim3(256), 0, st,
+                       (const float*)scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha);
   return vcv_check_launch();
 }
 
