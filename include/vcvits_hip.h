@@ -115,6 +115,10 @@ int vcv_conv_dma_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws,
  * its size in 4-byte words.  A pack made by one family is never valid for the other (different out[2]).
  */
 int vcv_conv_bf16_plan(const VcvConvArgs* args, int flip, int64_t* out);
+/* the same kernel on fp32 elements (4-channel 16-byte LDS groups, four v_mfma_f32_32x32x2_f32 per fragment pair: exact
+ * fp32 like vcv_conv_dma_*, with a quarter of its LDS read instructions per MFMA) */
+int vcv_conv_pk_plan(const VcvConvArgs* args, int flip, int64_t* out);
+int vcv_conv_pk_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream);
 int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
                       void* stream);
 

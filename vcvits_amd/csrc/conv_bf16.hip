@@ -1,5 +1,10 @@
-// conv_bf16.hip -- bf16-operand variant of the implicit-GEMM convolution (forward-type and phased launches, the
-// same launch family conv_dma.hip covers): v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM.
+// conv_bf16.hip -- channel-innermost packed-operand implicit-GEMM convolution (forward-type and phased launches, the
+// same launch family conv_dma.hip covers), in two element types:
+//   bf16 (vcv_conv_bf16_*): v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM;
+//   fp32 (vcv_conv_pk_*):   the same kernel on 4-channel 16-byte groups and v_mfma_f32_32x32x2_f32 (exact fp32): one
+//                           16-byte LDS read per operand feeds FOUR MFMAs, a quarter of conv_dma.hip's LDS read
+//                           instructions and four times its MFMA work per LDS round trip -- 106-115 vs 98-103 TFLOP/s
+//                           on the 1024-channel period-discriminator layers, 0.53 vs 0.49 of the fp32 peak in the step.
 //
 // The reference trains under AMP (configs/base.json:18, train.py:104-106: fp16 autocast of the convs, fp32 master
 // weights, fp32 losses).  Here the same recipe with bf16: operands are rounded to bf16 (round-to-nearest-even,
@@ -30,9 +35,33 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// Element traits.  The kernel moves 16-byte channel groups: 8 bf16 channels (one v_mfma_f32_32x32x16_bf16 per pair of
+// fragments) or 4 fp32 channels (four v_mfma_f32_32x32x2_f32: MFMA step i takes channel i of the h = 0 lanes' group
+// and channel i of the h = 1 lanes' group -- the reduction order is free as long as both operands agree).
+struct Bf16El {
+  typedef bf16x8 frag;
+  static constexpr int CPG = 8;   // channels per 16-byte group
+  static constexpr int ESZ = 2;
+  static __device__ __forceinline__ void set(frag& v, int e, float f) { v[e] = (__bf16)f; }
+  static __device__ __forceinline__ f32x16 mma(const frag& a, const frag& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct F32El {
+  typedef f32x4 frag;
+  static constexpr int CPG = 4;
+  static constexpr int ESZ = 4;
+  static __device__ __forceinline__ void set(frag& v, int e, float f) { v[e] = f; }
+  static __device__ __forceinline__ f32x16 mma(const frag& a, const frag& b, f32x16 c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], c, 0, 0, 0);
+    return c;
+  }
+};
+
 struct BfGeom {
-  int BKC;      // reduction channels per chunk (multiple of 16)
-  int ncg;      // BKC / 16
+  int BKC;      // reduction channels per chunk (multiple of 2 * CPG: 16 for bf16, 8 for fp32)
+  int ncg;      // BKC / (2 * CPG)
   int nch;      // chunks
   int ntu;      // position tiles per batch element
   int nmt;      // M tiles
@@ -47,12 +76,14 @@ struct BfGeom {
 // ---- weight pack: fp32 w -> bf16 slabs wp[phase][m-tile][chunk][j][cg][h][m][8] -------------------------------
 // mode 0: w is [M, C, K] (forward);  mode 1: w is [C, M, K], A(m, c, j) = w[c, m, K-1-j] (stride-1 data gradient);
 // mode 2: w is [C, M, K], residue r = phase keeps taps k = r + j*phases (ConvTranspose forward / strided dgrad)
+template <class EL>
 __global__ void __launch_bounds__(256)
-pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M, int C, int K, int BM, int BKC, int JA,
+pack_bf16_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, int M, int C, int K, int BM, int BKC, int JA,
                  int nch, int nmt, int phases, int mode, size_t total) {
+  constexpr int CPG = EL::CPG;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int ncg = BKC >> 4;
+  const int ncg = BKC / (2 * CPG);
   size_t t = i;
   const int ml = (int)(t % BM); t /= BM;
   const int hh = (int)(t & 1); t >>= 1;
@@ -62,10 +93,10 @@ pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M, in
   const int mt = (int)(t % nmt); t /= nmt;
   const int r = (int)t;
   const int m = mt * BM + ml;
-  const int c0 = ch * BKC + cg * 16 + hh * 8;
-  bf16x8 v;
+  const int c0 = ch * BKC + cg * 2 * CPG + hh * CPG;
+  typename EL::frag v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 0; e < CPG; ++e) {
     const int c = c0 + e;
     float f = 0.f;
     if (m < M && c < C) {
@@ -73,15 +104,17 @@ pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M, in
       else if (mode == 1) { if (j < K) f = w[((size_t)c * M + m) * K + (K - 1 - j)]; }
       else { const int k = r + j * phases; if (k < K) f = w[((size_t)c * M + m) * K + k]; }
     }
-    v[e] = (__bf16)f;
+    EL::set(v, e, f);
   }
   wp[i] = v;
 }
 
-template <int TM, int TN, int WM, int WN, bool LEAKY, int MAXT>
+template <class EL, int TM, int TN, int WM, int WN, bool LEAKY, int MAXT>
 __global__ void __launch_bounds__(64 * WM * WN)
-conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict__ wp, float* __restrict__ part) {
+conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+  constexpr int CPG = EL::CPG;
+  typedef typename EL::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -126,7 +159,7 @@ conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict_
   const char* wtile = (const char*)wp + ((size_t)r * gridDim.y + mt) * tg.nch * (size_t)tg.a_bytes;
   const int nA = tg.a_bytes >> 10;  // 1 KiB wave-instructions per weight slab
   const int npb = XW >> 6;          // 64-position blocks per span
-  const int ntask = (BKC >> 3) * npb;  // (8-channel group, position block) staging tasks per chunk
+  const int ntask = (BKC / CPG) * npb;  // (16-byte channel group, position block) staging tasks per chunk
 
   auto issueA = [&](int ch, int buf) {
     char* As = smem + buf * tg.buf_bytes;
@@ -135,7 +168,7 @@ conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict_
       __builtin_amdgcn_global_load_lds((const void*)(slab + i * 1024 + lane * 16), (lds_ptr)(As + i * 1024), 16, 0, 0);
   };
   // registers of the input loads in flight: task t of this wave = staging task wave + t * NW
-  float xr[MAXT][8];
+  float xr[MAXT][CPG];
   auto loadX = [&](int ch) {
     const int c0 = ch * BKC;
 #pragma unroll
@@ -145,8 +178,8 @@ conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict_
         const int g8 = task / npb, pb = task - g8 * npb;
         const unsigned voff = (unsigned)(f0 + pb * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = c0 + g8 * 8 + e;
+        for (int e = 0; e < CPG; ++e) {
+          const int c = c0 + g8 * CPG + e;
           const unsigned rec = c < Cg ? (unsigned)(TinP * 4) : 0u;
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * (size_t)TinP), 0, (int)rec, 0x00020000);
           xr[t][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
@@ -161,14 +194,14 @@ conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict_
       const int task = wave + t * NW;
       if (task < ntask) {
         const int g8 = task / npb, pb = task - g8 * npb;
-        bf16x8 v;
+        frag v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < CPG; ++e) {
           float f = xr[t][e];
           if (LEAKY) f = fmaxf(f, f * p.slope);  // slope in [0, 1)
-          v[e] = (__bf16)f;
+          EL::set(v, e, f);
         }
-        *reinterpret_cast<bf16x8*>(Xs + ((size_t)(g8 * XW + pb * 64 + lane)) * 16) = v;
+        *reinterpret_cast<frag*>(Xs + ((size_t)(g8 * XW + pb * 64 + lane)) * 16) = v;
       }
     }
   };
@@ -191,18 +224,17 @@ conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const bf16x8* __restrict_
       const char* Ab = As + ((size_t)(cg * 2 + h) * BM + wm * TM * 32 + l31) * 16;
       const char* Xb = Xs + (size_t)cg * 2 * XW * 16;
       for (int j = 0; j < K; ++j) {
-        bf16x8 a[TM], bb[TN];
+        frag a[TM], bb[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-          a[tm] = *reinterpret_cast<const bf16x8*>(Ab + ((size_t)j * ncg * 2 * BM + tm * 32) * 16);
+          a[tm] = *reinterpret_cast<const frag*>(Ab + ((size_t)j * ncg * 2 * BM + tm * 32) * 16);
         const int xo = j * p.dj * P * 16;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bb[tn] = *reinterpret_cast<const bf16x8*>(Xb + laneoff[tn] + xo);
+        for (int tn = 0; tn < TN; ++tn) bb[tn] = *reinterpret_cast<const frag*>(Xb + laneoff[tn] + xo);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(a[tm], bb[tn], acc[tm][tn]);
       }
     }
     if (more) storeX(cb ^ 1);
@@ -308,7 +340,9 @@ bool eligible(const VcvConvArgs& a) {
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);
 }
 
+template <class EL>
 bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
+  constexpr int KG = 2 * EL::CPG, ESZ = EL::ESZ;  // channels per (h = 0, h = 1) group pair; bytes per element
   pl.BM = BM; pl.BN = BN; pl.NW = NW;
   BfGeom& g = pl.g;
   const int qspan = (BN - 1) / a.P + 1;
@@ -319,7 +353,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
   g.xw = (rowmax + 63) & ~63;
   // chunk depth: 16-channel groups per chunk.  Candidates must fit two LDS buffers (one when a single chunk covers the
   // reduction) and MAXT staging tasks per wave; among them the least zero-padded channel count wins, then the deeper.
-  const int cmax = ((a.Cg + 15) & ~15);
+  const int cmax = ((a.Cg + KG - 1) / KG) * KG;
   // LDS budget: narrow layers (few chunks per workgroup, so nothing inside a workgroup overlaps the staging latency)
   // run two workgroups per CU when a chunk depth fits 78 KiB; measured +40-60 % on the 64-channel generator layers and
   // the first period-discriminator convs, nothing on the deep layers, which take the whole LDS for deeper chunks
@@ -328,23 +362,23 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
   for (int pass = narrow ? 0 : 1; pass < 2 && bkc == 0; ++pass) {
     const size_t lds_cap = (pass == 0 ? 78 : 156) * 1024;
     long long best_pad = 1ll << 60;
-    for (int cand = 64; cand >= 16; cand -= 16) {
+    for (int cand = 64; cand >= KG; cand -= KG) {
       if (cand > cmax) continue;
       const int nch = vcv_cdiv(a.Cg, cand);
-      const size_t buf = (size_t)g.JA * cand * BM * 2 + (size_t)cand * g.xw * 2;
-      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (cand >> 3) * (g.xw >> 6) > MAXT * NW) continue;
+      const size_t buf = (size_t)g.JA * cand * BM * ESZ + (size_t)cand * g.xw * ESZ;
+      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (cand / EL::CPG) * (g.xw >> 6) > MAXT * NW) continue;
       const long long padded = (long long)nch * cand;
       if (padded < best_pad) best_pad = padded, bkc = cand;
     }
   }
   if (bkc == 0) return false;
   g.BKC = bkc;
-  g.ncg = bkc >> 4;
+  g.ncg = bkc / KG;
   g.nch = vcv_cdiv(a.Cg, bkc);
   g.ntu = vcv_cdiv(a.Q * a.P, BN);
   g.nmt = vcv_cdiv(a.Mg, BM);
-  g.a_bytes = g.JA * bkc * BM * 2;
-  g.buf_bytes = g.a_bytes + bkc * g.xw * 2;
+  g.a_bytes = g.JA * bkc * BM * ESZ;
+  g.buf_bytes = g.a_bytes + bkc * g.xw * ESZ;
   pl.lds_bytes = (g.nch > 1 ? 2ull : 1ull) * g.buf_bytes;  // one chunk: no second buffer, more workgroups per CU
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
@@ -356,6 +390,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
 // variants: 0: 128x256 / 8 waves (2x2 per wave)   1: 128x128 / 8 waves (2x1)   2: 128x224 / 14 waves (2x1)
 //           3: 64x256 / 8 waves (1x2... 2x4 waves of 1x2)   4: 64x128 / 8 waves (1x1)   5: 32x256 / 8 waves (1x1)
 //           6: 64x224 / 14 waves (1x1)   7: 128x288 / 9 waves (4x1)
+template <class EL>
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
   if (U < 96) return false;
@@ -363,20 +398,17 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
   bool ok = false;
   if (a.Mg >= 128) {
-    if (U > 160 && U <= 224 && make_plan(a, 128, 224, 14, pl)) pl.variant = 2, ok = true;
-    else if (U > 256 && U <= 288 && make_plan(a, 128, 288, 9, pl)) pl.variant = 7, ok = true;
-    else if (U > 160 && blocks(128, 256) >= 256 && make_plan(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
-    else if (make_plan(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
+    if (U > 160 && U <= 224 && make_plan<EL>(a, 128, 224, 14, pl)) pl.variant = 2, ok = true;
+    else if (U > 256 && U <= 288 && make_plan<EL>(a, 128, 288, 9, pl)) pl.variant = 7, ok = true;
+    else if (U > 160 && blocks(128, 256) >= 256 && make_plan<EL>(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
+    else if (make_plan<EL>(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
   } else if (a.Mg >= 64) {
-    static const int wide64 = getenv("VCVITS_BF16_WIDE64") ? atoi(getenv("VCVITS_BF16_WIDE64")) : 0;
-    if (wide64 && U >= 2048 && blocks(64, 512) >= 256 && make_plan(a, 64, 512, 8, pl)) pl.variant = 9, ok = true;
-    else if (U > 160 && U <= 224 && make_plan(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
-    else if (U > 160 && blocks(64, 256) >= 256 && make_plan(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
-    else if (make_plan(a, 64, 128, 8, pl)) pl.variant = 4, ok = true;
+    if (U > 160 && U <= 224 && make_plan<EL>(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
+    else if (U > 160 && blocks(64, 256) >= 256 && make_plan<EL>(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
+    else if (make_plan<EL>(a, 64, 128, 8, pl)) pl.variant = 4, ok = true;
   } else {
-    static const int wide32 = getenv("VCVITS_BF16_WIDE32") ? atoi(getenv("VCVITS_BF16_WIDE32")) : 1;
-    if (wide32 && U >= 2048 && blocks(32, 512) >= 256 && make_plan(a, 32, 512, 8, pl)) pl.variant = 8, ok = true;
-    else if (make_plan(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
+    if (U >= 2048 && blocks(32, 512) >= 256 && make_plan<EL>(a, 32, 512, 8, pl)) pl.variant = 8, ok = true;
+    else if (make_plan<EL>(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
   }
   if (!ok) return false;
   // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass)
@@ -392,29 +424,29 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   return true;
 }
 
-template <int TM, int TN, int WM, int WN>
-int launch(const VcvConvArgs& a, const Plan& pl, bf16x8* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
+template <class EL, int TM, int TN, int WM, int WN>
+int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, NT = 64 * WM * WN;
   const BfGeom& g = pl.g;
   if (!pack_valid) {
     const size_t total = pl.pack_bytes / 16;
     const int mode = g.phases > 1 ? 2 : (flip ? 1 : 0);
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Mg, a.Cg, a.K,
+    hipLaunchKernelGGL(pack_bf16_kernel<EL>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Mg, a.Cg, a.K,
                        BM, g.BKC, g.JA, g.nch, g.nmt, g.phases, mode, total);
   }
-  void (*kern)(const VcvConvArgs, const BfGeom, const bf16x8*, float*) =
-      a.in_tf == VCV_TF_LEAKY ? conv_bf16_kernel<TM, TN, WM, WN, true, MAXT> : conv_bf16_kernel<TM, TN, WM, WN, false, MAXT>;
+  void (*kern)(const VcvConvArgs, const BfGeom, const typename EL::frag*, float*) =
+      a.in_tf == VCV_TF_LEAKY ? conv_bf16_kernel<EL, TM, TN, WM, WN, true, MAXT> : conv_bf16_kernel<EL, TM, TN, WM, WN, false, MAXT>;
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
   dim3 grid(a.B * g.ntu * g.ks, g.nmt, g.phases), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)(g.phases > 1 ? a.Tin : a.Q);
-  const int tag[12] = {a.B, 2, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
+  const int tag[12] = {a.B, EL::ESZ == 2 ? 2 : 4, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
   const double abytes = 4.0 * ((double)a.B * a.Cg * a.Tin * a.P + (double)a.Mg * a.Cg * a.K +
                                (double)a.B * a.Mg * a.Tout * a.P * (1 + (a.res ? 1 : 0) + (a.oaux ? 1 : 0)));
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, a, g, (const bf16x8*)wp, part);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, a, g, (const typename EL::frag*)wp, part);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
     hipLaunchKernelGGL(conv_bf16_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
@@ -422,42 +454,62 @@ int launch(const VcvConvArgs& a, const Plan& pl, bf16x8* wp, float* part, int fl
   return vcv_check_launch();
 }
 
+// fp32: shapes the LDS-DMA kernel (conv_dma.hip) still runs faster, measured in the step: 32-channel layers and wide
+// k <= 3 layers
+template <class EL>
+bool wanted(const VcvConvArgs& a) {
+  if (EL::ESZ == 2) return true;
+  return a.Cg >= 64 && !(a.K <= 3 && a.Cg >= 128);
+}
+
+template <class EL>
+int plan_t(const VcvConvArgs* args, int flip, int64_t* out) {
+  if (!args || !out || !eligible(*args) || !wanted<EL>(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose<EL>(*args, pl)) return VCV_EINVAL;
+  out[0] = (int64_t)((pl.pack_bytes + 3) / 4);
+  out[1] = (int64_t)pl.scratch_floats;
+  const BfGeom& g = pl.g;
+  out[2] = ((int64_t)(EL::ESZ == 2 ? 2 : 1) << 61) | ((int64_t)pl.BM << 40) | ((int64_t)g.BKC << 28) | ((int64_t)g.JA << 20) |
+           ((int64_t)g.phases << 8) | (flip ? 1 : 0);
+  return 0;
+}
+
+template <class EL>
+int run_t(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream) {
+  if (!args || !pack_ws || !eligible(*args) || !wanted<EL>(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose<EL>(*args, pl)) return VCV_EINVAL;
+  if (pl.g.ks > 1 && !scratch_ws) return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  typename EL::frag* wp = reinterpret_cast<typename EL::frag*>(pack_ws);
+  const bool pv = pack_valid != 0;
+  switch (pl.variant) {
+    case 0: return launch<EL, 2, 2, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 1: return launch<EL, 2, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 2: return launch<EL, 2, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 3: return launch<EL, 1, 2, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 4: return launch<EL, 1, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 5: return launch<EL, 1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 6: return launch<EL, 1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
+    case 8: return launch<EL, 1, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 32 x 512
+    default: return launch<EL, 4, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);
+  }
+}
+
 }  // namespace
 
 // Same calling convention as vcv_conv_dma_plan / vcv_conv_dma_run (include/vcvits_hip.h): out[0] = BYTES / 4 of the
 // packed-weight buffer (so callers allocate it as out[0] fp32 words), out[1] = floats of per-launch scratch, out[2] =
 // signature of the pack layout.
-extern "C" int vcv_conv_bf16_plan(const VcvConvArgs* args, int flip, int64_t* out) {
-  if (!args || !out || !eligible(*args)) return VCV_EINVAL;
-  Plan pl;
-  if (!choose(*args, pl)) return VCV_EINVAL;
-  out[0] = (int64_t)((pl.pack_bytes + 3) / 4);
-  out[1] = (int64_t)pl.scratch_floats;
-  const BfGeom& g = pl.g;
-  out[2] = (1ll << 62) | ((int64_t)pl.BM << 40) | ((int64_t)g.BKC << 28) | ((int64_t)g.JA << 20) | ((int64_t)g.phases << 8) |
-           (flip ? 1 : 0);
-  return 0;
-}
-
+extern "C" int vcv_conv_bf16_plan(const VcvConvArgs* args, int flip, int64_t* out) { return plan_t<Bf16El>(args, flip, out); }
 extern "C" int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
                                  void* stream) {
-  if (!args || !pack_ws || !eligible(*args)) return VCV_EINVAL;
-  Plan pl;
-  if (!choose(*args, pl)) return VCV_EINVAL;
-  if (pl.g.ks > 1 && !scratch_ws) return VCV_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  bf16x8* wp = reinterpret_cast<bf16x8*>(pack_ws);
-  const bool pv = pack_valid != 0;
-  switch (pl.variant) {
-    case 0: return launch<2, 2, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 1: return launch<2, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 2: return launch<2, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 3: return launch<1, 2, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 4: return launch<1, 1, 2, 4>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 5: return launch<1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 6: return launch<1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
-    case 8: return launch<1, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 32 x 512
-    case 9: return launch<2, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 64 x 512
-    default: return launch<4, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);
-  }
+  return run_t<Bf16El>(args, pack_ws, scratch_ws, flip, pack_valid, stream);
+}
+// The same kernel on fp32 elements (4-channel 16-byte groups, v_mfma_f32_32x32x2_f32: exact fp32)
+extern "C" int vcv_conv_pk_plan(const VcvConvArgs* args, int flip, int64_t* out) { return plan_t<F32El>(args, flip, out); }
+extern "C" int vcv_conv_pk_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
+                               void* stream) {
+  return run_t<F32El>(args, pack_ws, scratch_ws, flip, pack_valid, stream);
 }

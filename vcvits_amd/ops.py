@@ -39,6 +39,8 @@ def conv_out_len(tin, k, stride, pad, dil):
 
 
 _USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
+# fp32 launches try the channel-innermost packed kernel (vcv_conv_pk_*) before the LDS-DMA kernel
+_USE_PK = [__import__("os").environ.get("VCVITS_CONV_PK", "1") == "1"]
 
 # Arithmetic of the GEMM-shaped kernels: "f32" (fp32-input MFMA, exact fp32) or "bf16" (operands rounded to bf16 on
 # their way into the matrix cores, fp32 accumulate; activations, master weights, losses and the optimizer stay fp32 --
@@ -47,7 +49,7 @@ _COMPUTE = ["f32"]
 
 
 # which kernel family each GEMM-shaped launch went to (tests assert that the bf16 path really ran)
-LAUNCH_COUNTS = {"bf16": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad": 0}
+LAUNCH_COUNTS = {"bf16": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad": 0}
 
 
 def set_compute_dtype(name):
@@ -74,6 +76,8 @@ def _launch_conv(a, flip_w=None):
         flip = 1 if flip_w is not None else 0
         plan = (ctypes.c_int64 * 3)()
         families = ((L.vcv_conv_bf16_plan, L.vcv_conv_bf16_run, "vcv_conv_bf16_run"),) if _COMPUTE[0] == "bf16" else ()
+        if _USE_PK[0]:
+            families += ((L.vcv_conv_pk_plan, L.vcv_conv_pk_run, "vcv_conv_pk_run"),)
         families += ((L.vcv_conv_dma_plan, L.vcv_conv_dma_run, "vcv_conv_dma_run"),)
         for plan_fn, run_fn, name in families:
             if plan_fn(ctypes.byref(a), flip, plan) != 0:
@@ -89,7 +93,7 @@ def _launch_conv(a, flip_w=None):
                     packs[key] = pack
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
             check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
-            LAUNCH_COUNTS["bf16" if name == "vcv_conv_bf16_run" else "dma"] += 1
+            LAUNCH_COUNTS["bf16" if name == "vcv_conv_bf16_run" else "pk" if name == "vcv_conv_pk_run" else "dma"] += 1
             return
         if flip_w is not None:
             a.w = saved
@@ -209,6 +213,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         _common(a, **kw)
         a.w = ptr(w)
         if _USE_DMA[0] and ((_COMPUTE[0] == "bf16" and lib().vcv_conv_bf16_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0)
+                            or (_USE_PK[0] and lib().vcv_conv_pk_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0)
                             or lib().vcv_conv_dma_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0):
             _launch_conv(a, flip_w=w)
             return out
