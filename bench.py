@@ -37,8 +37,12 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 # algorithmic GFLOP per utterance (4 G + 9 D1, reference semantics); infer: per 10 s utterance
 GFLOP_PER_UTT = {("base", "vocoder"): 400.0, ("base", "full"): 488.0, ("48k", "vocoder"): 536.0, ("48k", "full"): 560.0,
                  ("48k", "infer"): 770.0, ("base", "infer"): 788.0}
+# profiler classes of the library (csrc/prof.h) and the kernel families (rocprofv3 names) each one times
 PROF_CLASSES = ["conv_gemm_kernel (register-staged)", "conv_wgrad_kernel (register-staged)",
-                "conv_dma_kernel (fwd + dgrad + convT, LDS-DMA staging, all tile variants)", "wgrad_dma_kernel"]
+                "packed-weight conv kernels: fwd + dgrad + convT (conv_pk_kernel<F32El | Bf16El>, conv_dma_kernel)",
+                "weight-gradient kernels (wgrad_dma_kernel, wgrad_bf16_kernel)"]
+PROF_FAMILIES = [["conv_gemm_kernel"], ["conv_wgrad_kernel"], ["conv_pk_kernel", "conv_dma_kernel"],
+                 ["wgrad_dma_kernel", "wgrad_bf16_kernel"]]
 
 
 def kernel_source_hash():
@@ -51,11 +55,11 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def profiled_traffic(kernel_family, workload_key):
-    """HBM bytes per launch of `kernel_family` from the newest committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
-    written by tools/profile_summary.py -- PMC counters cannot be read from inside this process).  Returns
-    (bytes, source, stale): a file recorded for other kernel sources or another workload is reported as stale and its
-    number withheld."""
+def profiled_traffic(families, workload_key):
+    """HBM bytes per launch of the kernel `families` of one profiler class (launch-weighted mean) from the newest
+    committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json, written by tools/profile_summary.py -- PMC counters
+    cannot be read from inside this process).  Returns (bytes, source, stale): a file recorded for other kernel sources
+    or another workload is reported as stale and its number withheld."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
     for f in reversed(files):
         try:
@@ -64,13 +68,15 @@ def profiled_traffic(kernel_family, workload_key):
             continue
         if d.get("workload", "base/vocoder/f32") != workload_key:
             continue
-        fam = d.get("kernels", {d.get("kernel", ""): d}).get(kernel_family)
-        if fam is None:
+        fams = [d.get("kernels", {}).get(k) for k in families]
+        fams = [k for k in fams if k]
+        if not fams:
             continue
         src = os.path.relpath(f, ROOT)
         if d.get("kernel_source_hash") != kernel_source_hash():
             return None, src, True
-        return round(fam["hbm_bytes_per_launch"]), src, False
+        n = sum(k["launches_profiled"] for k in fams)
+        return round(sum(k["launches_profiled"] * k["hbm_bytes_per_launch"] for k in fams) / n), src, False
     return None, None, False
 
 
@@ -278,8 +284,8 @@ def main():
         if fams:
             # the dominant kernel family by time carries the roofline; the others ride along for the record
             dom = max(fams, key=lambda c: c["share_of_step_time"])
-            fam_name = dom["kernel"].split(" ")[0]
-            traffic, traffic_src, stale = profiled_traffic(fam_name, "%s/%s/%s" % (a.config, a.workload, a.dtype))
+            traffic, traffic_src, stale = profiled_traffic(PROF_FAMILIES[PROF_CLASSES.index(dom["kernel"])],
+                                                           "%s/%s/%s" % (a.config, a.workload, a.dtype))
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": traffic_src, "traffic_stale": stale,

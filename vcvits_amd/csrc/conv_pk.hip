@@ -1,4 +1,4 @@
-// conv_bf16.hip -- channel-innermost packed-operand implicit-GEMM convolution (forward-type and phased launches, the
+// conv_pk.hip -- channel-innermost packed-operand implicit-GEMM convolution (forward-type and phased launches, the
 // same launch family conv_dma.hip covers), in two element types:
 //   bf16 (vcv_conv_bf16_*): v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM;
 //   fp32 (vcv_conv_pk_*):   the same kernel on 4-channel 16-byte groups and v_mfma_f32_32x32x2_f32 (exact fp32): one
@@ -78,7 +78,7 @@ struct BfGeom {
 // mode 2: w is [C, M, K], residue r = phase keeps taps k = r + j*phases (ConvTranspose forward / strided dgrad)
 template <class EL>
 __global__ void __launch_bounds__(256)
-pack_bf16_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, int M, int C, int K, int BM, int BKC, int JA,
+pack_pk_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, int M, int C, int K, int BM, int BKC, int JA,
                  int nch, int nmt, int phases, int mode, size_t total) {
   constexpr int CPG = EL::CPG;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -111,7 +111,7 @@ pack_bf16_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp
 
 template <class EL, int TM, int TN, int WM, int WN, bool LEAKY, int MAXT>
 __global__ void __launch_bounds__(64 * WM * WN)
-conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __restrict__ wp, float* __restrict__ part) {
+conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
   constexpr int CPG = EL::CPG;
   typedef typename EL::frag frag;
@@ -296,7 +296,7 @@ conv_bf16_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* 
 }
 
 // Adds the ks partial slabs of a split launch and applies the epilogue.
-__global__ void __launch_bounds__(256) conv_bf16_finish_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
+__global__ void __launch_bounds__(256) conv_pk_finish_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
   const int U = p.Q * p.P;
   const size_t n = (size_t)p.B * p.Mg * U;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -431,11 +431,11 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   if (!pack_valid) {
     const size_t total = pl.pack_bytes / 16;
     const int mode = g.phases > 1 ? 2 : (flip ? 1 : 0);
-    hipLaunchKernelGGL(pack_bf16_kernel<EL>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Mg, a.Cg, a.K,
+    hipLaunchKernelGGL(pack_pk_kernel<EL>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Mg, a.Cg, a.K,
                        BM, g.BKC, g.JA, g.nch, g.nmt, g.phases, mode, total);
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const typename EL::frag*, float*) =
-      a.in_tf == VCV_TF_LEAKY ? conv_bf16_kernel<EL, TM, TN, WM, WN, true, MAXT> : conv_bf16_kernel<EL, TM, TN, WM, WN, false, MAXT>;
+      a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, MAXT> : conv_pk_kernel<EL, TM, TN, WM, WN, false, MAXT>;
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
@@ -449,7 +449,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, a, g, (const typename EL::frag*)wp, part);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
-    hipLaunchKernelGGL(conv_bf16_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
+    hipLaunchKernelGGL(conv_pk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
   }
   return vcv_check_launch();
 }
