@@ -397,11 +397,32 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   const int nph = a.phases > 1 ? a.phases : 1;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
   bool ok = false;
+  // fill of the last round of 256 workgroups x useful columns of the position tiles
+  auto eff2 = [&](int bm, int bn) {
+    const long long nb = blocks(bm, bn);
+    const long long rounds = (nb + 255) / 256;
+    return ((double)U / ((double)vcv_cdiv(U, bn) * bn)) * ((double)nb / (double)(rounds * 256));
+  };
   if (a.Mg >= 128) {
-    if (U > 160 && U <= 224 && make_plan<EL>(a, 128, 224, 14, pl)) pl.variant = 2, ok = true;
+    // (the 3-phase data gradients of the 512-channel period layers: 384 tiles of 128 rows run 1.5 rounds, 768 of 64 rows 3)
+    if (U > 160 && U <= 224 && eff2(64, 224) > eff2(128, 224) + 0.2 && make_plan<EL>(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
+    else if (U > 160 && U <= 224 && make_plan<EL>(a, 128, 224, 14, pl)) pl.variant = 2, ok = true;
     else if (U > 256 && U <= 288 && make_plan<EL>(a, 128, 288, 9, pl)) pl.variant = 7, ok = true;
-    else if (U > 160 && blocks(128, 256) >= 256 && make_plan<EL>(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
-    else if (make_plan<EL>(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
+    else {
+      // tile width by efficiency = (useful columns of the position tiles) x (fill of the last round of 256 workgroups):
+      // the 128 -> 512 period layers have 608-629 positions per batch element: 3 tiles of 256 waste a fifth of the
+      // columns and 384 workgroups run 1.5 rounds (0.59), 2 tiles of 320 waste 3-5 % in exactly one round (0.95)
+      auto eff = [&](int bn) {
+        const long long nb = blocks(128, bn);
+        const long long rounds = (nb + 255) / 256;
+        return ((double)U / ((double)vcv_cdiv(U, bn) * bn)) * ((double)nb / (double)(rounds * 256));
+      };
+      const double e256 = (U > 160 && blocks(128, 256) >= 256) ? eff(256) : 0.0, e128 = eff(128);
+      const double e320 = (U > 320 && blocks(128, 320) >= 160) ? eff(320) : 0.0;
+      if (e320 > e256 + 0.08 && e320 > e128 + 0.08 && make_plan<EL>(a, 128, 320, 8, pl)) pl.variant = 11, ok = true;
+      else if (e256 > 0.0 && make_plan<EL>(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
+      else if (make_plan<EL>(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
+    }
   } else if (a.Mg >= 64) {
     if (U > 160 && U <= 224 && make_plan<EL>(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
     else if (U > 160 && blocks(64, 256) >= 256 && make_plan<EL>(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
@@ -493,6 +514,7 @@ int run_t(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, 
     case 5: return launch<EL, 1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 6: return launch<EL, 1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 8: return launch<EL, 1, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 32 x 512
+    case 11: return launch<EL, 1, 5, 4, 2>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 320: 8 waves of 32 rows x 5 column tiles
     default: return launch<EL, 4, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);
   }
 }
