@@ -432,10 +432,14 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     else if (make_plan<EL>(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
   }
   if (!ok) return false;
-  // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass)
+  // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass),
+  // aiming at one full round of resident workgroups (256 x the workgroups a CU holds at this LDS footprint)
   const long long nb = blocks(pl.BM, pl.BN);
   if (nph == 1 && nb < 192 && pl.g.nch >= 4) {
-    long long ks = (384 + nb - 1) / nb;
+    // (bf16 chunks are short enough that the finishing pass outweighs a second resident round: measured, it keeps
+    // the flat 384 target)
+    const long long target = pl.lds_bytes * 2 <= VCV_LDS_LIMIT ? 512 : 256;
+    long long ks = EL::ESZ == 4 ? (target + nb / 2) / nb : (384 + nb - 1) / nb;
     if (ks > pl.g.nch / 2) ks = pl.g.nch / 2;
     if (ks >= 2) {
       pl.g.ks = (int)ks;
