@@ -1,56 +1,217 @@
-// wgrad_dma.hip -- LDS-DMA variant of the MFMA weight-gradient kernel (see conv_wgrad.hip for the GEMM
-// mapping: M = channels of the un-shifted operand, N = (c, k) in the weight's memory order, reduction over
-// positions, split over the grid and combined with fp32 atomics).
+// wgrad_dma.hip -- the MFMA weight-gradient kernel of the fp32 path (see conv_wgrad.hip for the GEMM mapping: M =
+// channels of the un-shifted operand, N = (c, k) in the weight's memory order, reduction over positions, split over
+// the grid and combined with fp32 atomics or per-split slabs).
 //
-// Both operands are activations, so nothing needs packing: per stage of 64 positions
-//   As[m][u]   one `buffer_load_dword ... lds` per channel row (64 floats; rows past M and positions past
-//              the sequence end are zero-filled by the descriptor's range check); the odd row pitch makes
-//              the A-fragment read (lane -> consecutive m) conflict-free without a transpose pass;
-//   Xs[c][span] the shifted operand's contiguous span per channel (all K taps read it at their offset);
-// double-buffered: the DMA of stage s+1 runs under the MFMA loop of stage s, one barrier per stage, no
-// staging registers.  Input leaky-ReLU (ResBlock / generator convs) is applied to the fragments as read.
+// Both operands are activations, so nothing needs packing.  Per stage of 64 positions u = q*P + pc the LDS holds
+//   As[m][u]     the un-shifted operand, row pitch 68 floats (rows past M and positions past the sequence end zero);
+//   Xs[c][f]     the shifted operand's contiguous span of every channel of the column tile: all taps and all
+//                positions of the stage read it at their offsets (floats outside the sequence are zero).
+// Unit stride: tap k of position u sits at Xs[c][u + k*dj*P + const], so a lane reads FOUR consecutive positions of
+// its row / column with one ds_read_b128 (the B side at 4-byte alignment, which the LDS serves at full rate --
+// tools/scratch/lds_probe.hip) and feeds four v_mfma_f32_32x32x2_f32 per fragment pair: a quarter of the LDS
+// instructions of a dword-per-MFMA loop.  Strided launches (the period discriminators' s = 3 convs, the generator's
+// transposed convs) jump by (s-1)*P floats where the positions wrap to the next row: their B side reads dwords at a
+// per-position offset table the producers write beside the stage (the A side still reads 16 bytes).
+//
+// Warp-specialised: NW MFMA waves + NP producer waves per workgroup.  The producers stage with 16-byte buffer loads
+// into registers and 16-byte ds_writes; the loads of stage s+2 are issued as soon as stage s+1 is written, while
+// stage s is multiplied.  What was measured on the way here (DiscP conv4 / conv3 weight gradients, TFLOP/s):
+//   every wave issues `buffer_load_dword ... lds` DMAs at the top of its stage        83 / 59  (the issue phase -- ~12
+//       cycles per DMA instruction -- and the MFMA phase of a stage add up: all waves leave the barrier together)
+//   the same DMAs handed out between the MFMA groups                                  66 / 40
+//   the DMAs issued by producer waves                                                 98 / 65  (a dword DMA holds
+//       the LDS write port long enough to stall the fragment reads: with the X DMAs off 97, with 16-byte ds_writes
+//       of the same bytes in their place 91)
+//   register-staged producers that de-interleave strided rows by residue as they write                104 / 65
+//       (~25 VALU instructions per element: one producer wave per SIMD cannot keep up)
+// One barrier per stage; input leaky-ReLU (ResBlock / generator convs) is applied to the fragments as read.
 #include "common.h"
 #include "prof.h"
 
 namespace {
 
-constexpr int BU = 64, AP = BU + 1;
-typedef __attribute__((address_space(3))) void* lds_ptr;
+constexpr int BU = 64, AP = BU + 4, MAXX = 12, TABN = BU + 32;
 
 struct WgGeom {
-  int NCH, nXrow, XP, nmt, nnt, Z, nchunk_u, buf_floats, a_floats;
+  int NCH, CP, emin, G4, nmt, nnt, Z, nchunk_u, buf_floats, a_floats, tab_floats, dbg;
+  float invG4, invP;
 };
 
-template <int TM, int TN, int WM, int WN, bool LA, bool LB, bool BIAS>
-__global__ void __launch_bounds__(64 * WM * WN)
+// The fragment reads are inline asm (the compiler splits a 4-byte-aligned 16-byte LDS load into dword pairs), so
+// their completion is waited for by hand: `s_waitcnt lgkmcnt(0)` followed by an empty asm that redefines the
+// fragment registers, which keeps every MFMA that consumes them behind the wait.
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_rd128(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ float lds_rd32(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pin(f32x4& f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ void pin(float& f) { asm volatile("" : "+v"(f)); }
+template <typename T, int N>
+__device__ __forceinline__ void pin(T (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) pin(f[i]);
+}
+// n / d and n % d for 0 <= n < 2^22 with inv = 1.0f / d (one correction step makes the float quotient exact)
+__device__ __forceinline__ void divmod(int n, int d, float inv, int& q, int& r) {
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  if (r < 0) r += d, --q;
+  if (r >= d) r -= d, ++q;
+}
+__device__ __forceinline__ f32x4 ld128(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+template <int TM, int TN, int WM, int WN, bool LA, bool LB, bool BIAS, bool STR>
+__global__ void __launch_bounds__(64 * (WM * WN + (WM * WN >= 8 ? 4 : 2)))
 wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NP = NW >= 8 ? 4 : 2;
+  constexpr int MAXA = BM / (4 * NP);  // 16-byte loads per producer lane that cover the A tile
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
 
   const int nt = blockIdx.x, mt = blockIdx.y, z = blockIdx.z;
   const int K = p.K, Cg = p.Cg, Mg = p.Mg, P = p.P;
   const int N = Cg * K;
   const int n0 = nt * BN, m0 = mt * BM;
   const int cfirst = n0 / K;
-  const int XP = tg.XP, NCH = tg.NCH, nXrow = tg.nXrow;
+  const int CP = tg.CP, NCH = tg.NCH;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const int U = p.Ta * P, TbP = p.Tb * P;
+  const int total = p.B * tg.nchunk_u;
+  if (z >= total) return;
+  // first float of the X span of a stage inside its channel row (the image starts at this rounded down to a multiple
+  // of four: a 16-byte group that begins before the buffer is zero as a whole, so none may straddle the row start)
+  auto xspan0 = [&](int uc0) __attribute__((always_inline)) {
+    return STR ? ((uc0 / P) * p.s + tg.emin) * P : uc0 + tg.emin * P;
+  };
 
-  int nofs[TN];
+  if (wave >= NW) {
+    // ------------------------------------------------------------------------------------------ producer waves
+    const int pw = wave - NW;
+    __builtin_amdgcn_s_setprio(3);  // few instructions, all of them on the critical path of the next stage
+    f32x4 ra[MAXA], rx[MAXX];
+    const int ngx = NCH * tg.G4;  // 16-byte groups of the X image of a stage
+    // this lane's X groups: float offset inside the batch item's channel block, byte offset inside the LDS image
+    // (groups past the image are loaded from offset 0 and written to a scratch slot behind the table)
+    int xld[MAXX], xi4[MAXX];
+    unsigned xst[MAXX];
+#pragma unroll
+    for (int t = 0; t < MAXX; ++t) {
+      const int idx = (t * NP + pw) * 64 + lane;
+      int cl, i4;
+      divmod(idx, tg.G4, tg.invG4, cl, i4);
+      xi4[t] = 4 * i4;
+      xld[t] = idx < ngx ? cl * TbP + 4 * i4 : 0x20000000;
+      xst[t] = (unsigned)(idx < ngx ? tg.a_floats + cl * CP + 4 * i4 : tg.a_floats + tg.tab_floats + NCH * CP) * 4u;
+    }
+    if (STR && pw == 1 && lane < TABN - BU) {  // the table's spare entries (read one group ahead, never used)
+      asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + (unsigned)(tg.a_floats + NCH * CP + BU + lane) * 4u), "v"(0) : "memory");
+      asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + (unsigned)(tg.buf_floats + tg.a_floats + NCH * CP + BU + lane) * 4u), "v"(0)
+                   : "memory");
+    }
+    auto store = [&](int ch, int buf) __attribute__((always_inline)) {
+      const int b = ch / tg.nchunk_u;
+      const int uc0 = (ch - b * tg.nchunk_u) * BU;
+      const unsigned base = lds0 + (unsigned)(buf * tg.buf_floats) * 4u;
+      const bool tail = uc0 + BU > U;
+#pragma unroll
+      for (int t = 0; t < MAXA; ++t) {
+        const int row = (t * NP + pw) * 4 + (lane >> 4), c4 = lane & 15;
+        f32x4 v = ra[t];
+        if (tail) {
+          const int nv = U - uc0 - 4 * c4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = e < nv ? v[e] : 0.f;
+        }
+        asm volatile("ds_write_b128 %0, %1" ::"v"(base + (unsigned)(row * AP + 4 * c4) * 4u), "v"(v) : "memory");
+      }
+      const int f0 = xspan0(uc0), f0a = f0 & ~3;
+      if (STR && pw == 0) {
+        // byte offset of position uc0 + lane inside a channel's image: its row advances s rows per q
+        int q, pc;
+        divmod(uc0 + lane, P, tg.invP, q, pc);
+        const int off = ((q - uc0 / P) * p.s * P + pc + (f0 - f0a)) * 4;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)(tg.a_floats + NCH * CP + lane) * 4u), "v"(uc0 + lane < U ? off : 0)
+                     : "memory");
+      }
+      if (tg.dbg == 4) return;
+      const bool edge = f0a < 0 || f0a + 4 * tg.G4 > TbP;
+#pragma unroll
+      for (int t = 0; t < MAXX; ++t) {
+        if ((t * NP + pw) * 64 < ngx) {
+          f32x4 v = rx[t];
+          if (edge) {
+            const int f = f0a + xi4[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (unsigned)(f + e) < (unsigned)TbP ? v[e] : 0.f;
+          }
+          asm volatile("ds_write_b128 %0, %1" ::"v"(base + xst[t]), "v"(v) : "memory");
+        }
+      }
+    };
+    auto load = [&](int ch) __attribute__((always_inline)) {
+      const int b = ch / tg.nchunk_u;
+      const int uc0 = (ch - b * tg.nchunk_u) * BU;
+      __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + ((size_t)b * Mg + m0) * (size_t)U), 0,
+                                                                    (int)((size_t)(Mg - m0) * U * 4), 0x00020000);
+#pragma unroll
+      for (int t = 0; t < MAXA; ++t) {
+        const int row = (t * NP + pw) * 4 + (lane >> 4);
+        ra[t] = ld128(rA, (unsigned)(row * U + uc0 + 4 * (lane & 15)) * 4u);
+      }
+      if (tg.dbg == 4) return;
+      const int f0a = xspan0(uc0) & ~3;
+      __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + ((size_t)b * Cg + cfirst) * (size_t)TbP), 0,
+                                                                    (int)((size_t)(Cg - cfirst) * TbP * 4), 0x00020000);
+#pragma unroll
+      for (int t = 0; t < MAXX; ++t)
+        if ((t * NP + pw) * 64 < ngx) rx[t] = ld128(rX, (unsigned)(xld[t] + f0a) * 4u);
+    };
+    load(z);
+    store(z, 0);
+    if (z + tg.Z < total) load(z + tg.Z);
+    int bufi = 0;
+    for (int ch = z; ch < total; ch += tg.Z) {
+      lds_wait();
+      __syncthreads();
+      if (ch + tg.Z < total && tg.dbg != 1) {
+        store(ch + tg.Z, bufi ^ 1);
+        if (ch + 2 * tg.Z < total) load(ch + 2 * tg.Z);
+      }
+      bufi ^= 1;
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- MFMA waves
+  const int wm = wave / WN, wn = wave % WN;
+  // byte offsets of this lane's fragment rows inside a stage buffer (the lane's half h reads positions 4h..4h+3 of
+  // every group of eight)
+  unsigned aofs[TM], nofs[TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) aofs[tm] = (unsigned)(((wm * TM + tm) * 32 + l31) * AP + 4 * h) * 4u;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     int n = n0 + (wn * TN + tn) * 32 + l31;
     if (n > N - 1) n = N - 1;
     const int c = n / K, kw = n - c * K;
-    nofs[tn] = (c - cfirst) * XP + kw * p.dj * P;
+    const int e = kw * p.dj + p.off - tg.emin;  // >= 0: rows below the span's first row
+    // unit stride: position i of the stage sits i floats further (plus the span's round-down, the same for every
+    // stage: the stages start at multiples of 64); strided: the per-position table holds the rest
+    nofs[tn] = (unsigned)(tg.a_floats + (c - cfirst) * CP + e * P + (STR ? 0 : ((tg.emin * P) & 3) + 4 * h)) * 4u;
   }
-  const int jspan = (K - 1) * p.dj;
-  const int jmin = jspan < 0 ? jspan : 0;
-  const long long U = (long long)p.Ta * P;
-  const long long TbP = (long long)p.Tb * P;
-  const int total = p.B * tg.nchunk_u;
+  const unsigned tabofs = (unsigned)(tg.a_floats + NCH * CP + 4 * h) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -66,82 +227,100 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) bsum[tm] = 0.f;
 
-  auto issue = [&](int ch, int buf) {
-    float* As = smem + buf * tg.buf_floats;
-    float* Xs = As + tg.a_floats;
-    int* tab = (int*)(Xs + NCH * XP);
-    const int b = ch / tg.nchunk_u;
-    const int uc0 = (ch - b * tg.nchunk_u) * BU;
-    const int qa = uc0 / P;
-    const int f0 = (qa * p.s + p.off + jmin) * P;
-    const float* ab = p.a + ((size_t)b * Mg + m0) * (size_t)U;
-    const unsigned avoff = (unsigned)(uc0 + lane) * 4u;
-    for (int i = wave; i < BM; i += NW) {
-      const unsigned rec = (m0 + i < Mg) ? (unsigned)(U * 4) : 0u;
-      __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(ab + (size_t)i * (size_t)U), 0, (int)rec, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(As + i * AP), 4, avoff, 0, 0, 0);
-    }
-    const float* xb = p.b + ((size_t)b * Cg + cfirst) * (size_t)TbP;
-    const int nX = NCH * nXrow;
-    for (int i = wave; i < nX; i += NW) {
-      const int cl = i / nXrow, part = i - cl * nXrow;
-      const unsigned rec = (cfirst + cl < Cg) ? (unsigned)(TbP * 4) : 0u;
-      __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)cl * (size_t)TbP), 0, (int)rec, 0x00020000);
-      const unsigned voff = (unsigned)(f0 + part * 64 + lane) * 4u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(Xs + cl * XP + part * 64), 4, voff, 0, 0, 0);
-    }
-    if (tid < BU) {
-      const long long u = (long long)uc0 + tid;
-      int t = 0;
-      if (u < U) {
-        const int q = (int)(u / P), pc = (int)(u - (long long)q * P);
-        t = ((q - qa) * p.s - jmin) * P + pc;
-      }
-      tab[tid] = t;
-    }
-  };
+  int bufi = 0;
+  for (int ch = z; ch < total; ch += tg.Z) {
+    __syncthreads();
+    if (tg.dbg == 2) { bufi ^= 1; continue; }
+    const unsigned base = lds0 + (unsigned)(bufi * tg.buf_floats) * 4u;
+    const int uc0 = (ch % tg.nchunk_u) * BU;
+    // a sequence's last stage multiplies only the sixteen-position groups that hold positions
+    const int rem = U - uc0;
+    const int npair = rem >= BU ? BU / 16 : (rem + 15) >> 4;
+    unsigned aad[TM], bad[TN], tad = base + tabofs;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) aad[tm] = base + aofs[tm];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bad[tn] = base + nofs[tn];
 
-  if (z < total) {
-    issue(z, 0);
-    int bufi = 0;
-    for (int ch = z; ch < total; ch += tg.Z) {
-      __syncthreads();
-      if (ch + tg.Z < total) issue(ch + tg.Z, bufi ^ 1);
-      const float* As = smem + bufi * tg.buf_floats;
-      const float* Xs = As + tg.a_floats;
-      const int* tab = (const int*)(Xs + NCH * XP);
-#pragma unroll 4
-      for (int i = 0; i < BU; i += 2) {
-        const int ul = i + h;
-        const int bofs = tab[ul];
-        float a[TM], bb[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          float v = As[((wm * TM + tm) * 32 + l31) * AP + ul];
-          if (LA) v = fmaxf(v, v * p.slope);
-          a[tm] = v;
-          if (BIAS && do_bias) bsum[tm] += v;
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          float v = Xs[nofs[tn] + bofs];
-          if (LB) v = fmaxf(v, v * p.slope);
-          bb[tn] = v;
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
-      }
-      bufi ^= 1;
+    // (strided: the dword reads land in scalar registers b0s / b1s -- an asm output that is then moved into a vector
+    // element would be copied before its data has arrived)
+    f32x4 a0[TM], a1[TM], b0[TN], b1[TN], t0, t1;
+    float b0s[TN][4], b1s[TN][4];
+#define WG_LOAD(A, Bf, T, OFF)                                                                  \
+  {                                                                                             \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm] = lds_rd128<OFF>(aad[tm]);          \
+    if (!STR) {                                                                                 \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bf[tn] = lds_rd128<OFF>(bad[tn]);       \
+    } else {                                                                                    \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
+          Bf##s[tn][e] = lds_rd32(bad[tn] + __float_as_uint(T[e]));                             \
+    }                                                                                           \
+  }
+#define WG_MMA(A, Bf)                                                                                              \
+  {                                                                                                                \
+    if (LA) {                                                                                                      \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int e = 0; e < 4; ++e)              \
+          A[tm][e] = fmaxf(A[tm][e], A[tm][e] * p.slope);                                                          \
+    }                                                                                                              \
+    if (LB) {                                                                                                      \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int e = 0; e < 4; ++e) {            \
+        if (STR) Bf##s[tn][e] = fmaxf(Bf##s[tn][e], Bf##s[tn][e] * p.slope);                                       \
+        else Bf[tn][e] = fmaxf(Bf[tn][e], Bf[tn][e] * p.slope);                                                    \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (BIAS && do_bias) {                                                                                         \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) bsum[tm] += (A[tm][0] + A[tm][1]) + (A[tm][2] + A[tm][3]); \
+    }                                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                          \
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][e], STR ? Bf##s[tn][e] : Bf[tn][e], acc[tm][tn], 0, 0, 0); \
+  }
+#define PIN_S(B) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int e = 0; e < 4; ++e) pin(B[tn][e]);
+    // strided: the table entries of a group are read one group ahead of the fragments they address (the table has
+    // 32 spare entries, so the reads past the stage stay inside it)
+    if (STR) {
+      t0 = lds_rd128<0>(tad);
+      lds_wait();
+      pin(t0);
+      t1 = lds_rd128<32>(tad);
     }
+    WG_LOAD(a0, b0, t0, 0)
+    lds_wait();
+    pin(a0);
+    if (STR) { PIN_S(b0s) pin(t1); } else pin(b0);
+    for (int pr = 0; pr < npair; ++pr) {
+      // (the last pair's second load reads the eight floats after the stage: in the buffer, never multiplied)
+      WG_LOAD(a1, b1, t1, 32)
+      if (STR) t0 = lds_rd128<64>(tad);
+      WG_MMA(a0, b0)
+      lds_wait();
+      pin(a1);
+      if (STR) { PIN_S(b1s) pin(t0); } else pin(b1);
+      WG_LOAD(a0, b0, t0, 64)
+      if (STR) t1 = lds_rd128<96>(tad);
+      WG_MMA(a1, b1)
+      lds_wait();
+      pin(a0);
+      if (STR) { PIN_S(b0s) pin(t1); } else pin(b0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) aad[tm] += 64;
+      if (!STR) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bad[tn] += 64;
+      }
+      tad += 64;
+    }
+#undef PIN_S
+#undef WG_MMA
+#undef WG_LOAD
+    bufi ^= 1;
   }
 
+  if (tg.dbg == 3) return;
   if (do_bias) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      const float s2 = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);  // the two position parities of the lane halves
+      const float s2 = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);  // the two position halves of the lane halves
       const int ml = m0 + (wm * TM + tm) * 32 + l31;
       if (h == 0 && ml < Mg) unsafeAtomicAdd(p.dbias + ml, s2);
     }
@@ -173,23 +352,36 @@ __global__ void __launch_bounds__(256) wgrad_slab_finish_kernel(const float* __r
   dw[i] += alpha * s;
 }
 
-template <int TM, int TN, int WM, int WN>
-int launch(const VcvWgradArgs& a, hipStream_t st) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+template <int TM, int TN, int WM, int WN, bool STR>
+int launch2(const VcvWgradArgs& a, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NP = WM * WN >= 8 ? 4 : 2, NT = 64 * (WM * WN + NP);
   WgGeom g;
   const int N = a.Cg * a.K;
   g.nnt = vcv_cdiv(N, BN);
   g.nmt = vcv_cdiv(a.Mg, BM);
   g.NCH = (BN - 1) / a.K + 2;
   if (g.NCH > a.Cg + 1) g.NCH = a.Cg + 1;
-  const int qspan = (BU - 1) / a.P + 1;
-  const int adj = a.dj < 0 ? -a.dj : a.dj;
-  const int rowmax = (qspan * a.s + (a.K - 1) * adj + 1) * a.P;
-  g.nXrow = (rowmax + 63) / 64;
-  const int want = (a.K * adj * a.P) % 32;
-  g.XP = g.nXrow * 64 + want;  // pitch == K*dj*P (mod 32): the (c, k) columns of a B fragment hit distinct banks
+  // tap row offsets k*dj + off span emin .. emin + emax rows
+  const int jspan = (a.K - 1) * a.dj;
+  g.emin = a.off + (jspan < 0 ? jspan : 0);
+  const int emax = jspan < 0 ? -jspan : jspan;
+  // floats of a channel row a stage reads: the rows of its positions (the first one partial in strided launches, whose
+  // spans start at a row start) plus the taps' rows
+  const int nq = STR ? (a.P - 1 + BU - 1) / a.P + 1 : 0;
+  const int span = STR ? ((nq - 1) * a.s + emax + 1) * a.P : BU + emax * a.P;
+  g.G4 = (span + 3 + 3) / 4;  // + up to three floats of round-down at the start
+  // channel pitch: the (c, k) columns of a B fragment start |dj|*P floats apart inside a channel; step the channels by
+  // about K of those modulo the 64 banks
+  int want = (a.K * (emax / (a.K > 1 ? a.K - 1 : 1)) * a.P + 3) / 4 * 4 % 64;
+  if (want < 8) want = 8;
+  g.CP = 4 * g.G4;
+  while (g.CP % 64 != want % 64) g.CP += 4;
+  if (g.CP - 4 * g.G4 > 32) g.CP = 4 * g.G4 + 4;
+  g.invG4 = 1.0f / (float)g.G4, g.invP = 1.0f / (float)a.P;
+  if ((long long)g.NCH * g.G4 > (long long)MAXX * NP * 64) return -100;
   g.a_floats = BM * AP;
-  g.buf_floats = g.a_floats + g.NCH * g.XP + BU;
+  g.tab_floats = TABN;
+  g.buf_floats = g.a_floats + g.NCH * g.CP + g.tab_floats + 16;
   const size_t lds = 2ull * g.buf_floats * 4;
   if (lds > VCV_LDS_LIMIT) return -100;
   const long long U = (long long)a.Ta * a.P;
@@ -211,17 +403,18 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
     if (cost < best - 1e-9) best = cost, Z = z;
   }
   g.Z = (int)Z;
+  g.dbg = getenv("WG_DBG") ? atoi(getenv("WG_DBG")) : 0;
   const bool la = a.a_tf == VCV_TF_LEAKY, lb = a.b_tf == VCV_TF_LEAKY;
   // the bias-collecting variant exists for the transform-free `a` operand only (a Conv's dy)
   void (*kern)(const VcvWgradArgs, const WgGeom) =
-      la ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, true, true, false> : wgrad_dma_kernel<TM, TN, WM, WN, true, false, false>)
-         : (a.dbias ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, true> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, true>)
-                    : (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, false> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, false>));
+      la ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, true, true, false, STR> : wgrad_dma_kernel<TM, TN, WM, WN, true, false, false, STR>)
+         : (a.dbias ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, true, STR> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, true, STR>)
+                    : (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, false, STR> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, false, STR>));
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VCV_EHIP;
   dim3 grid(g.nnt, g.nmt, g.Z), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
-  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, BM * 1000 + BN, g.nXrow};
+  const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, BM * 1000 + BN, g.G4};
   hipEvent_t ev0, ev1;
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
@@ -232,27 +425,34 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
   return vcv_check_launch();
 }
 
+template <int TM, int TN, int WM, int WN>
+int launch(const VcvWgradArgs& a, hipStream_t st) {
+  static const bool force = getenv("WG_FORCESTR") != nullptr;
+  return a.s == 1 && !force ? launch2<TM, TN, WM, WN, false>(a, st) : launch2<TM, TN, WM, WN, true>(a, st);
+}
+
 }  // namespace
 
-// returns -100 when the launch is not eligible for the DMA path (the caller falls back)
+// returns -100 when the launch is not eligible for this kernel (the caller falls back)
 int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st) {
   const bool tf_ok = (a.a_tf == VCV_TF_NONE || a.a_tf == VCV_TF_LEAKY) && (a.b_tf == VCV_TF_NONE || a.b_tf == VCV_TF_LEAKY) &&
                      a.slope >= 0.f && a.slope < 1.f;
   const int N = a.Cg * a.K;
   const long long U = (long long)a.Ta * a.P;
-  if (a.G != 1 || !tf_ok || a.transpose_out || a.Mg < 32 || N < 96 || U < 64 || a.s < 1) return -100;
-  if (U * 4 >= (1ll << 31) || (long long)a.Tb * a.P * 4 >= (1ll << 31)) return -100;
+  if (a.G != 1 || !tf_ok || a.transpose_out || a.Mg < 32 || N < 96 || U < 64 || a.s < 1 || a.s > 8) return -100;
+  // 32-bit byte offsets inside one batch item of either operand
+  if ((long long)a.Mg * U * 4 >= (1ll << 31) || (long long)a.Cg * a.Tb * a.P * 4 >= (1ll << 31)) return -100;
   int rc = -100;
   if (a.Mg >= 128) {
-    if (N >= 1024) rc = launch<2, 1, 2, 8>(a, st);  // 128x256, 16 waves
-    if (rc == -100) rc = launch<2, 1, 2, 4>(a, st);  // 128x128, 8 waves: its LDS allows one workgroup per CU
-    if (rc == -100) rc = launch<1, 1, 4, 2>(a, st);  // 128x64, 8 waves
+    if (N >= 1024) rc = launch<2, 2, 2, 4>(a, st);  // 128x256, 8 + 4 waves
+    if (rc == -100) rc = launch<2, 1, 2, 4>(a, st);  // 128x128, 8 + 4 waves
+    if (rc == -100) rc = launch<1, 1, 4, 2>(a, st);  // 128x64, 8 + 4 waves
     return rc;
   }
   if (a.Mg >= 64) {
-    rc = launch<1, 1, 2, 4>(a, st);  // 64x128, 8 waves
+    rc = launch<1, 2, 2, 2>(a, st);  // 64x128, 4 + 2 waves
     if (rc == -100) rc = launch<1, 1, 2, 2>(a, st);
     return rc;
   }
-  return launch<1, 1, 1, 4>(a, st);
+  return launch<1, 2, 1, 2>(a, st);  // 32x128, 2 + 2 waves
 }
