@@ -33,7 +33,7 @@ namespace {
 constexpr int BU = 64, AP = BU + 4, MAXX = 12, TABN = BU + 32;
 
 struct WgGeom {
-  int NCH, CP, emin, G4, nmt, nnt, Z, nchunk_u, buf_floats, a_floats, tab_floats, dbg;
+  int NCH, CP, emin, G4, nmt, nnt, Z, nchunk_u, buf_floats, a_floats, tab_floats;
   float invG4, invP;
 };
 
@@ -145,7 +145,6 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
         asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)(tg.a_floats + NCH * CP + lane) * 4u), "v"(uc0 + lane < U ? off : 0)
                      : "memory");
       }
-      if (tg.dbg == 4) return;
       const bool edge = f0a < 0 || f0a + 4 * tg.G4 > TbP;
 #pragma unroll
       for (int t = 0; t < MAXX; ++t) {
@@ -170,7 +169,6 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
         const int row = (t * NP + pw) * 4 + (lane >> 4);
         ra[t] = ld128(rA, (unsigned)(row * U + uc0 + 4 * (lane & 15)) * 4u);
       }
-      if (tg.dbg == 4) return;
       const int f0a = xspan0(uc0) & ~3;
       __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + ((size_t)b * Cg + cfirst) * (size_t)TbP), 0,
                                                                     (int)((size_t)(Cg - cfirst) * TbP * 4), 0x00020000);
@@ -185,7 +183,7 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
     for (int ch = z; ch < total; ch += tg.Z) {
       lds_wait();
       __syncthreads();
-      if (ch + tg.Z < total && tg.dbg != 1) {
+      if (ch + tg.Z < total) {
         store(ch + tg.Z, bufi ^ 1);
         if (ch + 2 * tg.Z < total) load(ch + 2 * tg.Z);
       }
@@ -230,7 +228,6 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
   int bufi = 0;
   for (int ch = z; ch < total; ch += tg.Z) {
     __syncthreads();
-    if (tg.dbg == 2) { bufi ^= 1; continue; }
     const unsigned base = lds0 + (unsigned)(bufi * tg.buf_floats) * 4u;
     const int uc0 = (ch % tg.nchunk_u) * BU;
     // a sequence's last stage multiplies only the sixteen-position groups that hold positions
@@ -316,7 +313,6 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
     bufi ^= 1;
   }
 
-  if (tg.dbg == 3) return;
   if (do_bias) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -353,9 +349,31 @@ __global__ void __launch_bounds__(256) wgrad_slab_finish_kernel(const float* __r
 }
 
 template <int TM, int TN, int WM, int WN, bool STR>
-int launch2(const VcvWgradArgs& a, hipStream_t st) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NP = WM * WN >= 8 ? 4 : 2, NT = 64 * (WM * WN + NP);
+void (*pick_kernel(const VcvWgradArgs& a))(const VcvWgradArgs, const WgGeom) {
+  const bool la = a.a_tf == VCV_TF_LEAKY, lb = a.b_tf == VCV_TF_LEAKY;
+  // the bias-collecting variant exists for the transform-free `a` operand only (a Conv's dy)
+  return la ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, true, true, false, STR> : wgrad_dma_kernel<TM, TN, WM, WN, true, false, false, STR>)
+            : (a.dbias ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, true, STR> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, true, STR>)
+                       : (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, false, STR> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, false, STR>));
+}
+
+struct WgPlan {
   WgGeom g;
+  size_t lds;
+  double cost;  // estimated microseconds; < 0: the tile does not fit
+};
+
+// Geometry of one tile shape for a launch, the split of the reduction over grid.z and an estimate of the time:
+//   rounds of resident workgroups x (stages per workgroup x stage time x workgroups sharing the CU + a fixed
+//   prologue) + the epilogue's Z x M x N atomic adds at the chip-wide atomic rate (MI355X_MICROARCH.md: ~1.3 TB/s)
+//   [slab mode: the slab written and read back at streaming rates].
+// The stage time prices the MFMAs at the rate the tile shape reaches in this kernel (LDS instructions per MFMA).
+template <int TM, int TN, int WM, int WN, bool STR>
+WgPlan plan(const VcvWgradArgs& a) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NP = WM * WN >= 8 ? 4 : 2, NT = 64 * (WM * WN + NP);
+  WgPlan pl;
+  pl.cost = -1.0;
+  WgGeom& g = pl.g;
   const int N = a.Cg * a.K;
   g.nnt = vcv_cdiv(N, BN);
   g.nmt = vcv_cdiv(a.Mg, BM);
@@ -370,65 +388,116 @@ int launch2(const VcvWgradArgs& a, hipStream_t st) {
   const int nq = STR ? (a.P - 1 + BU - 1) / a.P + 1 : 0;
   const int span = STR ? ((nq - 1) * a.s + emax + 1) * a.P : BU + emax * a.P;
   g.G4 = (span + 3 + 3) / 4;  // + up to three floats of round-down at the start
+  g.invG4 = 1.0f / (float)g.G4, g.invP = 1.0f / (float)a.P;
+  if ((long long)g.NCH * g.G4 > (long long)MAXX * NP * 64) return pl;
+  g.a_floats = BM * AP;
+  g.tab_floats = TABN;
   // channel pitch: the (c, k) columns of a B fragment start |dj|*P floats apart inside a channel; step the channels by
-  // about K of those modulo the 64 banks
+  // about K of those modulo the 64 banks -- when the LDS has room for the padding
   int want = (a.K * (emax / (a.K > 1 ? a.K - 1 : 1)) * a.P + 3) / 4 * 4 % 64;
   if (want < 8) want = 8;
   g.CP = 4 * g.G4;
   while (g.CP % 64 != want % 64) g.CP += 4;
   if (g.CP - 4 * g.G4 > 32) g.CP = 4 * g.G4 + 4;
-  g.invG4 = 1.0f / (float)g.G4, g.invP = 1.0f / (float)a.P;
-  if ((long long)g.NCH * g.G4 > (long long)MAXX * NP * 64) return -100;
-  g.a_floats = BM * AP;
-  g.tab_floats = TABN;
-  g.buf_floats = g.a_floats + g.NCH * g.CP + g.tab_floats + 16;
-  const size_t lds = 2ull * g.buf_floats * 4;
-  if (lds > VCV_LDS_LIMIT) return -100;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    g.buf_floats = g.a_floats + g.NCH * g.CP + g.tab_floats + 16;
+    pl.lds = 2ull * g.buf_floats * 4;
+    if (pl.lds <= VCV_LDS_LIMIT) break;
+    g.CP = 4 * g.G4 + ((4 * g.G4) % 32 == 0 ? 4 : 0);
+  }
+  if (pl.lds > VCV_LDS_LIMIT) return pl;
   const long long U = (long long)a.Ta * a.P;
   g.nchunk_u = (int)((U + BU - 1) / BU);
   const long long total = (long long)a.B * g.nchunk_u;
-  // split of the position chunks over grid.z: minimise (rounds of resident blocks) x (chunks per block + a
-  // fixed prologue/atomic-epilogue cost of about two chunks)
+  // workgroups a CU holds (registers and LDS): asked once per kernel variant
+  void (*kern)(const VcvWgradArgs, const WgGeom) = pick_kernel<TM, TN, WM, WN, STR>(a);
+  static int occ_cache[2][2][2] = {};
+  int& oc = occ_cache[a.a_tf == VCV_TF_LEAKY][a.b_tf == VCV_TF_LEAKY][a.dbias != nullptr];
+  if (oc == 0) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, VCV_LDS_LIMIT);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NT, 0) != hipSuccess || nb < 1) nb = 1;
+    oc = nb;
+  }
+  long long occ = (long long)(VCV_LDS_LIMIT / pl.lds);
+  if (occ > oc) occ = oc;
+  if (occ < 1) occ = 1;
+  // full-load MFMA rate of the tile shape relative to 128x256 (measured on the DiscP conv4 weight gradient: LDS
+  // instructions per MFMA, MFMA waves per SIMD, producers per workgroup), 128x256 itself at 0.70 of the fp32 peak
+  const double shape = BM == 128 ? (BN == 256 ? 1.0 : BN == 128 ? 0.93 : 0.77)
+                     : BM == 64  ? (BN == 256 ? 0.905 : BN == 128 ? 0.76 : 0.58)
+                                 : 0.62;
+  const double rate = 0.70 * shape * (STR ? 0.93 : 1.0) * 157.3e12 / 256.0;  // per CU
+  const double t_stage = 2.0 * BM * BN * BU / rate * 1e6, t_fix = 4.0;
   const long long tiles = (long long)g.nnt * g.nmt;
-  const long long occ = lds * 2 <= VCV_LDS_LIMIT ? 2 : 1;
   const long long slots = 256 * occ;
-  long long Z = 1;
-  double best = 1e30;
   const size_t nw = (size_t)a.Mg * N;
   const long long zcap = a.slab ? (long long)(a.slab_floats / (int64_t)nw) : 1024;
-  if (a.slab && zcap < 1) return VCV_EINVAL;
+  if (a.slab && zcap < 1) return pl;
+  long long Z = 1;
+  double best = 1e30;
   for (long long z = 1; z <= total && z <= 1024 && z <= zcap; ++z) {
     const double rounds = (double)((tiles * z + slots - 1) / slots);
-    const double cost = rounds * ((double)((total + z - 1) / z) + 2.0) / (double)occ;
+    // workgroups sharing a CU: a partly filled CU runs each of them faster, but not in proportion
+    const double r = tiles * z < slots ? (double)(tiles * z) / 256.0 : (double)occ;
+    const double share = r <= 1.0 ? (0.3 + 0.7 / (double)occ) * (double)occ : (0.3 + 0.7 * r / (double)occ) * (double)occ;
+    const double epi = a.slab ? (double)z * nw * 4.0 * (1.0 / 4e12 + 1.0 / 4e12) * 1e6 + 3.0 : (double)z * nw * 4.0 / 1.3e12 * 1e6;
+    const double cost = rounds * ((double)((total + z - 1) / z) * t_stage * share + t_fix) + epi;
     if (cost < best - 1e-9) best = cost, Z = z;
   }
   g.Z = (int)Z;
-  g.dbg = getenv("WG_DBG") ? atoi(getenv("WG_DBG")) : 0;
-  const bool la = a.a_tf == VCV_TF_LEAKY, lb = a.b_tf == VCV_TF_LEAKY;
-  // the bias-collecting variant exists for the transform-free `a` operand only (a Conv's dy)
-  void (*kern)(const VcvWgradArgs, const WgGeom) =
-      la ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, true, true, false, STR> : wgrad_dma_kernel<TM, TN, WM, WN, true, false, false, STR>)
-         : (a.dbias ? (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, true, STR> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, true, STR>)
-                    : (lb ? wgrad_dma_kernel<TM, TN, WM, WN, false, true, false, STR> : wgrad_dma_kernel<TM, TN, WM, WN, false, false, false, STR>));
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  pl.cost = best;
+  static const bool verbose = getenv("VCVITS_WGRAD_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "wgrad plan M%d C%d K%d U%lld s%d tile %dx%d: occ %lld tiles %lld total %lld Z %lld cost %.1f us lds %zu\n", a.Mg, a.Cg, a.K,
+            U, a.s, BM, BN, occ, tiles, total, Z, best, pl.lds);
+  return pl;
+}
+
+template <int TM, int TN, int WM, int WN, bool STR>
+int run(const VcvWgradArgs& a, const WgPlan& pl, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NP = WM * WN >= 8 ? 4 : 2, NT = 64 * (WM * WN + NP);
+  const WgGeom& g = pl.g;
+  void (*kern)(const VcvWgradArgs, const WgGeom) = pick_kernel<TM, TN, WM, WN, STR>(a);
+  if (pl.lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
     return VCV_EHIP;
+  const int N = a.Cg * a.K;
+  const size_t nw = (size_t)a.Mg * N;
   dim3 grid(g.nnt, g.nmt, g.Z), block(NT);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
   const int tag[12] = {a.B, 1, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, BM * 1000 + BN, g.G4};
   hipEvent_t ev0, ev1;
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g);
+  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds, st, ev0, ev1, 0, a, g);
   if (a.slab)
     hipLaunchKernelGGL(wgrad_slab_finish_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)a.slab, a.dw,
                        nw, g.Z, a.alpha);
   return vcv_check_launch();
 }
 
-template <int TM, int TN, int WM, int WN>
+// the tile shapes: <TM, TN, WM, WN> = 32x32 MFMA tiles per wave and waves per workgroup, rows x columns
+#define WG_TILES(X) X(0, 2, 2, 2, 4) X(1, 2, 1, 2, 4) X(2, 1, 1, 4, 2) X(3, 1, 2, 2, 4) X(4, 1, 2, 2, 2) X(5, 1, 1, 2, 2) X(6, 1, 2, 1, 2)
+
+template <bool STR>
 int launch(const VcvWgradArgs& a, hipStream_t st) {
-  static const bool force = getenv("WG_FORCESTR") != nullptr;
-  return a.s == 1 && !force ? launch2<TM, TN, WM, WN, false>(a, st) : launch2<TM, TN, WM, WN, true>(a, st);
+  static const int only = getenv("VCVITS_WGRAD_TILE") ? atoi(getenv("VCVITS_WGRAD_TILE")) : -1;  // tuning sweeps
+  WgPlan best;
+  best.cost = -1.0;
+  int which = -1;
+#define WG_PLAN(I, TM, TN, WM, WN)                                                        \
+  if ((only < 0 || only == I) && a.Mg >= 32 * TM * WM / 2 + 1 || (I == 6 && which < 0)) { \
+    const WgPlan pl = plan<TM, TN, WM, WN, STR>(a);                                       \
+    if (pl.cost >= 0.0 && (which < 0 || pl.cost < best.cost)) best = pl, which = I;       \
+  }
+  WG_TILES(WG_PLAN)
+#undef WG_PLAN
+  if (which < 0) return -100;
+#define WG_RUN(I, TM, TN, WM, WN) \
+  if (which == I) return run<TM, TN, WM, WN, STR>(a, best, st);
+  WG_TILES(WG_RUN)
+#undef WG_RUN
+  return -100;
 }
 
 }  // namespace
@@ -442,17 +511,5 @@ int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st) {
   if (a.G != 1 || !tf_ok || a.transpose_out || a.Mg < 32 || N < 96 || U < 64 || a.s < 1 || a.s > 8) return -100;
   // 32-bit byte offsets inside one batch item of either operand
   if ((long long)a.Mg * U * 4 >= (1ll << 31) || (long long)a.Cg * a.Tb * a.P * 4 >= (1ll << 31)) return -100;
-  int rc = -100;
-  if (a.Mg >= 128) {
-    if (N >= 1024) rc = launch<2, 2, 2, 4>(a, st);  // 128x256, 8 + 4 waves
-    if (rc == -100) rc = launch<2, 1, 2, 4>(a, st);  // 128x128, 8 + 4 waves
-    if (rc == -100) rc = launch<1, 1, 4, 2>(a, st);  // 128x64, 8 + 4 waves
-    return rc;
-  }
-  if (a.Mg >= 64) {
-    rc = launch<1, 2, 2, 2>(a, st);  // 64x128, 4 + 2 waves
-    if (rc == -100) rc = launch<1, 1, 2, 2>(a, st);
-    return rc;
-  }
-  return launch<1, 2, 1, 2>(a, st);  // 32x128, 2 + 2 waves
+  return a.s == 1 ? launch<false>(a, st) : launch<true>(a, st);
 }
