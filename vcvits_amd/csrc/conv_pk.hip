@@ -109,10 +109,14 @@ pack_pk_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, 
   wp[i] = v;
 }
 
-template <class EL, int TM, int TN, int WM, int WN, bool LEAKY, int MAXT>
-__global__ void __launch_bounds__(64 * WM * WN)
+// NP = 0: every wave stages and multiplies.  NP > 0: warp-specialised -- the NP waves after the NW MFMA waves do all
+// the staging (weight DMA, input loads and LDS writes of chunk c+1 while the MFMA waves multiply chunk c), so the
+// MFMA waves never sit in the vector-memory issue queue (see wgrad_dma.hip for the measurements behind this).
+template <class EL, int TM, int TN, int WM, int WN, bool LEAKY, int MAXT, int NP = 0>
+__global__ void __launch_bounds__(64 * (WM * WN + NP))
 conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+  constexpr int NS = NP ? NP : NW;  // staging waves
   constexpr int CPG = EL::CPG;
   typedef typename EL::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,6 +125,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
+  const int sw = NP ? wave - NW : wave;  // index among the staging waves (negative: an MFMA wave of a specialised launch)
 
   const int kz = blockIdx.x % tg.ks;
   const int bx = blockIdx.x / tg.ks;
@@ -164,19 +169,22 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   auto issueA = [&](int ch, int buf) {
     char* As = smem + buf * tg.buf_bytes;
     const char* slab = wtile + (size_t)ch * tg.a_bytes;
-    for (int i = wave; i < nA; i += NW)
+    for (int i = sw; i < nA; i += NS)
       __builtin_amdgcn_global_load_lds((const void*)(slab + i * 1024 + lane * 16), (lds_ptr)(As + i * 1024), 16, 0, 0);
   };
-  // registers of the input loads in flight: task t of this wave = staging task wave + t * NW
+  // registers of the input loads in flight: task t of this wave = staging task sw + t * NS
   float xr[MAXT][CPG];
-  auto loadX = [&](int ch) {
+  auto loadX = [&](int ch, int tbase = 0) {
     const int c0 = ch * BKC;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      const int task = wave + t * NW;
+      const int task = tbase + sw + t * NS;
       if (task < ntask) {
         const int g8 = task / npb, pb = task - g8 * npb;
-        const unsigned voff = (unsigned)(f0 + pb * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
+        unsigned voff = (unsigned)(f0 + pb * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
+        // (opaque to the compiler: it otherwise moves the constant part of the task index into the instruction's
+        // immediate offset, and a negative register offset plus an immediate that sum to 0 or 4 came back as zero)
+        asm volatile("" : "+v"(voff));
 #pragma unroll
         for (int e = 0; e < CPG; ++e) {
           const int c = c0 + g8 * CPG + e;
@@ -187,11 +195,11 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
       }
     }
   };
-  auto storeX = [&](int buf) {
+  auto storeX = [&](int buf, int tbase = 0) {
     char* Xs = smem + buf * tg.buf_bytes + tg.a_bytes;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      const int task = wave + t * NW;
+      const int task = tbase + sw + t * NS;
       if (task < ntask) {
         const int g8 = task / npb, pb = task - g8 * npb;
         frag v;
@@ -207,13 +215,37 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   };
 
   const int ch_begin = (int)((long long)kz * tg.nch / tg.ks), ch_end = (int)((long long)(kz + 1) * tg.nch / tg.ks);
-  issueA(ch_begin, 0);
-  loadX(ch_begin);
-  storeX(0);
+  if (NP && wave >= NW) {  // producer waves: one chunk ahead of the MFMA waves, one barrier per chunk like them
+    __builtin_amdgcn_s_setprio(3);
+    // (a chunk with more staging tasks than the producers' registers hold goes through them in batches)
+    issueA(ch_begin, 0);
+    for (int tb = 0; tb < ntask; tb += MAXT * NS) {
+      loadX(ch_begin, tb);
+      storeX(0, tb);
+    }
+    __syncthreads();
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+      const int cb = (ch - ch_begin) & 1;
+      if (ch + 1 < ch_end) {
+        issueA(ch + 1, cb ^ 1);
+        for (int tb = 0; tb < ntask; tb += MAXT * NS) {
+          loadX(ch + 1, tb);
+          storeX(cb ^ 1, tb);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (!NP) {
+    issueA(ch_begin, 0);
+    loadX(ch_begin);
+    storeX(0);
+  }
   __syncthreads();
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const int cb = (ch - ch_begin) & 1;
-    const bool more = ch + 1 < ch_end;
+    const bool more = !NP && ch + 1 < ch_end;
     if (more) {
       issueA(ch + 1, cb ^ 1);
       loadX(ch + 1);
@@ -329,7 +361,8 @@ struct Plan {
   size_t scratch_floats, pack_bytes, lds_bytes;
 };
 
-constexpr int MAXT = 5;  // staging tasks (8 loads each) a wave keeps in flight
+constexpr int MAXT = 5;      // staging tasks (CPG loads each) a wave keeps in flight
+constexpr int MAXT_WS = 10;  // ... a producer wave of a warp-specialised launch (it holds no accumulators)
 
 bool eligible(const VcvConvArgs& a) {
   const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
@@ -341,7 +374,8 @@ bool eligible(const VcvConvArgs& a) {
 }
 
 template <class EL>
-bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
+bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 0) {
+  if (NS == 0) NS = NW;  // staging waves (a specialised variant's producers)
   constexpr int KG = 2 * EL::CPG, ESZ = EL::ESZ;  // channels per (h = 0, h = 1) group pair; bytes per element
   pl.BM = BM; pl.BN = BN; pl.NW = NW;
   BfGeom& g = pl.g;
@@ -366,7 +400,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
       if (cand > cmax) continue;
       const int nch = vcv_cdiv(a.Cg, cand);
       const size_t buf = (size_t)g.JA * cand * BM * ESZ + (size_t)cand * g.xw * ESZ;
-      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (cand / EL::CPG) * (g.xw >> 6) > MAXT * NW) continue;
+      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (NS == NW && (cand / EL::CPG) * (g.xw >> 6) > MAXT * NS)) continue;
       const long long padded = (long long)nch * cand;
       if (padded < best_pad) best_pad = padded, bkc = cand;
     }
@@ -431,6 +465,17 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     if (U >= 2048 && blocks(32, 512) >= 256 && make_plan<EL>(a, 32, 512, 8, pl)) pl.variant = 8, ok = true;
     else if (make_plan<EL>(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
   }
+  // warp-specialised twins of the wide fp32 tiles (8 or 4 MFMA waves + 4 producer waves): measured +5 % on the
+  // 1024-channel period layers, +10 % on the 128-channel generator layers -- where 128 workgroups of 128x256 with
+  // producers beat 256 of the plain 128x128 tile; the phased data gradients (two taps per staged span: staging-bound)
+  // and the 128x320 / 128x128 twins measured slower and keep every wave staging
+  static const bool no_ws = getenv("VCVITS_PK_NO_WS") != nullptr;
+  if (ok && !no_ws && a.Mg >= 128 && EL::ESZ == 4 && nph == 1) {
+    Plan p2;
+    if (pl.variant == 0 && make_plan<EL>(a, 128, 256, 8, p2, 4)) pl = p2, pl.variant = 12;
+    else if (pl.variant == 2 && make_plan<EL>(a, 128, 224, 4, p2, 4)) pl = p2, pl.variant = 13;
+    else if (pl.variant == 1 && U > 160 && blocks(128, 256) >= 112 && make_plan<EL>(a, 128, 256, 8, p2, 4)) pl = p2, pl.variant = 12;
+  }
   if (!ok) return false;
   // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass),
   // aiming at one full round of resident workgroups (256 x the workgroups a CU holds at this LDS footprint)
@@ -449,9 +494,9 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   return true;
 }
 
-template <class EL, int TM, int TN, int WM, int WN>
+template <class EL, int TM, int TN, int WM, int WN, int NP = 0>
 int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
-  constexpr int BM = 32 * TM * WM, NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM, NT = 64 * (WM * WN + NP);
   const BfGeom& g = pl.g;
   if (!pack_valid) {
     const size_t total = pl.pack_bytes / 16;
@@ -460,7 +505,8 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
                        BM, g.BKC, g.JA, g.nch, g.nmt, g.phases, mode, total);
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const typename EL::frag*, float*) =
-      a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, MAXT> : conv_pk_kernel<EL, TM, TN, WM, WN, false, MAXT>;
+      a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, (NP ? MAXT_WS : MAXT), NP>
+                              : conv_pk_kernel<EL, TM, TN, WM, WN, false, (NP ? MAXT_WS : MAXT), NP>;
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
@@ -518,6 +564,8 @@ int run_t(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, 
     case 5: return launch<EL, 1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 6: return launch<EL, 1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 8: return launch<EL, 1, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 32 x 512
+    case 12: return launch<EL, 2, 2, 2, 4, 4>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 256, 8 MFMA + 4 producer waves
+    case 13: return launch<EL, 1, 7, 4, 1, 4>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 224, 4 MFMA waves of 32 x 224 + 4 producers
     case 11: return launch<EL, 1, 5, 4, 2>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 320: 8 waves of 32 rows x 5 column tiles
     default: return launch<EL, 4, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);
   }

@@ -174,7 +174,11 @@ wgrad_dma_kernel(const VcvWgradArgs p, const WgGeom tg) {
                                                                     (int)((size_t)(Cg - cfirst) * TbP * 4), 0x00020000);
 #pragma unroll
       for (int t = 0; t < MAXX; ++t)
-        if ((t * NP + pw) * 64 < ngx) rx[t] = ld128(rX, (unsigned)(xld[t] + f0a) * 4u);
+        if ((t * NP + pw) * 64 < ngx) {
+          unsigned voff = (unsigned)(xld[t] + f0a) * 4u;
+          asm volatile("" : "+v"(voff));  // keep it one register: see conv_pk.hip loadX (immediate-offset folding)
+          rx[t] = ld128(rX, voff);
+        }
     };
     load(z);
     store(z, 0);
