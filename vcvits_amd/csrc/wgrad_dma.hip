@@ -27,6 +27,8 @@
 // One barrier per stage; input leaky-ReLU (ResBlock / generator convs) is applied to the fragments as read.
 #include "common.h"
 #include "prof.h"
+#include <cstring>
+#include <unordered_map>
 
 namespace {
 
@@ -483,12 +485,34 @@ int run(const VcvWgradArgs& a, const WgPlan& pl, hipStream_t st) {
 // the tile shapes: <TM, TN, WM, WN> = 32x32 MFMA tiles per wave and waves per workgroup, rows x columns
 #define WG_TILES(X) X(0, 2, 2, 2, 4) X(1, 2, 1, 2, 4) X(2, 1, 1, 4, 2) X(3, 1, 2, 2, 4) X(4, 1, 2, 2, 2) X(5, 1, 1, 2, 2) X(6, 1, 2, 1, 2)
 
+// plans are memoised per launch shape: evaluating seven tile shapes x up to 1024 splits costs ~50 us of host time,
+// which a launch-bound step (the 48 kHz full model) would pay two hundred times
+struct PlanKey {
+  int v[14];
+  int64_t slab;
+  bool operator==(const PlanKey& o) const { return memcmp(v, o.v, sizeof(v)) == 0 && slab == o.slab; }
+};
+struct PlanKeyHash {
+  size_t operator()(const PlanKey& k) const {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)k.slab;
+    for (int i = 0; i < 14; ++i) h = (h ^ (uint64_t)(uint32_t)k.v[i]) * 1099511628211ull;
+    return (size_t)h;
+  }
+};
+struct PlanEntry { WgPlan pl; int which; };
+
 template <bool STR>
 int launch(const VcvWgradArgs& a, hipStream_t st) {
   static const int only = getenv("VCVITS_WGRAD_TILE") ? atoi(getenv("VCVITS_WGRAD_TILE")) : -1;  // tuning sweeps
+  static thread_local std::unordered_map<PlanKey, PlanEntry, PlanKeyHash> cache;
+  const PlanKey key = {{a.B, a.Cg, a.Mg, a.Ta, a.Tb, a.P, a.K, a.s, a.dj, a.off, a.a_tf, a.b_tf, a.dbias != nullptr, a.slab != nullptr},
+                       a.slab ? a.slab_floats : 0};
+  auto hit = cache.find(key);
   WgPlan best;
   best.cost = -1.0;
   int which = -1;
+  if (hit != cache.end()) best = hit->second.pl, which = hit->second.which;
+  else {
 #define WG_PLAN(I, TM, TN, WM, WN)                                                        \
   if ((only < 0 || only == I) && a.Mg >= 32 * TM * WM / 2 + 1 || (I == 6 && which < 0)) { \
     const WgPlan pl = plan<TM, TN, WM, WN, STR>(a);                                       \
@@ -496,6 +520,9 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
   }
   WG_TILES(WG_PLAN)
 #undef WG_PLAN
+    if (cache.size() > 4096) cache.clear();
+    cache[key] = PlanEntry{best, which};
+  }
   if (which < 0) return -100;
 #define WG_RUN(I, TM, TN, WM, WN) \
   if (which == I) return run<TM, TN, WM, WN, STR>(a, best, st);
