@@ -423,7 +423,8 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 
 
 // variants: 0: 128x256 / 8 waves (2x2 per wave)   1: 128x128 / 8 waves (2x1)   2: 128x224 / 14 waves (2x1)
 //           3: 64x256 / 8 waves (1x2... 2x4 waves of 1x2)   4: 64x128 / 8 waves (1x1)   5: 32x256 / 8 waves (1x1)
-//           6: 64x224 / 14 waves (1x1)   7: 128x288 / 9 waves (4x1)
+//           6: 64x224 / 14 waves (1x1)   7: 128x288 / 9 waves (4x1)   16: 64x288 / 9 waves (2x1)
+//           12 / 13: warp-specialised 128x256 (8 + 4 waves) / 128x224 (4 + 4 waves)
 template <class EL>
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
@@ -441,6 +442,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     // (the 3-phase data gradients of the 512-channel period layers: 384 tiles of 128 rows run 1.5 rounds, 768 of 64 rows 3)
     if (U > 160 && U <= 224 && eff2(64, 224) > eff2(128, 224) + 0.2 && make_plan<EL>(a, 64, 224, 14, pl)) pl.variant = 6, ok = true;
     else if (U > 160 && U <= 224 && make_plan<EL>(a, 128, 224, 14, pl)) pl.variant = 2, ok = true;
+    else if (U > 256 && U <= 288 && eff2(64, 288) > eff2(128, 288) + 0.2 && make_plan<EL>(a, 64, 288, 9, pl)) pl.variant = 16, ok = true;
     else if (U > 256 && U <= 288 && make_plan<EL>(a, 128, 288, 9, pl)) pl.variant = 7, ok = true;
     else {
       // tile width by efficiency = (useful columns of the position tiles) x (fill of the last round of 256 workgroups):
@@ -564,6 +566,7 @@ int run_t(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, 
     case 5: return launch<EL, 1, 1, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 6: return launch<EL, 1, 1, 2, 7>(*args, pl, wp, scratch_ws, flip, pv, st);
     case 8: return launch<EL, 1, 2, 1, 8>(*args, pl, wp, scratch_ws, flip, pv, st);   // 32 x 512
+    case 16: return launch<EL, 2, 1, 1, 9>(*args, pl, wp, scratch_ws, flip, pv, st);  // 64 x 288, 9 waves of 64 rows x 32 columns
     case 12: return launch<EL, 2, 2, 2, 4, 4>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 256, 8 MFMA + 4 producer waves
     case 13: return launch<EL, 1, 7, 4, 1, 4>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 224, 4 MFMA waves of 32 x 224 + 4 producers
     case 11: return launch<EL, 1, 5, 4, 2>(*args, pl, wp, scratch_ws, flip, pv, st);  // 128 x 320: 8 waves of 32 rows x 5 column tiles
