@@ -375,7 +375,8 @@ bool eligible(const VcvConvArgs& a) {
 
 template <class EL>
 bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 0) {
-  if (NS == 0) NS = NW;  // staging waves (a specialised variant's producers)
+  const bool ws = NS != 0;  // warp-specialised variant: NS producer waves, which stage a chunk in as many batches as it takes
+  if (NS == 0) NS = NW;
   constexpr int KG = 2 * EL::CPG, ESZ = EL::ESZ;  // channels per (h = 0, h = 1) group pair; bytes per element
   pl.BM = BM; pl.BN = BN; pl.NW = NW;
   BfGeom& g = pl.g;
@@ -400,7 +401,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 
       if (cand > cmax) continue;
       const int nch = vcv_cdiv(a.Cg, cand);
       const size_t buf = (size_t)g.JA * cand * BM * ESZ + (size_t)cand * g.xw * ESZ;
-      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (NS == NW && (cand / EL::CPG) * (g.xw >> 6) > MAXT * NS)) continue;
+      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (!ws && (cand / EL::CPG) * (g.xw >> 6) > MAXT * NS)) continue;
       const long long padded = (long long)nch * cand;
       if (padded < best_pad) best_pad = padded, bkc = cand;
     }
@@ -469,10 +470,11 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   }
   // warp-specialised twins of the wide fp32 tiles (8 or 4 MFMA waves + 4 producer waves): measured +5 % on the
   // 1024-channel period layers, +10 % on the 128-channel generator layers -- where 128 workgroups of 128x256 with
-  // producers beat 256 of the plain 128x128 tile; the phased data gradients (two taps per staged span: staging-bound)
-  // and the 128x320 / 128x128 twins measured slower and keep every wave staging
+  // producers beat 256 of the plain 128x128 tile; the phased data gradients (two taps per staged span: staging-bound),
+  // the stride-3 layers (three times the span per position: 105 -> 87 TFLOP/s with four producers) and the
+  // 128x320 / 128x128 twins measured slower and keep every wave staging
   static const bool no_ws = getenv("VCVITS_PK_NO_WS") != nullptr;
-  if (ok && !no_ws && a.Mg >= 128 && EL::ESZ == 4 && nph == 1) {
+  if (ok && !no_ws && a.Mg >= 128 && EL::ESZ == 4 && nph == 1 && a.s == 1) {
     Plan p2;
     if (pl.variant == 0 && make_plan<EL>(a, 128, 256, 8, p2, 4)) pl = p2, pl.variant = 12;
     else if (pl.variant == 2 && make_plan<EL>(a, 128, 224, 4, p2, 4)) pl = p2, pl.variant = 13;
