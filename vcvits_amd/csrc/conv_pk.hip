@@ -112,7 +112,10 @@ pack_pk_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, 
 // NP = 0: every wave stages and multiplies.  NP > 0: warp-specialised -- the NP waves after the NW MFMA waves do all
 // the staging (weight DMA, input loads and LDS writes of chunk c+1 while the MFMA waves multiply chunk c), so the
 // MFMA waves never sit in the vector-memory issue queue (see wgrad_dma.hip for the measurements behind this).
-template <class EL, int TM, int TN, int WM, int WN, bool LEAKY, int MAXT, int NP = 0>
+// X4: a staging task is a 16-byte channel group x 256 positions, each lane loading FOUR consecutive positions of every
+// channel with one 16-byte buffer load (a 4x4 block that is transposed by register naming: a quarter of the load
+// instructions); otherwise x 64 positions with one dword load per channel.
+template <class EL, int TM, int TN, int WM, int WN, bool LEAKY, int MAXT, int NP = 0, bool X4 = false>
 __global__ void __launch_bounds__(64 * (WM * WN + NP))
 conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
@@ -139,7 +142,11 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   const int qa = u0 / P;
   const int jspan = (JA - 1) * p.dj;
   const int jmin = jspan < 0 ? jspan : 0;
-  const int f0 = (qa * p.s + p.off + jmin) * P;  // first staged input position (flattened [row][P]); may be < 0
+  const int f0r = (qa * p.s + p.off + jmin) * P;  // first input position the tile reads (flattened [row][P]); may be < 0
+  // X4: the image starts at that rounded down to a multiple of four floats of the channel row, so that no 16-byte load
+  // straddles the row start (a load that begins before the buffer comes back as zeros as a whole)
+  const int f0 = X4 ? (f0r & ~3) : f0r;
+  const int fsh = f0r - f0;
   const int BKC = tg.BKC, ncg = tg.ncg, XW = tg.xw;
 
   int laneoff[TN];
@@ -148,7 +155,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
     int u = u0 + (wn * TN + tn) * 32 + l31;
     if (u > U - 1) u = U - 1;
     const int q = u / P, pc = u - q * P;
-    laneoff[tn] = (((q - qa) * p.s - jmin) * P + pc + h * XW) * 16;  // byte offset in the Xs image (h plane included)
+    laneoff[tn] = (((q - qa) * p.s - jmin) * P + pc + fsh + h * XW) * 16;  // byte offset in the Xs image (h plane included)
   }
 
   f32x16 acc[TM][TN];
@@ -163,7 +170,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   const float* xb = p.x + (size_t)b * Cg * (size_t)TinP;
   const char* wtile = (const char*)wp + ((size_t)r * gridDim.y + mt) * tg.nch * (size_t)tg.a_bytes;
   const int nA = tg.a_bytes >> 10;  // 1 KiB wave-instructions per weight slab
-  const int npb = XW >> 6;          // 64-position blocks per span
+  const int npb = X4 ? (XW + 255) >> 8 : XW >> 6;  // position blocks per span (256 / 64 positions)
   const int ntask = (BKC / CPG) * npb;  // (16-byte channel group, position block) staging tasks per chunk
 
   auto issueA = [&](int ch, int buf) {
@@ -173,7 +180,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
       __builtin_amdgcn_global_load_lds((const void*)(slab + i * 1024 + lane * 16), (lds_ptr)(As + i * 1024), 16, 0, 0);
   };
   // registers of the input loads in flight: task t of this wave = staging task sw + t * NS
-  float xr[MAXT][CPG];
+  float xr[MAXT][X4 ? 4 * CPG : CPG];
   auto loadX = [&](int ch, int tbase = 0) {
     const int c0 = ch * BKC;
 #pragma unroll
@@ -181,7 +188,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
       const int task = tbase + sw + t * NS;
       if (task < ntask) {
         const int g8 = task / npb, pb = task - g8 * npb;
-        unsigned voff = (unsigned)(f0 + pb * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
+        unsigned voff = (unsigned)(X4 ? f0 + pb * 256 + 4 * lane : f0 + pb * 64 + lane) * 4u;  // negative -> wraps -> out of range -> 0
         // (opaque to the compiler: it otherwise moves the constant part of the task index into the instruction's
         // immediate offset, and a negative register offset plus an immediate that sum to 0 or 4 came back as zero)
         asm volatile("" : "+v"(voff));
@@ -190,7 +197,13 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
           const int c = c0 + g8 * CPG + e;
           const unsigned rec = c < Cg ? (unsigned)(TinP * 4) : 0u;
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * (size_t)TinP), 0, (int)rec, 0x00020000);
-          xr[t][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+          if (X4) {
+            const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) xr[t][(X4 ? 4 : 1) * e + (X4 ? jj : 0)] = v4[jj];
+          } else {
+            xr[t][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+          }
         }
       }
     }
@@ -202,6 +215,22 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
       const int task = tbase + sw + t * NS;
       if (task < ntask) {
         const int g8 = task / npb, pb = task - g8 * npb;
+        if (X4) {
+          const int pos = pb * 256 + 4 * lane;
+          if (pos < XW) {  // (XW is a multiple of 64: the four positions of a lane are inside or outside together)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              frag v;
+#pragma unroll
+              for (int e = 0; e < CPG; ++e) {
+                float f = xr[t][(X4 ? 4 : 1) * e + (X4 ? jj : 0)];
+                if (LEAKY) f = fmaxf(f, f * p.slope);
+                EL::set(v, e, f);
+              }
+              *reinterpret_cast<frag*>(Xs + ((size_t)(g8 * XW + pos + jj)) * 16) = v;
+            }
+          }
+        } else {
         frag v;
 #pragma unroll
         for (int e = 0; e < CPG; ++e) {
@@ -210,6 +239,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
           EL::set(v, e, f);
         }
         *reinterpret_cast<frag*>(Xs + ((size_t)(g8 * XW + pb * 64 + lane)) * 16) = v;
+        }
       }
     }
   };
@@ -356,6 +386,7 @@ __global__ void __launch_bounds__(256) conv_pk_finish_kernel(const VcvConvArgs p
 
 struct Plan {
   int variant;
+  bool x4;  // 16-byte input loads (kernel template X4)
   int BM, BN, NW;
   BfGeom g;
   size_t scratch_floats, pack_bytes, lds_bytes;
@@ -363,6 +394,8 @@ struct Plan {
 
 constexpr int MAXT = 5;      // staging tasks (CPG loads each) a wave keeps in flight
 constexpr int MAXT_WS = 10;  // ... a producer wave of a warp-specialised launch (it holds no accumulators)
+constexpr int MAXT_X4 = 2;   // ... of 4 x CPG loaded floats each, with 16-byte loads
+constexpr int MAXT_X4_WS = 4;
 
 bool eligible(const VcvConvArgs& a) {
   const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
@@ -374,18 +407,18 @@ bool eligible(const VcvConvArgs& a) {
 }
 
 template <class EL>
-bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 0) {
+bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 0, bool x4 = false) {
   const bool ws = NS != 0;  // warp-specialised variant: NS producer waves, which stage a chunk in as many batches as it takes
   if (NS == 0) NS = NW;
   constexpr int KG = 2 * EL::CPG, ESZ = EL::ESZ;  // channels per (h = 0, h = 1) group pair; bytes per element
-  pl.BM = BM; pl.BN = BN; pl.NW = NW;
+  pl.BM = BM; pl.BN = BN; pl.NW = NW; pl.x4 = x4;
   BfGeom& g = pl.g;
   const int qspan = (BN - 1) / a.P + 1;
   const int adj = a.dj < 0 ? -a.dj : a.dj;
   g.phases = a.phases > 1 ? a.phases : 1;
   g.JA = vcv_cdiv(a.K, g.phases);
   const int rowmax = (qspan * a.s + (g.JA - 1) * adj + 1) * a.P;
-  g.xw = (rowmax + 63) & ~63;
+  g.xw = (rowmax + (x4 ? 3 : 0) + 63) & ~63;  // (x4: up to three floats of round-down at the start)
   // chunk depth: 16-channel groups per chunk.  Candidates must fit two LDS buffers (one when a single chunk covers the
   // reduction) and MAXT staging tasks per wave; among them the least zero-padded channel count wins, then the deeper.
   const int cmax = ((a.Cg + KG - 1) / KG) * KG;
@@ -401,7 +434,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 
       if (cand > cmax) continue;
       const int nch = vcv_cdiv(a.Cg, cand);
       const size_t buf = (size_t)g.JA * cand * BM * ESZ + (size_t)cand * g.xw * ESZ;
-      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (!ws && (cand / EL::CPG) * (g.xw >> 6) > MAXT * NS)) continue;
+      if ((nch > 1 ? 2 : 1) * buf > lds_cap || (!ws && (cand / EL::CPG) * (x4 ? (g.xw + 255) >> 8 : g.xw >> 6) > (x4 ? MAXT_X4 : MAXT) * NS)) continue;
       const long long padded = (long long)nch * cand;
       if (padded < best_pad) best_pad = padded, bkc = cand;
     }
@@ -480,6 +513,17 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     else if (pl.variant == 2 && make_plan<EL>(a, 128, 224, 4, p2, 4)) pl = p2, pl.variant = 13;
     else if (pl.variant == 1 && U > 160 && blocks(128, 256) >= 112 && make_plan<EL>(a, 128, 256, 8, p2, 4)) pl = p2, pl.variant = 12;
   }
+  // 16-byte input loads (kernel template X4): a quarter of the load instructions of the staging phase.  Measured
+  // against dword loads: the stride-3 layers +4-8 % forward and +8-11 % in their phased data gradients, the rest
+  // +0-3 %, the bf16 conv class 264 -> 287 TFLOP/s in the step; only the 32-row phased data gradients (128 -> 32
+  // channels: 39 -> 36) and the bf16 launches with <= 64 input channels (278 -> 252 on the 64-channel k7 layers: two
+  // workgroups per CU there, and the 32 staged floats per task cost registers) lose and keep dword loads
+  static const bool no_x4 = getenv("VCVITS_PK_NO_X4") != nullptr;
+  if (ok && !no_x4 && !(nph > 1 && a.Mg < 64) && !(EL::ESZ == 2 && a.Cg <= 64)) {
+    Plan p2;
+    const int ns = pl.variant == 12 || pl.variant == 13 ? 4 : 0;
+    if (make_plan<EL>(a, pl.BM, pl.BN, pl.NW, p2, ns, true)) { p2.variant = pl.variant; pl = p2; }
+  }
   if (!ok) return false;
   // too few tiles for 256 CUs: split the reduction over ks blocks per tile (deterministic slabs + finishing pass),
   // aiming at one full round of resident workgroups (256 x the workgroups a CU holds at this LDS footprint)
@@ -509,8 +553,10 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
                        BM, g.BKC, g.JA, g.nch, g.nmt, g.phases, mode, total);
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const typename EL::frag*, float*) =
-      a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, (NP ? MAXT_WS : MAXT), NP>
-                              : conv_pk_kernel<EL, TM, TN, WM, WN, false, (NP ? MAXT_WS : MAXT), NP>;
+      pl.x4 ? (a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, (NP ? MAXT_X4_WS : MAXT_X4), NP, true>
+                                       : conv_pk_kernel<EL, TM, TN, WM, WN, false, (NP ? MAXT_X4_WS : MAXT_X4), NP, true>)
+            : (a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, (NP ? MAXT_WS : MAXT), NP, false>
+                                       : conv_pk_kernel<EL, TM, TN, WM, WN, false, (NP ? MAXT_WS : MAXT), NP, false>);
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
