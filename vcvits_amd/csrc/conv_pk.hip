@@ -575,12 +575,12 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   return vcv_check_launch();
 }
 
-// fp32: shapes the LDS-DMA kernel (conv_dma.hip) still runs faster, measured in the step: 32-channel layers and wide
-// k <= 3 layers
+// fp32: with 16-byte input loads this kernel is ahead of the LDS-DMA kernel (conv_dma.hip) on every shape of the step
+// it was behind on before (32-channel layers +6-9 %, wide k <= 3 layers +12-38 %); conv_dma.hip keeps 16..31 channels
 template <class EL>
 bool wanted(const VcvConvArgs& a) {
   if (EL::ESZ == 2) return true;
-  return a.Cg >= 64 && !(a.K <= 3 && a.Cg >= 128);
+  return a.Cg >= 32;
 }
 
 template <class EL>
