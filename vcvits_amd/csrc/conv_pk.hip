@@ -74,6 +74,8 @@ struct BfGeom {
   int JA;         // taps stored per channel in a weight slab (K, or ceil(K/phases) for a phased launch)
   int phases;     // > 1: transposed / strided-data-gradient launch, one residue per blockIdx.z
   int ks;         // > 1: the chunks are split over ks blocks per tile, partial sums go to a scratch slab each
+  int vec;        // 1: rows of the output are contiguous in the column index and the LDS has room for a 32 x 40 tile per
+                  // wave: the epilogue goes through LDS and stores 16 bytes per lane (4 consecutive columns of one row)
 };
 
 // ---- weight pack: fp32 w -> bf16 slabs wp[phase][m-tile][chunk][j][cg][h][m][8] -------------------------------
@@ -308,6 +310,72 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
 
   const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
   const bool mtail = m0 + BM > Mg;
+  if (tg.vec) {
+    // ---- 16-byte epilogue: each 32 x 32 accumulator tile goes through a wave-private LDS tile (pitch 40 floats: the
+    // two row halves of the MFMA layout land 32 banks apart), comes back as rows of four consecutive columns per lane,
+    // and the epilogue operands (residual, activation-derivative mask, accumulate) are read the same way: a quarter
+    // of the global memory instructions of the dword-per-lane path below.  Needs os == 1, oo == 0 and no row mask,
+    // i.e. output index = row * rowstride + u (the launcher sets tg.vec).  The LDS is free: the chunk loop ended
+    // with a barrier, producers of a specialised launch have left.
+    float* T = reinterpret_cast<float*>(smem) + wave * (32 * 40);
+    const unsigned rowstride = (unsigned)(p.Tout * P);
+    const bool split = tg.ks > 1;
+    const size_t ybase = split ? (((size_t)kz * p.B + b) * Mg + m0) * (size_t)U : ((size_t)b * Mg + m0) * rowstride;
+    const unsigned rs = split ? (unsigned)U : rowstride;
+    float* __restrict__ yout = split ? part : p.y;
+    const float* bias = (!split && p.bias) ? p.bias + m0 : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = acc[tm][tn][e];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int r = ps * 8 + (lane >> 3), c4 = lane & 7;
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(T + r * 40 + 4 * c4);
+          const int ml = (wm * TM + tm) * 32 + r;
+          const int u = u0 + (wn * TN + tn) * 32 + 4 * c4;
+          if ((mtail && ml >= rows_valid) || u >= U) continue;
+          const size_t idx = ybase + (size_t)((unsigned)ml * rs) + u;
+          const int nv = U - u < 4 ? U - u : 4;
+          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+          if (split) {
+            if (nv == 4) *reinterpret_cast<f32x4*>(yout + idx) = a4;
+            else for (int j = 0; j < nv; ++j) yout[idx + j] = v[j];
+            continue;
+          }
+          float oa[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, yy[4] = {0.f, 0.f, 0.f, 0.f};
+          if (nv == 4) {
+            if (p.out_tf >= VCV_TF_DLEAKY) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.oaux + idx); oa[0] = t4[0], oa[1] = t4[1], oa[2] = t4[2], oa[3] = t4[3]; }
+            if (p.res) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.res + idx); rr[0] = t4[0], rr[1] = t4[1], rr[2] = t4[2], rr[3] = t4[3]; }
+            if (p.accumulate) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.y + idx); yy[0] = t4[0], yy[1] = t4[1], yy[2] = t4[2], yy[3] = t4[3]; }
+          } else {
+            for (int j = 0; j < nv; ++j) {
+              if (p.out_tf >= VCV_TF_DLEAKY) oa[j] = p.oaux[idx + j];
+              if (p.res) rr[j] = p.res[idx + j];
+              if (p.accumulate) yy[j] = p.y[idx + j];
+            }
+          }
+          const float bv = bias ? bias[ml] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = p.alpha * v[j] + bv;
+            x = vcv_act(x, p.out_act, p.slope);
+            if (p.out_tf == VCV_TF_DLEAKY) x *= vcv_dleaky(oa[j], p.slope);
+            else if (p.out_tf == VCV_TF_DRELU) x = oa[j] > 0.f ? x : 0.f;
+            else if (p.out_tf == VCV_TF_DTANH) x *= 1.f - oa[j] * oa[j];
+            x += rr[j];
+            x += yy[j];
+            v[j] = x;
+          }
+          if (nv == 4) *reinterpret_cast<f32x4*>(p.y + idx) = f32x4{v[0], v[1], v[2], v[3]};
+          else for (int j = 0; j < nv; ++j) p.y[idx + j] = v[j];
+        }
+      }
+    }
+    return;
+  }
   if (tg.ks > 1) {
     float* pb = part + (((size_t)kz * p.B + b) * Mg + m0) * (size_t)U;
 #pragma unroll
@@ -453,6 +521,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 
   pl.lds_bytes = (g.nch > 1 ? 2ull : 1ull) * g.buf_bytes;  // one chunk: no second buffer, more workgroups per CU
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
+  g.vec = 0;
   pl.pack_bytes = (size_t)g.phases * g.nmt * g.nch * g.a_bytes;
   pl.scratch_floats = 0;
   return true;
@@ -542,6 +611,10 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
       pl.scratch_floats = (size_t)ks * a.B * a.Mg * U;
     }
   }
+  // 16-byte epilogue through LDS: output rows contiguous in the column index, room for a 32 x 40 float tile per MFMA wave
+  static const bool no_vec = getenv("VCVITS_PK_NO_VEC") != nullptr;
+  pl.g.vec = (!no_vec && nph == 1 && a.os == 1 && a.oo == 0 && !a.mask &&
+              (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
   return true;
 }
 
