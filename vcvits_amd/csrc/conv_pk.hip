@@ -314,8 +314,8 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
     // ---- 16-byte epilogue: each 32 x 32 accumulator tile goes through a wave-private LDS tile (pitch 40 floats: the
     // two row halves of the MFMA layout land 32 banks apart), comes back as rows of four consecutive columns per lane,
     // and the epilogue operands (residual, activation-derivative mask, accumulate) are read the same way: a quarter
-    // of the global memory instructions of the dword-per-lane path below.  Needs os == 1, oo == 0 and no row mask,
-    // i.e. output index = row * rowstride + u (the launcher sets tg.vec).  The LDS is free: the chunk loop ended
+    // of the global memory instructions of the dword-per-lane path below.  Needs os == 1, oo == 0, i.e. output index
+    // = row * rowstride + u, and a row mask only with P == 1 (mask index = u; the launcher sets tg.vec).  The LDS is free: the chunk loop ended
     // with a barrier, producers of a specialised launch have left.
     float* T = reinterpret_cast<float*>(smem) + wave * (32 * 40);
     const unsigned rowstride = (unsigned)(p.Tout * P);
@@ -346,6 +346,11 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
             continue;
           }
           float oa[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, yy[4] = {0.f, 0.f, 0.f, 0.f};
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.mask) {  // (P == 1: the mask row of this batch element is indexed by u)
+            const float* mrow = p.mask + (size_t)b * p.Tout + u;
+            for (int j = 0; j < nv; ++j) mk[j] = mrow[j];
+          }
           if (nv == 4) {
             if (p.out_tf >= VCV_TF_DLEAKY) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.oaux + idx); oa[0] = t4[0], oa[1] = t4[1], oa[2] = t4[2], oa[3] = t4[3]; }
             if (p.res) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.res + idx); rr[0] = t4[0], rr[1] = t4[1], rr[2] = t4[2], rr[3] = t4[3]; }
@@ -366,6 +371,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
             else if (p.out_tf == VCV_TF_DRELU) x = oa[j] > 0.f ? x : 0.f;
             else if (p.out_tf == VCV_TF_DTANH) x *= 1.f - oa[j] * oa[j];
             x += rr[j];
+            x *= mk[j];
             x += yy[j];
             v[j] = x;
           }
@@ -613,7 +619,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   }
   // 16-byte epilogue through LDS: output rows contiguous in the column index, room for a 32 x 40 float tile per MFMA wave
   static const bool no_vec = getenv("VCVITS_PK_NO_VEC") != nullptr;
-  pl.g.vec = (!no_vec && nph == 1 && a.os == 1 && a.oo == 0 && !a.mask &&
+  pl.g.vec = (!no_vec && nph == 1 && a.os == 1 && a.oo == 0 && (!a.mask || a.P == 1) &&
               (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
   return true;
 }
