@@ -310,7 +310,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
 
   const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
   const bool mtail = m0 + BM > Mg;
-  if (tg.vec) {
+  if (TM * TN <= 4 && tg.vec) {  // (compile-time bound: the unrolled body of the 5- and 7-tile waves would not stay in registers)
     // ---- 16-byte epilogue: each 32 x 32 accumulator tile goes through a wave-private LDS tile (pitch 40 floats: the
     // two row halves of the MFMA layout land 32 banks apart), comes back as rows of four consecutive columns per lane,
     // and the epilogue operands (residual, activation-derivative mask, accumulate) are read the same way: a quarter
@@ -342,24 +342,33 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
           float v[4] = {a4[0], a4[1], a4[2], a4[3]};
           if (split) {
             if (nv == 4) *reinterpret_cast<f32x4*>(yout + idx) = a4;
-            else for (int j = 0; j < nv; ++j) yout[idx + j] = v[j];
+            else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (j < nv) yout[idx + j] = v[j];  // (constant indices: a runtime trip count would put v[] in scratch)
+            }
             continue;
           }
           float oa[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, yy[4] = {0.f, 0.f, 0.f, 0.f};
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
           if (p.mask) {  // (P == 1: the mask row of this batch element is indexed by u)
             const float* mrow = p.mask + (size_t)b * p.Tout + u;
-            for (int j = 0; j < nv; ++j) mk[j] = mrow[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nv) mk[j] = mrow[j];
           }
           if (nv == 4) {
             if (p.out_tf >= VCV_TF_DLEAKY) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.oaux + idx); oa[0] = t4[0], oa[1] = t4[1], oa[2] = t4[2], oa[3] = t4[3]; }
             if (p.res) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.res + idx); rr[0] = t4[0], rr[1] = t4[1], rr[2] = t4[2], rr[3] = t4[3]; }
             if (p.accumulate) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.y + idx); yy[0] = t4[0], yy[1] = t4[1], yy[2] = t4[2], yy[3] = t4[3]; }
           } else {
-            for (int j = 0; j < nv; ++j) {
-              if (p.out_tf >= VCV_TF_DLEAKY) oa[j] = p.oaux[idx + j];
-              if (p.res) rr[j] = p.res[idx + j];
-              if (p.accumulate) yy[j] = p.y[idx + j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j < nv) {
+                if (p.out_tf >= VCV_TF_DLEAKY) oa[j] = p.oaux[idx + j];
+                if (p.res) rr[j] = p.res[idx + j];
+                if (p.accumulate) yy[j] = p.y[idx + j];
+              }
             }
           }
           const float bv = bias ? bias[ml] : 0.f;
@@ -376,7 +385,11 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
             v[j] = x;
           }
           if (nv == 4) *reinterpret_cast<f32x4*>(p.y + idx) = f32x4{v[0], v[1], v[2], v[3]};
-          else for (int j = 0; j < nv; ++j) p.y[idx + j] = v[j];
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nv) p.y[idx + j] = v[j];
+          }
         }
       }
     }
