@@ -474,6 +474,36 @@ __global__ void __launch_bounds__(256) conv_pk_finish_kernel(const VcvConvArgs p
   p.y[idx] = v;
 }
 
+// The same pass for launches whose output index equals the slab index (os == 1, oo == 0, no mask, element count a
+// multiple of four): four consecutive elements per thread, 16-byte loads of every slab and epilogue operand.
+__global__ void __launch_bounds__(256) conv_pk_finish4_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
+  const int U = p.Q * p.P;
+  const size_t n = (size_t)p.B * p.Mg * U;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
+  for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (size_t)k * n + i);
+  f32x4 oa = {0.f, 0.f, 0.f, 0.f}, rr = oa, yy = oa;
+  if (p.out_tf >= VCV_TF_DLEAKY) oa = *reinterpret_cast<const f32x4*>(p.oaux + i);
+  if (p.res) rr = *reinterpret_cast<const f32x4*>(p.res + i);
+  if (p.accumulate) yy = *reinterpret_cast<const f32x4*>(p.y + i);
+  const size_t bm0 = i / U;
+  const int u0 = (int)(i - bm0 * U);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t bm = u0 + j < U ? bm0 : bm0 + 1;  // (a group of four may run into the next row)
+    float x = p.alpha * v[j];
+    if (p.bias) x += p.bias[(int)(bm % p.Mg)];
+    x = vcv_act(x, p.out_act, p.slope);
+    if (p.out_tf == VCV_TF_DLEAKY) x *= vcv_dleaky(oa[j], p.slope);
+    else if (p.out_tf == VCV_TF_DRELU) x = oa[j] > 0.f ? x : 0.f;
+    else if (p.out_tf == VCV_TF_DTANH) x *= 1.f - oa[j] * oa[j];
+    o[j] = x + rr[j] + yy[j];
+  }
+  *reinterpret_cast<f32x4*>(p.y + i) = o;
+}
+
 struct Plan {
   int variant;
   bool x4;  // 16-byte input loads (kernel template X4)
@@ -665,7 +695,10 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, a, g, (const typename EL::frag*)wp, part);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
-    hipLaunchKernelGGL(conv_pk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
+    if (g.vec && !a.mask && n % 4 == 0 && a.Q == a.Tout && a.Q * a.P >= 4)
+      hipLaunchKernelGGL(conv_pk_finish4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
+    else
+      hipLaunchKernelGGL(conv_pk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (const float*)part, g.ks);
   }
   return vcv_check_launch();
 }
