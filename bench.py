@@ -11,8 +11,17 @@ optimizer passes, AdamW included.  The other BASELINE configurations are reachab
   configs[4]  --config 48k --workload infer --dtype bf16       (flow inverse + decode, 64 x 10 s -> real-time factor)
 
   python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus N --steps K --warmup W     (N > 1 without torchrun: this process starts N rank processes
+                                                      itself BEFORE touching the GPU, relays rank 0's line and exits
+                                                      non-zero if fewer than N GPUs are visible or a rank fails --
+                                                      the reference's own launch is one command too: train.sh:1,
+                                                      train.py:98-100)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+
+The default invocation (N = 1, configs[1]) also times short legs of BASELINE configs[2] (full model, B = 32, bf16) and
+configs[4] (48 kHz inference, 64 x 10 s, bf16) after the main timed region and reports them under
+`config.extra_configs` (`--no-extra` skips them).
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (the dominant kernel family, timed
 with HIP events attached to each dispatch on the launch stream inside the timed region) and `cpu_baseline` (the CPU
@@ -80,7 +89,7 @@ def profiled_traffic(families, workload_key):
     return None, None, False
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -94,17 +103,68 @@ def parse():
     ap.add_argument("--no-cpu-baseline-full", action="store_true",
                     help="skip the second CPU leg (SURVEY 8d's config 1: full model, B=2)")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch event timing")
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the short configs[2] / configs[4] legs of the default run")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend (gloo only with --dry-run: launcher test on a CPU-only host)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, form the process group, run the timing collectives and print the line "
+                         "without launching a kernel (tests the N-rank launcher where there is no GPU)")
+    return ap.parse_args(argv)
 
 
-# Host threads for the CPU oracle: measured on the GPU box host (2 x EPYC 9575F = 128 physical cores, 256 hardware
-# threads): one B=1 oracle batch takes 1.2 s at 16 torch threads, 1.9 s at 32, 5.1 s at 64 and ~545 s at 256
-# (oversubscribed intra-op pool), so the fastest setting is used and the sweep is carried in the JSON.
-CPU_THREADS = 16
-CPU_THREAD_SWEEP = {"16": 1.2, "32": 1.9, "64": 5.1, "256": 545.0}
+# ---------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no torchrun around it
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def _cpu_train(cfg, workload, periods):
+def launch_ranks(a, argv):
+    """Parent of an N-rank run.  Touches no GPU (torch.cuda.device_count() does not initialise HIP on this image):
+    checks that N devices are visible, starts one fresh `bench.py` process per rank with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and returns non-zero if any rank failed.  Never falls back
+    to fewer ranks."""
+    import subprocess
+    n = a.gpus
+    if not a.dry_run and os.environ.get("VCVITS_BENCH_SKIP_DEVICE_CHECK") != "1":  # (the skip is for the launcher test)
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks\n" % (n, have))
+            return 3
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                "LOCAL_WORLD_SIZE": str(n), "VCVITS_BENCH_CHILD": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(codes) or not lines:
+        sys.stderr.write("bench.py: rank exit codes %s, %d JSON line(s) from rank 0\n" % (codes, len(lines)))
+        sys.stdout.write(out0 or "")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------------
+# Host threads for the CPU oracle.  torch's intra-op pool oversubscribes badly on the GPU box host (2 x EPYC 9575F,
+# 256 hardware threads: a B=1 batch took 1.2 s at 16 threads and minutes at 256 when measured by hand in round 2), so
+# the thread count is chosen by a short sweep measured IN this run and the sweep is reported as measured.
+CPU_THREAD_CANDIDATES = (8, 16, 32)
+
+
+def _cpu_trainer(cfg, workload, periods):
     from oracle.cpu_step import CpuTrainer
     from vcvits_amd import synthetic
     from vcvits_amd.light.vcvits import VCVITS, VocoderGAN
@@ -122,23 +182,23 @@ def _cpu_train(cfg, workload, periods):
         batch["noise"] = torch.randn(2, m["inter_channels"], 384, generator=g)
         batch["ids_slice"] = torch.tensor([10, 20])
         return batch
+    return trainer, make
 
-    trainer.batch(make(98))
-    n = 3
+
+def _time_batches(trainer, make, n, seed0):
     t0 = time.perf_counter()
     for i in range(n):
-        trainer.batch(make(99 + i))
+        trainer.batch(make(seed0 + i))
     return (time.perf_counter() - t0) / n
 
 
 def cpu_baseline(cfg, workload, periods, frames, also_full=False):
-    """The oracle (CPU restatement: torch CPU autograd + torch.optim.AdamW) on a bounded sample of the same workload
-    at the thread count that is fastest on this host."""
-    cores = min(CPU_THREADS, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    host = {"hardware_threads": os.cpu_count() or 1, "torch_threads_used": cores,
-            "thread_sweep_s_per_B1_batch": CPU_THREAD_SWEEP}
+    """The oracle (CPU restatement: torch CPU autograd + torch.optim.AdamW) on a bounded sample of the same workload,
+    at the torch thread count a sweep measured in this very run finds fastest."""
+    hw = os.cpu_count() or 1
     if workload == "infer":
+        cores = min(16, hw)
+        torch.set_num_threads(cores)
         from oracle import vits_oracle as O
         from vcvits_amd.model.synthesizers.synthesizer_svc import SynthesizerSVC
         d, m = cfg["data"], cfg["model"]
@@ -162,19 +222,35 @@ def cpu_baseline(cfg, workload, periods, frames, also_full=False):
         audio = o.shape[-1] / d["target_sampling_rate"]
         return {"value": round(dt / audio, 5), "unit": "wall s / audio s", "cores": cores, "kind": "port",
                 "sample": "1 utterance x %d frames (%.2f s of audio) after 1 warm-up: oracle flow reverse + HiFi-GAN "
-                          "decode, fp32 torch-CPU, %.2f s" % (T, audio, dt), "host": host}
-    dt = _cpu_train(cfg, workload, periods)
+                          "decode, fp32 torch-CPU, %.2f s" % (T, audio, dt),
+                "host": {"hardware_threads": hw, "torch_threads_used": cores}}
+    trainer, make = _cpu_trainer(cfg, workload, periods)
+    sweep = {}
+    for th in sorted(set(min(c, hw) for c in CPU_THREAD_CANDIDATES)):
+        torch.set_num_threads(th)
+        if not sweep:
+            trainer.batch(make(98))  # warm-up (allocator, oneDNN primitive caches)
+        sweep[th] = _time_batches(trainer, make, 1, 90 + th)
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    dt = _time_batches(trainer, make, 3, 99)
     out = {"value": round(2.0 / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
            "sample": "3 timed batches of 2 utterances after 1 warm-up (%s workload, fp32, torch-CPU oracle with AdamW), "
-                     "%.2f s per batch on %d of %d host threads" % (workload, dt, cores, os.cpu_count() or 1),
-           "host": host}
+                     "%.2f s per batch on %d of %d host threads" % (workload, dt, cores, hw),
+           "host": {"hardware_threads": hw, "torch_threads_used": cores,
+                    "thread_sweep_measured_s_per_B2_batch": {str(k): round(v, 3) for k, v in sweep.items()}}}
     if also_full and workload != "full":
         # SURVEY 8d's CPU baseline proper: BASELINE configs[0] (full model, B=2, one G step + one D step)
-        dtf = _cpu_train(cfg, "full", periods)
+        trainer, make = _cpu_trainer(cfg, "full", periods)
+        trainer.batch(make(98))
+        dtf = _time_batches(trainer, make, 2, 99)
         out["config1_full_model_B2"] = {"value": round(2.0 / dtf, 4), "unit": "utterances/s", "s_per_batch": round(dtf, 2)}
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# one timed leg
+# ---------------------------------------------------------------------------------------------------------------
 def build_infer(cfg, B, T, dev):
     from vcvits_amd.model.synthesizers.synthesizer_svc import SynthesizerSVC
     d, m = cfg["data"], cfg["model"]
@@ -199,41 +275,29 @@ def build_infer(cfg, B, T, dev):
     return step
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    infer = a.workload == "infer"
-    if (world > 1 and not infer) or os.environ.get("VCVITS_FORCE_DDP") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    elif world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # replicas: timing barrier only
+def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True):
+    """Build the workload, do `warmup` untimed steps, time exactly `steps` steps between barrier + synchronize on both
+    sides, MAX over ranks.  Returns the pieces of the JSON line."""
     from vcvits_amd import _lib, configs, ops, synthetic
     from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS, VocoderGAN
     L = _lib.lib()
-    ops.set_compute_dtype(a.dtype)
-
-    cfg = configs.base() if a.config == "base" else configs.base_48k()
-    B = a.batch if a.batch is not None else (64 if infer else 16)
+    ops.set_compute_dtype(dtype)
+    infer = workload == "infer"
+    cfg = configs.base() if config == "base" else configs.base_48k()
+    B = batch if batch is not None else (64 if infer else 16)
     m = cfg["model"]
     torch.manual_seed(1234)  # identical initial weights on every rank
+    module = None
     if infer:
-        run = build_infer(cfg, B, a.frames, dev)
+        run = build_infer(cfg, B, frames, dev)
     else:
-        module = (VocoderGAN if a.workload == "vocoder" else VCVITS)(**cfg).to(dev)
+        module = (VocoderGAN if workload == "vocoder" else VCVITS)(**cfg).to(dev)
         module.train()
         module.configure_optimizers()
         module.optim_g.broadcast_parameters()
         module.optim_d.broadcast_parameters()
-        make = synthetic.vocoder_batch if a.workload == "vocoder" else synthetic.full_batch
-        width = m["inter_channels"] if a.workload == "vocoder" else m["hubert_channels"]
+        make = synthetic.vocoder_batch if workload == "vocoder" else synthetic.full_batch
+        width = m["inter_channels"] if workload == "vocoder" else m["hubert_channels"]
         batches = [make(B, width, seed=1234 + 17 * rank + i, device=dev) for i in range(2)]
 
         def run(i=[0]):
@@ -245,14 +309,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         run()
     sync()
-    prof = (not a.no_prof)
     if prof:
-        _lib.check(L.vcv_prof_begin(8192 * max(a.steps, 1)), "vcv_prof_begin")
+        _lib.check(L.vcv_prof_begin(8192 * max(steps, 1)), "vcv_prof_begin")
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         run()
     sync()
     dt = time.perf_counter() - t0
@@ -260,7 +323,7 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    peak = PEAK_TFLOPS[a.dtype]
+    peak = PEAK_TFLOPS[dtype]
     roof = None
     if prof:
         out = (ctypes.c_double * 12)()
@@ -276,7 +339,7 @@ def main():
                 return None
             ach = fl / (ms * 1e-3) / 1e12
             return {"kernel": PROF_CLASSES[i], "achieved": round(ach, 2), "frac": round(ach / peak, 4),
-                    "launches_per_step": n / a.steps, "avg_launch_us": round(1e3 * ms / n, 2),
+                    "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / n, 2),
                     "gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms * 1e-3 / dt, 3),
                     "algorithmic_bytes_per_launch": round(nbytes[i] / n) if nbytes[i] > 0 else None}
 
@@ -285,7 +348,7 @@ def main():
             # the dominant kernel family by time carries the roofline; the others ride along for the record
             dom = max(fams, key=lambda c: c["share_of_step_time"])
             traffic, traffic_src, stale = profiled_traffic(PROF_FAMILIES[PROF_CLASSES.index(dom["kernel"])],
-                                                           "%s/%s/%s" % (a.config, a.workload, a.dtype))
+                                                           "%s/%s/%s" % (config, workload, dtype))
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": traffic_src, "traffic_stale": stale,
@@ -294,36 +357,129 @@ def main():
                     "gflop_per_launch": dom["gflop_per_launch"], "share_of_step_time": dom["share_of_step_time"],
                     "kernel_source_hash": kernel_source_hash(),
                     "other_kernels": [c for c in fams if c is not dom]}
+    periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
+    if module is not None:
+        module.optim_g.close()
+        module.optim_d.close()
+    del run, module
+    ops.invalidate_weights()
+    ops.set_compute_dtype("f32")
+    torch.cuda.empty_cache()
+    return {"dt": dt, "roof": roof, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
+            "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world}
+
+
+def make_line(r):
+    """The JSON line of one leg (contract in the task description)."""
+    cfg, B, world, steps, dt, frames = r["cfg"], r["B"], r["world"], r["steps"], r["dt"], r["frames"]
+    config, workload, dtype = r["config"], r["workload"], r["dtype"]
+    infer = workload == "infer"
+    gfl = GFLOP_PER_UTT[(config, workload)] * (frames / 938.0 if infer else 1.0)
+    utt_s = world * B * steps / dt
+    cfgname = "configs/base.json" if config == "base" else "configs/48k_base.json"
+    if infer:
+        audio_s = B * frames * cfg["data"]["hop_length"] / cfg["data"]["target_sampling_rate"]
+        line = {"metric": "inference real-time factor (infer.py voice-conversion path: flow inverse + HiFi-GAN decode)",
+                "value": round(dt / steps / audio_s / world, 7), "unit": "wall s / audio s",
+                "higher_is_better": False, "scaling": "weak"}
+        wl = "%s widths, prior sample + flow reverse + HiFi-GAN decode, %d x %d frames (%.1f s each)" % (
+            cfgname, B, frames, frames * cfg["data"]["hop_length"] / cfg["data"]["target_sampling_rate"])
+    else:
+        line = {"metric": "training utterances/sec (gen+disc step) at base.json segment_size",
+                "value": round(utt_s, 3), "unit": "utterances/s", "higher_is_better": True, "scaling": "weak"}
+        wl = ("%s widths, HiFi-GAN generator + MPD(%d periods+S) + MSD + STFT/mel-L1, G step + D step + AdamW"
+              % (cfgname, len(r["periods"])) if workload == "vocoder" else
+              "%s full SynthesizerSVC (feature input) + MPD + MSD, G step + D step + AdamW" % cfgname)
+    line.update({"n_gpus": world, "steps": steps, "warmup": r["warmup"], "ms_per_step": round(1e3 * dt / steps, 3),
+                 "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                 "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world,
+                            "segment_size": cfg["train"]["segment_size"],
+                            "parallelism": ("dp%d" % world) if not infer else ("replicas%d" % world),
+                            "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                            "utterances_per_s": round(utt_s, 3), "algorithmic_gflop_per_utterance": round(gfl, 1),
+                            "algorithmic_tflops": round(utt_s * gfl / 1e3, 2),
+                            "arithmetic": ("fp32 throughout (fp32-input MFMA)" if dtype == "f32" else
+                                           "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},
+                 "roofline": r["roof"]})
+    return line
+
+
+def short(line):
+    """An extra leg as it is carried inside the main line."""
+    roof = line.get("roofline") or {}
+    return {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+            "steps": line["steps"], "warmup": line["warmup"], "dtype": line["dtype"],
+            "workload": line["config"]["workload"], "per_gpu_batch": line["config"]["per_gpu_batch"],
+            "algorithmic_tflops": line["config"]["algorithmic_tflops"],
+            "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "frac", "traffic", "traffic_source",
+                                                  "avg_launch_us", "share_of_step_time")} if roof else None}
+
+
+def dry_run(a, world, rank):
+    """Launcher test: N ranks, process group, the timing collectives, one line -- no kernels, no GPU."""
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
-        gfl = GFLOP_PER_UTT[(a.config, a.workload)] * (a.frames / 938.0 if infer else 1.0)
-        utt_s = world * B * a.steps / dt
-        cfgname = "configs/base.json" if a.config == "base" else "configs/48k_base.json"
-        if infer:
-            audio_s = B * a.frames * cfg["data"]["hop_length"] / cfg["data"]["target_sampling_rate"]
-            line = {"metric": "inference real-time factor (infer.py voice-conversion path: flow inverse + HiFi-GAN decode)",
-                    "value": round(dt / a.steps / audio_s / world, 7), "unit": "wall s / audio s",
-                    "higher_is_better": False, "scaling": "weak"}
-            wl = "%s widths, prior sample + flow reverse + HiFi-GAN decode, %d x %d frames (%.1f s each)" % (
-                cfgname, B, a.frames, a.frames * cfg["data"]["hop_length"] / cfg["data"]["target_sampling_rate"])
-        else:
-            line = {"metric": "training utterances/sec (gen+disc step) at base.json segment_size",
-                    "value": round(utt_s, 3), "unit": "utterances/s", "higher_is_better": True, "scaling": "weak"}
-            wl = ("%s widths, HiFi-GAN generator + MPD(%d periods+S) + MSD + STFT/mel-L1, G step + D step + AdamW"
-                  % (cfgname, len(m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS))
-                  if a.workload == "vocoder" else
-                  "%s full SynthesizerSVC (feature input) + MPD + MSD, G step + D step + AdamW" % cfgname)
-        line.update({"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-                     "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-                     "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world, "segment_size": 16384,
-                                "parallelism": ("dp%d" % world) if not infer else ("replicas%d" % world),
-                                "utterances_per_s": round(utt_s, 3), "algorithmic_gflop_per_utterance": round(gfl, 1),
-                                "algorithmic_tflops": round(utt_s * gfl / 1e3, 2),
-                                "arithmetic": ("fp32 throughout (fp32-input MFMA)" if a.dtype == "f32" else
-                                               "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},
-                     "roofline": roof})
+        print(json.dumps({"metric": "dry run (launcher only)", "value": 0.0, "unit": "utterances/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * float(tt) / max(a.steps, 1), 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+                          "data": "none", "config": {"workload": "dry run", "process_group_ranks": dist.get_world_size(),
+                                                     "backend": a.backend}}), flush=True)
+    dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        # no torchrun around us: become the launcher (nothing has touched the GPU in this process)
+        sys.exit(launch_ranks(a, argv))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and (a.gpus > 1 or world > 1):
+        raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, world, rank)
+    if a.backend != "nccl":
+        raise SystemExit("bench.py: --backend gloo is for --dry-run only (the product path is RCCL)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    infer = a.workload == "infer"
+    if world > 1 or os.environ.get("VCVITS_FORCE_DDP") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # training: gradient all-reduce over RCCL; inference: replicas, the group carries the timing barrier only
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != world:
+            raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
+    r = run_leg(a.config, a.workload, a.dtype, a.batch, a.frames, a.steps, a.warmup, dev, world, rank, prof=not a.no_prof)
+    line = make_line(r) if rank == 0 else None
+    default_run = (world == 1 and a.config == "base" and a.workload == "vocoder" and a.dtype == "f32"
+                   and a.batch is None and not a.no_extra)
+    if default_run:
+        # BASELINE configs[2] and configs[4], a few steps each, so that the driver's line carries them too
+        extra = {}
+        for key, (c, w, dt_, b) in {"configs[2]": ("base", "full", "bf16", 32),
+                                    "configs[4]": ("48k", "infer", "bf16", 64)}.items():
+            try:
+                extra[key] = short(make_line(run_leg(c, w, dt_, b, 938, 4 if w != "infer" else 3, 2, dev, 1, 0,
+                                                     prof=not a.no_prof)))
+            except Exception as e:  # a failed extra leg must not cost the headline line
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["config"]["extra_configs"] = extra
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
-            line["cpu_baseline"] = cpu_baseline(cfg, a.workload, periods, a.frames, also_full=not a.no_cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(r["cfg"], a.workload, r["periods"], a.frames,
+                                                also_full=not a.no_cpu_baseline_full)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
