@@ -57,18 +57,32 @@ def load(name):
     return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
 
 
-def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.03, cap=0.25, floor=0.0):
+def record_stats(kind, name, **kv):
+    """Observed parity statistics, appended to $VCVITS_PARITY_STATS when set (the bounds in the tests are re-based on
+    these files: profiles/r3_parity_stats_*.txt)."""
+    path = os.environ.get("VCVITS_PARITY_STATS")
+    if path:
+        with open(path, "a") as f:
+            f.write("%s %s %s\n" % (kind, name, " ".join("%s=%.4g" % (k, v) for k, v in kv.items())))
+
+
+def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.015, frac4=0.004, cap=0.05, floor=0.0):
     """Comparison for gradients that passed through (leaky-)ReLU layers at full size.
 
     A pre-activation within fp32 rounding of zero can land on different sides of the kink on the two machines; that
     flips ONE derivative (1 vs slope) and moves every gradient element depending on it -- a cone of input positions, a
     row of a weight gradient, a little of every bias sum -- by up to a percent.  With ~1e8 activations per pass a
     handful of such flips is certain, so whole-model gradients cannot meet a 1e-4 max-norm bound element for element
-    (the CPU reference run twice in different summation orders would not either).  The statistic used instead:
-      * relative L2 error of the tensor <= tol_l2,
-      * all but a fraction `frac` of the elements within tol * max|b| (+ floor); tensors under 4096 elements (bias
-        sums, which collect a little of EVERY flip) are held to 10 tol * max|b| instead, two elements excepted,
-      * no element further than cap * max|b| (+ floor) away (garbage fails).
+    (the CPU reference run twice in different summation orders would not either).  The statistic used instead, re-based
+    in round 3 on what the full-width tests observe on the MI355X (profiles/r3_parity_stats_f32.txt: over 770 tensors of
+    >= 4096 elements the worst relative L2 is 4.1e-3, the worst share of elements beyond tol 0.93 %, the worst single
+    element 3.4 % of the scale; over 1952 small tensors the worst element is 1.1 % of the scale):
+      * relative L2 error of the tensor <= tol_l2 (5e-3),
+      * all but `frac` (1.5 %) of the elements within tol * max|b| (+ floor) and all but `frac4` (0.4 %) within
+        4 tol * max|b|; tensors under 4096 elements (bias sums, which collect a little of EVERY flip) are held to
+        10 tol * max|b| instead, two elements excepted,
+      * no element further than `cap` (5 %) of max|b| (+ floor) away: a wrong edge tile -- a few percent of a tensor off
+        by the size of the values -- fails this and the L2 bound.
     The same layer shapes are compared strictly -- as linear launches without activations -- in
     tests/test_48k_gpu.py::test_period_conv_layers_strict and tests/test_conv_gpu.py."""
     a = a.detach().double().cpu().reshape(-1)
@@ -78,12 +92,19 @@ def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.03, cap=0.25, floor=0
     assert bool(torch.isfinite(err).all()), name
     mx = b.abs().max().item()
     l2 = err.norm().item()
+    slack = floor + 2e-6 * mx
+    record_stats("kinked", name, n=err.numel(), rel_l2=l2 / (b.norm().item() + 1e-300),
+                 frac_beyond_tol=float((err > tol * mx + slack).double().mean()),
+                 frac_beyond_4tol=float((err > 4 * tol * mx + slack).double().mean()),
+                 frac_beyond_10tol=float((err > 10 * tol * mx + slack).double().mean()),
+                 max_err_over_scale=err.max().item() / (mx + floor + 1e-300))
     assert l2 <= tol_l2 * b.norm().item() + floor * err.numel() ** 0.5, "%s: relative L2 error %.3e" % (name, l2 / (b.norm().item() + 1e-30))
-    if err.numel() < 4096:
-        bad = int((err > 10 * tol * mx + floor + 2e-6 * mx).sum())  # a flip right under a bias moves that one sum
-        assert bad <= frac * err.numel() + 2, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad, err.numel(), 10 * tol)
-        assert err.max().item() <= cap * mx + floor, "%s: max err %.3e vs scale %.3e" % (name, err.max().item(), mx)
-        return
-    bad = int((err > tol * mx + floor + 2e-6 * mx).sum())
-    assert bad <= frac * err.numel() + 1, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad, err.numel(), tol)
     assert err.max().item() <= cap * mx + floor, "%s: max err %.3e vs scale %.3e" % (name, err.max().item(), mx)
+    if err.numel() < 4096:
+        bad = int((err > 10 * tol * mx + slack).sum())  # a flip right under a bias moves that one sum
+        assert bad <= 2, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad, err.numel(), 10 * tol)
+        return
+    bad = int((err > tol * mx + slack).sum())
+    assert bad <= frac * err.numel() + 1, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad, err.numel(), tol)
+    bad4 = int((err > 4 * tol * mx + slack).sum())
+    assert bad4 <= frac4 * err.numel() + 1, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad4, err.numel(), 4 * tol)

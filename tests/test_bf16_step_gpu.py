@@ -1,0 +1,129 @@
+"""GPU: ONE whole reference batch in bf16 MODE (BASELINE configs[2] / configs[3] arithmetic: bf16 MFMA operands, bf16
+conv activations, fp32 accumulate / master weights / losses / optimizer -- the reference's AMP recipe, train.py:104-106,
+configs/base.json:18, with bf16 for fp16) at FULL widths of both configs against the fp32 CPU oracle trainer: both
+losses and every parameter gradient of both optimizer passes (vits/light/vcvits.py:54-183).
+
+Bounds: one bf16 rounding is a relative error of at most 2^-9 per operand (rms 2^-9 / sqrt 3 =
+1.1e-3, two operands per GEMM: 1.6e-3); the gradient of the generator's first layer has passed ~30 generator GEMMs
+forward, 6 + 6 discriminator GEMMs and ~30 back: a random walk of ~70 steps -> 1.4e-2 expected for a well-conditioned
+sum, more where a gradient is a sum of terms of both signs (bias sums) or sits behind (leaky-)ReLU kinks.  Observed on
+the MI355X (profiles/r3_parity_stats_bf16.txt): losses 5e-7 ... 9e-4; whole-gradient relative L2 1.0-2.7e-2 (generator),
+1.7-2.3e-3 (discriminators); worst tensor of >= 4096 elements 1.0e-1 (`conv_pre.weight`, the deepest), worst small tensor
+1.2e-1 (a 32-element bias sum).  Asserted with ~1.5x margin: losses within LOSS_REL, every gradient tensor within
+GRAD_REL_L2 (GRAD_REL_L2_SMALL under 4096 elements; analytically-zero gradients are held to an absolute floor), the whole
+gradient of each network within TOTAL_REL_L2."""
+import copy
+
+import pytest
+import torch
+
+from golden_util import record_stats
+
+pytestmark = pytest.mark.gpu
+
+LOSS_REL = 2e-3
+GRAD_REL_L2 = 1.5e-1
+GRAD_REL_L2_SMALL = 2.5e-1
+TOTAL_REL_L2 = 4e-2
+
+
+@pytest.fixture
+def bf16_mode():
+    from vcvits_amd import ops
+    ops.set_compute_dtype("bf16")
+    yield ops
+    ops.set_compute_dtype("f32")
+
+
+def _compare_bf16(tag, module, trainer, batch, gpu, ops):
+    lc = trainer.batch(batch)
+    names = {id(p): n for n, p in module.named_parameters()}
+    grads = {}
+
+    def probe(idx, opt):
+        for p in opt.params:
+            grads[names[id(p)]] = p.grad.detach().cpu().clone()
+
+    before = dict(ops.LAUNCH_COUNTS)
+    out = module.fit_batch({k: v.to(gpu) for k, v in batch.items()}, after_backward=probe)
+    torch.cuda.synchronize()
+    ran = {k: ops.LAUNCH_COUNTS[k] - before[k] for k in before}
+    # the step really ran on the bf16 kernels: most GEMM-shaped launches and weight gradients
+    assert ran["bf16"] >= 100 and ran["wgrad_bf16"] >= 40, ran
+    assert ran["bf16"] > 2 * (ran["pk"] + ran["dma"]), ran
+    for a, b, n in zip((out["g"], out["d"]), lc, ("loss_g", "loss_d")):
+        rel = abs(float(a) - float(b)) / abs(float(b))
+        record_stats("bf16step", "%s/%s" % (tag, n), rel=rel, hip=float(a), oracle=float(b))
+        assert rel <= LOSS_REL, (n, float(a), float(b), rel)
+    ref = dict(trainer.grads_g)
+    ref.update(trainer.grads_d)
+    assert set(ref) <= set(grads), set(ref) - set(grads)
+    tops, num, den = {}, {}, {}
+    for kk, v in ref.items():
+        net = kk.split(".")[0]
+        tops[net] = max(tops.get(net, 0.0), float(v.abs().max()))
+    worst = (0.0, None)
+    for k, b in ref.items():
+        net = k.split(".")[0]
+        a, b = grads[k].double().reshape(-1), b.double().reshape(-1)
+        assert bool(torch.isfinite(a).all()), k
+        e2, b2 = float((a - b).pow(2).sum()), float(b.pow(2).sum())
+        num[net] = num.get(net, 0.0) + e2
+        den[net] = den.get(net, 0.0) + b2
+        floor = 2e-4 * tops[net] * b.numel() ** 0.5  # analytically-zero gradients (e.g. softmax key biases)
+        rel = e2 ** 0.5 / (b2 ** 0.5 + 1e-300)
+        record_stats("bf16step", "%s/%s" % (tag, k), n=b.numel(), rel_l2=rel, norm=b2 ** 0.5, floor=floor)
+        if e2 ** 0.5 > floor:
+            worst = max(worst, (rel, k))
+            assert rel <= GRAD_REL_L2, "%s: relative L2 error %.3e of the bf16-mode gradient" % (k, rel)
+    for net in num:
+        tot = (num[net] / den[net]) ** 0.5
+        record_stats("bf16step", "%s/TOTAL/%s" % (tag, net), rel_l2=tot)
+        assert tot <= TOTAL_REL_L2, (net, tot)
+    record_stats("bf16step", "%s/WORST" % tag, rel_l2=worst[0])
+
+
+@pytest.mark.parametrize("config", ["base", "48k"])
+def test_vocoder_gan_bf16_step(gpu, bf16_mode, config):
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import configs, synthetic
+    from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VocoderGAN
+    torch.manual_seed(0)
+    cfg = configs.base() if config == "base" else configs.base_48k()
+    periods = cfg["model"].get("multi_period_discriminator_periods") or DEFAULT_PERIODS
+    module = VocoderGAN(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=True)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    _compare_bf16("vocoder-" + config, module, trainer,
+                  synthetic.vocoder_batch(2, cfg["model"]["inter_channels"], seed=21), gpu, bf16_mode)
+
+
+@pytest.mark.parametrize("config", ["base", "48k"])
+def test_vcvits_bf16_step(gpu, bf16_mode, config):
+    """BASELINE configs[2] (base) / configs[3] (48k) arithmetic on the full SynthesizerSVC step."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import configs, synthetic
+    from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS
+    torch.manual_seed(1)
+    cfg = configs.base() if config == "base" else configs.base_48k()
+    cfg["model"]["p_dropout"] = 0.0  # dropout at real widths: tests/test_dropout_step_gpu.py
+    periods = cfg["model"].get("multi_period_discriminator_periods") or DEFAULT_PERIODS
+    module = VCVITS(**cfg)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if ".post." in n:
+                p.normal_(0.0, 0.02)  # zero-initialised coupling layers would be identities
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=False)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    m = cfg["model"]
+    batch = synthetic.full_batch(2, m["hubert_channels"], t_y=96, t_x=52, seed=22)
+    batch["y_wav_lengths"][1] = 80 * 512
+    batch["y_wav_values"][1, :, 80 * 512:] = 0
+    batch["x_hubert_features_lengths"][1] = 44
+    batch["x_pitch_lengths"][1] = 44
+    g = torch.Generator().manual_seed(23)
+    batch["noise"] = torch.randn(2, m["inter_channels"], 96, generator=g)
+    batch["ids_slice"] = torch.tensor([7, 41])
+    _compare_bf16("full-" + config, module, trainer, batch, gpu, bf16_mode)
