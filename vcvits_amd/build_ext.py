@@ -25,7 +25,18 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(obj, src, hdrs):
+    """Headers a source really includes: from the compiler's depfile (`-MMD`) when the last build left one, every header
+    of csrc/ otherwise."""
+    d = obj[:-2] + ".d"
+    if not os.path.exists(d):
+        return [src] + hdrs
+    words = open(d).read().replace("\\\n", " ").split()
+    inc = [os.path.normpath(os.path.join(CSRC, w)) for w in words[1:] if not w.endswith(":")]
+    return [src] + [w for w in inc if w.startswith(ROOT)]
 
 
 def build(force=False, verbose=True):
@@ -37,12 +48,12 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, _deps(o, s, hdrs)):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + ["-MMD", "-MF", o[:-2] + ".d", "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))

@@ -32,6 +32,7 @@
 // staging of chunk c+1 to NP producer waves instead (see the kernel's comment and wgrad_dma.hip).
 #include "common.h"
 #include "prof.h"
+#include "conv_tile.h"  // BfGeom, conv_tile_epilogue, conv_pk_finish*_kernel
 
 namespace {
 
@@ -62,21 +63,6 @@ struct F32El {
   }
 };
 
-struct BfGeom {
-  int BKC;      // reduction channels per chunk (multiple of 2 * CPG: 16 for bf16, 8 for fp32)
-  int ncg;      // BKC / (2 * CPG)
-  int nch;      // chunks
-  int ntu;      // position tiles per batch element
-  int nmt;      // M tiles
-  int xw;       // staged span (positions, a multiple of 64)
-  int a_bytes;  // JA * BKC * BM * 2
-  int buf_bytes;  // a_bytes + BKC * xw * 2
-  int JA;         // taps stored per channel in a weight slab (K, or ceil(K/phases) for a phased launch)
-  int phases;     // > 1: transposed / strided-data-gradient launch, one residue per blockIdx.z
-  int ks;         // > 1: the chunks are split over ks blocks per tile, partial sums go to a scratch slab each
-  int vec;        // 1: rows of the output are contiguous in the column index and the LDS has room for a 32 x 40 tile per
-                  // wave: the epilogue goes through LDS and stores 16 bytes per lane (4 consecutive columns of one row)
-};
 
 // ---- weight pack: fp32 w -> bf16 slabs wp[phase][m-tile][chunk][j][cg][h][m][8] -------------------------------
 // mode 0: w is [M, C, K] (forward);  mode 1: w is [C, M, K], A(m, c, j) = w[c, m, K-1-j] (stride-1 data gradient);
@@ -308,201 +294,9 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
     __syncthreads();  // publishes chunk ch+1 (LDS writes + the weight DMA) and retires the reads of chunk ch
   }
 
-  const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
-  const bool mtail = m0 + BM > Mg;
-  if (TM * TN <= 4 && tg.vec) {  // (compile-time bound: the unrolled body of the 5- and 7-tile waves would not stay in registers)
-    // ---- 16-byte epilogue: each 32 x 32 accumulator tile goes through a wave-private LDS tile (pitch 40 floats: the
-    // two row halves of the MFMA layout land 32 banks apart), comes back as rows of four consecutive columns per lane,
-    // and the epilogue operands (residual, activation-derivative mask, accumulate) are read the same way: a quarter
-    // of the global memory instructions of the dword-per-lane path below.  Needs os == 1, oo == 0, i.e. output index
-    // = row * rowstride + u, and a row mask only with P == 1 (mask index = u; the launcher sets tg.vec).  The LDS is free: the chunk loop ended
-    // with a barrier, producers of a specialised launch have left.
-    float* T = reinterpret_cast<float*>(smem) + wave * (32 * 40);
-    const unsigned rowstride = (unsigned)(p.Tout * P);
-    const bool split = tg.ks > 1;
-    const size_t ybase = split ? (((size_t)kz * p.B + b) * Mg + m0) * (size_t)U : ((size_t)b * Mg + m0) * rowstride;
-    const unsigned rs = split ? (unsigned)U : rowstride;
-    float* __restrict__ yout = split ? part : p.y;
-    const float* bias = (!split && p.bias) ? p.bias + m0 : nullptr;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = acc[tm][tn][e];
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const int r = ps * 8 + (lane >> 3), c4 = lane & 7;
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(T + r * 40 + 4 * c4);
-          const int ml = (wm * TM + tm) * 32 + r;
-          const int u = u0 + (wn * TN + tn) * 32 + 4 * c4;
-          if ((mtail && ml >= rows_valid) || u >= U) continue;
-          const size_t idx = ybase + (size_t)((unsigned)ml * rs) + u;
-          const int nv = U - u < 4 ? U - u : 4;
-          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-          if (split) {
-            if (nv == 4) *reinterpret_cast<f32x4*>(yout + idx) = a4;
-            else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (j < nv) yout[idx + j] = v[j];  // (constant indices: a runtime trip count would put v[] in scratch)
-            }
-            continue;
-          }
-          float oa[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, yy[4] = {0.f, 0.f, 0.f, 0.f};
-          float mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (p.mask) {  // (P == 1: the mask row of this batch element is indexed by u)
-            const float* mrow = p.mask + (size_t)b * p.Tout + u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nv) mk[j] = mrow[j];
-          }
-          if (nv == 4) {
-            if (p.out_tf >= VCV_TF_DLEAKY) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.oaux + idx); oa[0] = t4[0], oa[1] = t4[1], oa[2] = t4[2], oa[3] = t4[3]; }
-            if (p.res) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.res + idx); rr[0] = t4[0], rr[1] = t4[1], rr[2] = t4[2], rr[3] = t4[3]; }
-            if (p.accumulate) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.y + idx); yy[0] = t4[0], yy[1] = t4[1], yy[2] = t4[2], yy[3] = t4[3]; }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (j < nv) {
-                if (p.out_tf >= VCV_TF_DLEAKY) oa[j] = p.oaux[idx + j];
-                if (p.res) rr[j] = p.res[idx + j];
-                if (p.accumulate) yy[j] = p.y[idx + j];
-              }
-            }
-          }
-          const float bv = bias ? bias[ml] : 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x = p.alpha * v[j] + bv;
-            x = vcv_act(x, p.out_act, p.slope);
-            if (p.out_tf == VCV_TF_DLEAKY) x *= vcv_dleaky(oa[j], p.slope);
-            else if (p.out_tf == VCV_TF_DRELU) x = oa[j] > 0.f ? x : 0.f;
-            else if (p.out_tf == VCV_TF_DTANH) x *= 1.f - oa[j] * oa[j];
-            x += rr[j];
-            x *= mk[j];
-            x += yy[j];
-            v[j] = x;
-          }
-          if (nv == 4) *reinterpret_cast<f32x4*>(p.y + idx) = f32x4{v[0], v[1], v[2], v[3]};
-          else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nv) p.y[idx + j] = v[j];
-          }
-        }
-      }
-    }
-    return;
-  }
-  if (tg.ks > 1) {
-    float* pb = part + (((size_t)kz * p.B + b) * Mg + m0) * (size_t)U;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int u = u0 + (wn * TN + tn) * 32 + l31;
-      if (u >= U) continue;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (mtail && ml >= rows_valid) continue;
-          pb[(size_t)ml * U + u] = acc[tm][tn][e];
-        }
-    }
-    return;
-  }
-  // ---- epilogue (as conv_gemm_kernel / conv_dma_kernel) ----
-  const unsigned rowstride = (unsigned)(p.Tout * P);
-  const size_t ybase = ((size_t)b * Mg + m0) * rowstride;
-  const float* bias = p.bias ? p.bias + m0 : nullptr;
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int u = u0 + (wn * TN + tn) * 32 + l31;
-    if (u >= U) continue;
-    const int q = u / P, pc = u - q * P;
-    const int trow = q * p.os + oo;
-    if (trow < 0 || trow >= p.Tout) continue;
-    const float mk = p.mask ? p.mask[(size_t)b * p.Tout + trow] : 1.f;
-    const size_t colbase = ybase + (size_t)trow * P + pc;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ml = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (mtail && ml >= rows_valid) continue;
-        const size_t idx = colbase + (size_t)((unsigned)ml * rowstride);
-        float v = p.alpha * acc[tm][tn][e];
-        if (bias) v += bias[ml];
-        v = vcv_act(v, p.out_act, p.slope);
-        if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
-        else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
-        else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
-        if (p.res) v += p.res[idx];
-        v *= mk;
-        if (p.accumulate) v += p.y[idx];
-        p.y[idx] = v;
-      }
-    }
-  }
+  conv_tile_epilogue<TM, TN>(p, tg, acc, smem, part, wave, wm, wn, lane, b, kz, u0, m0, oo, BM);
 }
 
-// Adds the ks partial slabs of a split launch and applies the epilogue.
-__global__ void __launch_bounds__(256) conv_pk_finish_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
-  const int U = p.Q * p.P;
-  const size_t n = (size_t)p.B * p.Mg * U;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int u = (int)(i % U);
-  const size_t bm = i / U;
-  const int m = (int)(bm % p.Mg), b = (int)(bm / p.Mg);
-  const int q = u / p.P, pc = u - q * p.P;
-  const int trow = q * p.os + p.oo;
-  if (trow < 0 || trow >= p.Tout) return;
-  float v = 0.f;
-  for (int k = 0; k < ks; ++k) v += part[(size_t)k * n + i];
-  v *= p.alpha;
-  if (p.bias) v += p.bias[m];
-  v = vcv_act(v, p.out_act, p.slope);
-  const size_t idx = (bm * p.Tout + trow) * p.P + pc;
-  if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
-  else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
-  else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
-  if (p.res) v += p.res[idx];
-  if (p.mask) v *= p.mask[(size_t)b * p.Tout + trow];
-  if (p.accumulate) v += p.y[idx];
-  p.y[idx] = v;
-}
-
-// The same pass for launches whose output index equals the slab index (os == 1, oo == 0, no mask, element count a
-// multiple of four): four consecutive elements per thread, 16-byte loads of every slab and epilogue operand.
-__global__ void __launch_bounds__(256) conv_pk_finish4_kernel(const VcvConvArgs p, const float* __restrict__ part, int ks) {
-  const int U = p.Q * p.P;
-  const size_t n = (size_t)p.B * p.Mg * U;
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
-  for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (size_t)k * n + i);
-  f32x4 oa = {0.f, 0.f, 0.f, 0.f}, rr = oa, yy = oa;
-  if (p.out_tf >= VCV_TF_DLEAKY) oa = *reinterpret_cast<const f32x4*>(p.oaux + i);
-  if (p.res) rr = *reinterpret_cast<const f32x4*>(p.res + i);
-  if (p.accumulate) yy = *reinterpret_cast<const f32x4*>(p.y + i);
-  const size_t bm0 = i / U;
-  const int u0 = (int)(i - bm0 * U);
-  f32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const size_t bm = u0 + j < U ? bm0 : bm0 + 1;  // (a group of four may run into the next row)
-    float x = p.alpha * v[j];
-    if (p.bias) x += p.bias[(int)(bm % p.Mg)];
-    x = vcv_act(x, p.out_act, p.slope);
-    if (p.out_tf == VCV_TF_DLEAKY) x *= vcv_dleaky(oa[j], p.slope);
-    else if (p.out_tf == VCV_TF_DRELU) x = oa[j] > 0.f ? x : 0.f;
-    else if (p.out_tf == VCV_TF_DTANH) x *= 1.f - oa[j] * oa[j];
-    o[j] = x + rr[j] + yy[j];
-  }
-  *reinterpret_cast<f32x4*>(p.y + i) = o;
-}
 
 struct Plan {
   int variant;
