@@ -123,6 +123,19 @@ int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws
                       void* stream);
 
 /*
+ * fp32 convolutions on the bf16 matrix pipe by exact operand splitting (conv_x3.hip): every fp32 operand is the exact sum
+ * of three bf16 terms, so an fp32 product is the sum of nine exact bf16 products accumulated in fp32 -- the arithmetic
+ * of the fp32 kernels above (torch.nn.functional.conv1d / conv2d / conv_transpose1d in fp32: vits/model/modules.py,
+ * discriminators/discriminator.py, the hub generator) up to summation order, at the bf16 MFMA rate.  Same launch family,
+ * argument meaning and epilogue as vcv_conv_pk_plan / vcv_conv_pk_run; `x`, `y` and all epilogue operands are fp32.
+ * vcv_conv_x3_set_terms(9 | 6): 9 = all products (default), 6 = the three smallest (each < 2^-24 of the product) left out.
+ */
+int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out);
+int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream);
+int vcv_conv_x3_set_terms(int n);
+int vcv_conv_x3_get_terms(void);
+
+/*
  * Weight gradient of the same family (torch autograd of the call sites above):
  *   dw[(g*Mg + m), c, k] (+)= alpha * sum_{b, q, p} tfa(dy[b, g*Mg+m, q, p]) *
  *                                               tfb(x[b, g*Cg+c, q*s + k*dj + off, p])

@@ -37,6 +37,7 @@ def test_pk_kernel_matches_torch_and_dma(gpu, case):
     outs = {}
     for use_pk in (True, False):
         ops._USE_PK[0] = use_pk
+        ops._USE_X3[0] = False  # (the split-operand kernel would take these launches first: tests/test_conv_x3_gpu.py)
         try:
             before = ops.LAUNCH_COUNTS["pk"]
             xg, wg, bg = (v.to(gpu).requires_grad_(True) for v in (x, w, b))
@@ -48,6 +49,7 @@ def test_pk_kernel_matches_torch_and_dma(gpu, case):
             used = ops.LAUNCH_COUNTS["pk"] - before
         finally:
             ops._USE_PK[0] = True
+            ops._USE_X3[0] = True
         if use_pk and not (K <= 3 and C >= 128):
             assert used >= 1, "the packed kernel did not take this launch"
         if not use_pk:

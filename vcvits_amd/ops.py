@@ -42,6 +42,19 @@ _USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
 # fp32 launches try the channel-innermost packed kernel (vcv_conv_pk_*) before the LDS-DMA kernel
 _USE_PK = [__import__("os").environ.get("VCVITS_CONV_PK", "1") == "1"]
 
+# fp32 launches try the split-operand kernel first (vcv_conv_x3_*: fp32 operands as three exact bf16 terms each, nine -- or
+# six -- bf16 MFMA products per fp32 product, fp32 accumulate: fp32 results at 1.8-2.7 x the fp32 MFMA peak)
+_USE_X3 = [__import__("os").environ.get("VCVITS_CONV_X3", "1") == "1"]
+
+
+def set_f32_split(on, terms=None):
+    """fp32 GEMM-shaped launches on the bf16 matrix pipe by exact operand splitting (True, default) or on fp32-input MFMAs
+    (False: bit-for-bit an fmaf chain).  terms: 9 (all bf16 products) or 6 (the three below 2^-24 of the product left out)."""
+    _USE_X3[0] = bool(on)
+    if terms is not None:
+        check(lib().vcv_conv_x3_set_terms(int(terms)), "vcv_conv_x3_set_terms")
+
+
 # Arithmetic of the GEMM-shaped kernels: "f32" (fp32-input MFMA, exact fp32) or "bf16" (operands rounded to bf16 on
 # their way into the matrix cores, fp32 accumulate; activations, master weights, losses and the optimizer stay fp32 --
 # the reference's AMP recipe, configs/base.json:18 / train.py:104-106, with bf16 in place of fp16).
@@ -49,7 +62,7 @@ _COMPUTE = ["f32"]
 
 
 # which kernel family each GEMM-shaped launch went to (tests assert that the bf16 path really ran)
-LAUNCH_COUNTS = {"bf16": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad": 0}
+LAUNCH_COUNTS = {"bf16": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad": 0}
 
 
 def set_compute_dtype(name):
@@ -76,6 +89,8 @@ def _launch_conv(a, flip_w=None):
         flip = 1 if flip_w is not None else 0
         plan = (ctypes.c_int64 * 3)()
         families = ((L.vcv_conv_bf16_plan, L.vcv_conv_bf16_run, "vcv_conv_bf16_run"),) if _COMPUTE[0] == "bf16" else ()
+        if _USE_X3[0] and _COMPUTE[0] == "f32":
+            families += ((L.vcv_conv_x3_plan, L.vcv_conv_x3_run, "vcv_conv_x3_run"),)
         if _USE_PK[0]:
             families += ((L.vcv_conv_pk_plan, L.vcv_conv_pk_run, "vcv_conv_pk_run"),)
         families += ((L.vcv_conv_dma_plan, L.vcv_conv_dma_run, "vcv_conv_dma_run"),)
@@ -93,7 +108,7 @@ def _launch_conv(a, flip_w=None):
                     packs[key] = pack
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
             check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
-            LAUNCH_COUNTS["bf16" if name == "vcv_conv_bf16_run" else "pk" if name == "vcv_conv_pk_run" else "dma"] += 1
+            LAUNCH_COUNTS[{"vcv_conv_bf16_run": "bf16", "vcv_conv_x3_run": "x3", "vcv_conv_pk_run": "pk"}.get(name, "dma")] += 1
             return
         if flip_w is not None:
             a.w = saved
@@ -213,6 +228,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         _common(a, **kw)
         a.w = ptr(w)
         if _USE_DMA[0] and ((_COMPUTE[0] == "bf16" and lib().vcv_conv_bf16_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0)
+                            or (_COMPUTE[0] == "f32" and _USE_X3[0] and lib().vcv_conv_x3_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0)
                             or (_USE_PK[0] and lib().vcv_conv_pk_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0)
                             or lib().vcv_conv_dma_plan(ctypes.byref(a), 1, (ctypes.c_int64 * 3)()) == 0):
             _launch_conv(a, flip_w=w)
