@@ -128,12 +128,15 @@ int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws
  * of the fp32 kernels above (torch.nn.functional.conv1d / conv2d / conv_transpose1d in fp32: vits/model/modules.py,
  * discriminators/discriminator.py, the hub generator) up to summation order, at the bf16 MFMA rate.  Same launch family,
  * argument meaning and epilogue as vcv_conv_pk_plan / vcv_conv_pk_run; `x`, `y` and all epilogue operands are fp32.
- * vcv_conv_x3_set_terms(9 | 6): 9 = all products (default), 6 = the three smallest (each < 2^-24 of the product) left out.
+ * vcv_conv_x3_set_terms(6 | 9): 6 (default) = the three smallest products (each < 2^-24 of the fp32 product) left out,
+ * 9 = all products.
+ * vcv_conv_x3_set_all(1): take every eligible launch; 0 (default): only the shapes where the split kernel is the faster one.
  */
 int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out);
 int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream);
 int vcv_conv_x3_set_terms(int n);
 int vcv_conv_x3_get_terms(void);
+int vcv_conv_x3_set_all(int all);
 
 /*
  * Weight gradient of the same family (torch autograd of the call sites above):
@@ -177,6 +180,11 @@ int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
  */
 int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* args);
 int vcv_wgrad_bf16(const VcvWgradArgs* args, float* scratch, int64_t scratch_floats, void* stream);
+/* weight gradient in the split-operand fp32 arithmetic of vcv_conv_x3_* (wgrad_bf16.hip with three term planes per
+ * operand): calling convention of vcv_wgrad_bf16_scratch / vcv_wgrad_bf16; deterministic (per-workgroup slabs added in
+ * a fixed order) */
+int64_t vcv_wgrad_x3_scratch(const VcvWgradArgs* args);
+int vcv_wgrad_x3(const VcvWgradArgs* args, float* scratch, int64_t scratch_floats, void* stream);
 
 /* Thin convolutions (HBM-bound, no MFMA): a conv with ONE output channel (discriminator conv_post
  * 1024->1, discriminator.py:25,61; generator conv_post 32->1 + tanh) and the weight gradient of a

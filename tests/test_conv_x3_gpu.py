@@ -52,7 +52,7 @@ def test_x3_kernel_is_fp32_arithmetic(gpu, case):
     errs = {}
     try:
         for mode in ("x3-9", "x3-6", "pk"):
-            ops.set_f32_split(mode != "pk", terms=9 if mode != "x3-6" else 6)
+            ops.set_f32_split(mode != "pk", terms=9 if mode != "x3-6" else 6, all_shapes=True)
             before = dict(ops.LAUNCH_COUNTS)
             xg, wg, bg = (v.to(gpu).requires_grad_(True) for v in (x, w, b))
             if kind == "convT":
@@ -67,7 +67,7 @@ def test_x3_kernel_is_fp32_arithmetic(gpu, case):
                 assert used >= 1, "the split kernel took none of this case's launches"
             errs[mode] = (rel64(yg, yr.detach()), rel64(xg.grad, xr.grad))
     finally:
-        ops.set_f32_split(True, terms=9)
+        ops.set_f32_split(True, terms=6, all_shapes=False)
     record_stats("x3", "%s-C%d-M%d-T%d-K%d-s%d-P%d" % (kind, C, M, T, K, s, P),
                  **{"%s_%s" % (m.replace("-", "_"), n): v for m, e in errs.items() for n, v in zip(("y", "dx"), e)})
     for mode, (ey, ex) in errs.items():
@@ -86,8 +86,66 @@ def test_split_is_exact(gpu):
     w = torch.zeros(32, 32, 1)
     for m in range(32):
         w[m, (m * 7) % 32, 0] = 1.0
-    ops.set_f32_split(True, terms=9)
-    before = ops.LAUNCH_COUNTS["x3"]
-    y = ops.conv_forward(x.to(gpu), w.to(gpu))
-    assert ops.LAUNCH_COUNTS["x3"] == before + 1
+    ops.set_f32_split(True, terms=9, all_shapes=True)
+    try:
+        before = ops.LAUNCH_COUNTS["x3"]
+        y = ops.conv_forward(x.to(gpu), w.to(gpu))
+        assert ops.LAUNCH_COUNTS["x3"] == before + 1
+    finally:
+        ops.set_f32_split(True, terms=6, all_shapes=False)
     assert torch.equal(y.cpu(), x[:, [(m * 7) % 32 for m in range(32)], :])
+
+
+# (ConvTranspose weight gradients with stride > 3 stay on the fp32 kernels, as in bf16 mode)
+WG_CASES = [c for c in CASES if c[2] >= 16 and not (c[0] == "convT" and c[6] > 3)] + EXTRA[:3]
+
+
+@pytest.mark.parametrize("case", WG_CASES,
+                         ids=lambda c: "%s-C%d-M%d-T%d-K%d-s%d-d%d-P%d" % (c[0], c[2], c[3], c[4], c[5], c[6], c[8], c[9]))
+def test_x3_weight_gradient_is_fp32_arithmetic(gpu, case):
+    """Weight (and bias) gradient on the split-operand kernel (vcv_wgrad_x3) vs float64, next to the fp32-input MFMA
+    kernel; bit-reproducible between two identical launches (slabs added in a fixed order)."""
+    from vcvits_amd import ops
+    kind, B, C, M, T, K, s, pad, d, P, in_leaky = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    t = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))
+    if kind == "convT":
+        x, w = t(B, C, T), t(C, M, K) * (C * K / s) ** -0.5
+    elif kind == "period":
+        x, w = t(B, C, T, P), t(M, C, K, 1) * (C * K) ** -0.5
+    else:
+        x, w = t(B, C, T), t(M, C, K) * (C * K) ** -0.5
+    b = t(M) * 0.1
+    xr, wr, br = x.double(), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    xin = F.leaky_relu(xr, 0.1) if in_leaky else xr
+    if kind == "convT":
+        yr = F.conv_transpose1d(xin, wr, br, stride=s, padding=pad)
+    elif kind == "period":
+        yr = F.conv2d(xin, wr, br, stride=(s, 1), padding=(pad, 0))
+    else:
+        yr = F.conv1d(xin, wr, br, stride=s, padding=pad, dilation=d)
+    gy = t(*yr.shape)
+    yr.backward(gy.double())
+    errs, grads = {}, {}
+    try:
+        for mode in ("x3-9", "x3-9b", "x3-6", "pk"):
+            ops.set_f32_split(mode != "pk", terms=6 if mode == "x3-6" else 9, wgrad=True)
+            before = dict(ops.LAUNCH_COUNTS)
+            xg, wg, bg = x.to(gpu), w.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+            if kind == "convT":
+                yg = ops.conv_transpose1d(xg, wg, bg, stride=s, pad=pad, in_leaky=in_leaky, slope=0.1)
+            else:
+                yg = ops.conv1d(xg, wg, bg, stride=s, pad=pad, dil=d, in_leaky=in_leaky, slope=0.1)
+            yg.backward(gy.to(gpu))
+            used = ops.LAUNCH_COUNTS["wgrad_x3"] - before["wgrad_x3"]
+            assert used == (0 if mode == "pk" else 1), (mode, used)
+            errs[mode] = (rel64(wg.grad, wr.grad), rel64(bg.grad, br.grad))
+            grads[mode] = wg.grad.detach().clone()
+    finally:
+        ops.set_f32_split(True, terms=6, wgrad=False)
+    record_stats("x3wgrad", "%s-C%d-M%d-T%d-K%d-s%d-P%d" % (kind, C, M, T, K, s, P),
+                 **{"%s_%s" % (m.replace("-", "_"), n): v for m, e in errs.items() for n, v in zip(("dw", "db"), e)})
+    assert torch.equal(grads["x3-9"], grads["x3-9b"]), "two identical launches differ"
+    for mode, (ew, eb) in errs.items():
+        assert ew < 3e-5 and eb < 3e-5, (mode, ew, eb)
+    assert errs["x3-9"][0] <= 3 * errs["pk"][0] + 3e-7 and errs["x3-6"][0] <= 4 * errs["pk"][0] + 6e-7, errs

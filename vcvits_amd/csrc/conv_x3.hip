@@ -413,7 +413,12 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   return true;
 }
 
-int g_terms = [] { const char* e = getenv("VCVITS_X3_TERMS"); return e && atoi(e) == 6 ? 6 : 9; }();
+// default: six product terms.  Measured against float64 on the layer shapes of both configs (tests/test_conv_x3_gpu.py,
+// profiles/r3_x3_vs_f64.txt) the six- and nine-term results have the same error to three digits, 2e-7 .. 1e-6 of the
+// output scale -- the error of the fp32 accumulation order, as large for the fp32-input MFMA kernel -- because each left
+// out term is below 2^-24 of its product while one accumulator rounding is 2^-24 of the whole running sum.
+int g_all = getenv("VCVITS_X3_ALL") != nullptr ? 1 : 0;
+int g_terms = [] { const char* e = getenv("VCVITS_X3_TERMS"); return e && atoi(e) == 9 ? 9 : 6; }();
 
 template <int NTERM, int TM, int TN, int WM, int WN>
 int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
@@ -468,11 +473,26 @@ extern "C" int vcv_conv_x3_set_terms(int n) {
   return VCV_OK;
 }
 extern "C" int vcv_conv_x3_get_terms(void) { return g_terms; }
+// all != 0: take every eligible launch (tests); 0: only the shapes where this kernel is the faster one (wanted())
+extern "C" int vcv_conv_x3_set_all(int all) {
+  g_all = all ? 1 : 0;
+  return VCV_OK;
+}
 
 // Same calling convention as vcv_conv_pk_plan / vcv_conv_pk_run: out[0] = size of the packed-weight buffer in 4-byte
 // words, out[1] = floats of per-launch scratch, out[2] = signature of the pack layout.
+// Where the split kernel is ahead of the fp32-input MFMA kernel (conv_pk.hip) in the training step
+// (tools/prof_compare.py on the bench workload): everything but the 32-channel layers and the 64-channel k <= 3 layers,
+// whose few reduction stages per tile leave the prologue / epilogue exposed.
+static bool wanted(const VcvConvArgs& a) {
+  if (g_all) return true;
+  if (a.Cg <= 32) return false;
+  if (a.Cg <= 64 && a.K <= 3) return false;
+  return true;
+}
+
 extern "C" int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out) {
-  if (!args || !out || !eligible(*args)) return VCV_EINVAL;
+  if (!args || !out || !eligible(*args) || !wanted(*args)) return VCV_EINVAL;
   Plan pl;
   if (!choose(*args, pl)) return VCV_EINVAL;
   out[0] = (int64_t)((pl.pack_bytes + 3) / 4);
@@ -482,7 +502,7 @@ extern "C" int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out)
 }
 
 extern "C" int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream) {
-  if (!args || !pack_ws || !eligible(*args)) return VCV_EINVAL;
+  if (!args || !pack_ws || !eligible(*args) || !wanted(*args)) return VCV_EINVAL;
   Plan pl;
   if (!choose(*args, pl)) return VCV_EINVAL;
   if (pl.g.ks > 1 && !scratch_ws) return VCV_EINVAL;

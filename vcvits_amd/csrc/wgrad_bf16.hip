@@ -35,6 +35,7 @@ struct WbGeom {
   int XR;              // staged x rows per stage (multiple of 16)
   int pa, pb;          // row pitches (bytes) of the two images
   int a_bytes, buf_bytes;
+  int a_plane, x_plane;  // bytes between the term planes of an image (split-operand launches)
 };
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -50,10 +51,13 @@ __device__ __forceinline__ bf16x8 tr_pair(const lds_char* p0, const lds_char* p1
 
 // WM x WC waves tile the (m, c) block, WU waves split the 16-position steps of a stage; each wave owns TM x 1 MFMA
 // tiles per tap and KT tap accumulators.
-template <int WM, int WC, int WU, int KT, int MAXT>
+// NT = 1: operands rounded to bf16.  NT = 6 / 9: exact fp32 operands as three bf16 terms each (conv_x3.hip's arithmetic):
+// three image planes per operand, NT MFMAs per fragment pair.
+template <int WM, int WC, int WU, int KT, int MAXT, int NT>
 __global__ void __launch_bounds__(64 * WM * WC * WU)
 wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ slab) {
   constexpr int BM = 32 * WM, BC = 32 * WC, NW = WM * WC * WU;
+  constexpr int PL = NT == 1 ? 1 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,23 +157,34 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
         const bool lk = isA ? p.a_tf == VCV_TF_LEAKY : p.b_tf == VCV_TF_LEAKY;
         char* img = isA ? Ya : Xb;
         const int pitch = isA ? PA : PB;
+        const int plane = isA ? tg.a_plane : tg.x_plane;  // bytes between the term planes of an image
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          bf16x8 v;
+          bf16x8 v, v1, v2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float f = xr[t][e][j];
             if (lk) f = fmaxf(f, f * p.slope);
             v[e] = (__bf16)f;
+            if (PL == 3) {
+              const float r1 = f - (float)v[e];  // exact
+              v1[e] = (__bf16)r1;
+              v2[e] = (__bf16)(r1 - (float)v1[e]);
+            }
           }
-          *reinterpret_cast<bf16x8*>(img + (size_t)(pblk * 64 + lpq * 4 + j) * pitch + (quad * 4 + lg8) * 16) = v;
+          char* dst = img + (size_t)(pblk * 64 + lpq * 4 + j) * pitch + (quad * 4 + lg8) * 16;
+          *reinterpret_cast<bf16x8*>(dst) = v;
+          if (PL == 3) {
+            *reinterpret_cast<bf16x8*>(dst + plane) = v1;
+            *reinterpret_cast<bf16x8*>(dst + 2 * plane) = v2;
+          }
         }
       }
     }
   };
   // tab[u] = x row (relative to the staged span) that tap offset tap_lo of position u reads
   auto build_tab = [&](int ch, int buf) {
-    int* tab = (int*)(smem + buf * tg.buf_bytes + tg.a_bytes + tg.XR * PB);
+    int* tab = (int*)(smem + buf * tg.buf_bytes + tg.a_bytes + PL * tg.x_plane);
     if (tid < BU) {
       const int b = ch / tg.nchunk_u;
       const int uc0 = (ch - b * tg.nchunk_u) * BU;
@@ -202,18 +217,36 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
       if (more) load(ch + tg.Z);
       const lds_char* Ya = (const lds_char*)smem + bufi * tg.buf_bytes;  // 32-bit LDS addresses from here on
       const lds_char* Xb = Ya + tg.a_bytes;
-      const int* tab = (const int*)(smem + bufi * tg.buf_bytes + tg.a_bytes + tg.XR * PB);
+      const int* tab = (const int*)(smem + bufi * tg.buf_bytes + tg.a_bytes + PL * tg.x_plane);
       for (int i16 = wu; i16 < BU / 16; i16 += WU) {
         const int ur = i16 * 16 + rowl;
-        const bf16x8 a = tr_pair(Ya + ur * PA + colA, Ya + (ur + 4) * PA + colA);
+        bf16x8 a[PL];
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) a[pl] = tr_pair(Ya + pl * tg.a_plane + ur * PA + colA, Ya + pl * tg.a_plane + (ur + 4) * PA + colA);
         const lds_char* x0 = Xb + tab[ur] + colB;
         const lds_char* x1 = Xb + tab[ur + 4] + colB;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           if (k < kn) {
             const int ro = ((k0 + k) * p.dj - tap_lo) * P * PB;
-            const bf16x8 bb = tr_pair(x0 + ro, x1 + ro);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[k], 0, 0, 0);
+            bf16x8 bb[PL];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) bb[pl] = tr_pair(x0 + pl * tg.x_plane + ro, x1 + pl * tg.x_plane + ro);
+            if (PL == 1) {
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc[k], 0, 0, 0);
+            } else {  // small terms first (literal plane indices: see conv_x3.hip)
+              if (NT == 9) {
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], bb[PL - 1], acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL / 2], bb[PL - 1], acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], bb[PL / 2], acc[k], 0, 0, 0);
+              }
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[PL - 1], acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], bb[0], acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL / 2], bb[PL / 2], acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[PL / 2], acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL / 2], bb[0], acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc[k], 0, 0, 0);
+            }
           }
         }
       }
@@ -329,7 +362,7 @@ constexpr int MAXT = 2;
 
 struct Cfg { int WM, WC, WU, KT; };
 
-bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds) {
+bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
   const int BM = 32 * c.WM, BC = 32 * c.WC, NW = c.WM * c.WC * c.WU;
   g.nmt = vcv_cdiv(a.Mg, BM);
   g.nct = vcv_cdiv(a.Cg, BC);
@@ -342,8 +375,10 @@ bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds) {
   auto pitch = [](int w) { const int b = w * 2; return b >= 128 ? b + 64 : b; };
   g.pa = pitch(BM);
   g.pb = pitch(BC);
-  g.a_bytes = BU * g.pa;
-  g.buf_bytes = g.a_bytes + g.XR * g.pb + BU * 4;
+  g.a_plane = BU * g.pa;
+  g.x_plane = g.XR * g.pb;
+  g.a_bytes = PL * g.a_plane;
+  g.buf_bytes = g.a_bytes + PL * g.x_plane + BU * 4;
   lds = 2ull * g.buf_bytes;
   const size_t red = c.WU > 1 ? (size_t)c.WM * c.WC * c.KT * 16 * 64 * 4 : 0;
   if (red > lds) lds = red;
@@ -355,7 +390,7 @@ bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds) {
   return true;
 }
 
-template <int WM, int WC, int WU, int KT>
+template <int WM, int WC, int WU, int KT, int NT>
 int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, int64_t scratch_floats, hipStream_t st) {
   WbGeom g = g0;
   const long long total = (long long)a.B * g.nchunk_u;
@@ -372,12 +407,12 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
     if (cost < best - 1e-9) best = cost, Z = z;
   }
   g.Z = (int)Z;
-  auto kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT>;
+  auto kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT, NT>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VCV_EHIP;
   dim3 grid(g.nct * g.ntg, g.nmt, g.Z), block(64 * WM * WC * WU);
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
-  const int tag[12] = {a.B, 2, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, WM * 32 * 1000 + WC * 32, KT};
+  const int tag[12] = {a.B, NT == 1 ? 2 : 3, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, WM * 32 * 1000 + WC * 32, NT * 100 + KT};
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
@@ -391,7 +426,7 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   return vcv_check_launch();
 }
 
-bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds) {
+bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
   const bool tf_ok = (a.a_tf == VCV_TF_NONE || a.a_tf == VCV_TF_LEAKY) && (a.b_tf == VCV_TF_NONE || a.b_tf == VCV_TF_LEAKY) &&
                      a.slope >= 0.f && a.slope < 1.f;
   const long long U = (long long)a.Ta * a.P;
@@ -399,6 +434,8 @@ bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds) {
     return false;
   if (U * 4 >= (1ll << 31) || (long long)a.Tb * a.P * 4 >= (1ll << 31)) return false;
   c.KT = a.K == 1 ? 1 : a.K <= 3 ? 3 : a.K <= 5 ? 5 : (a.K == 7 || a.K == 8 || a.K >= 15) ? 8 : 6;
+  // (three term planes: eight tap accumulators + nine fragments do not fit 256 registers; K = 7 runs as 4 + 3 taps)
+  if (PL == 3 && c.KT == 8) c.KT = 4;
   // (WM, WC, WU) candidates, widest tile first; a candidate that does not fit the LDS / staging budget (long x spans of
   // the wide-period layouts) falls through to a narrower channel tile
   static const int cand[6][3] = {{4, 2, 1}, {4, 1, 2}, {2, 2, 2}, {2, 1, 4}, {1, 2, 4}, {1, 1, 8}};
@@ -407,20 +444,17 @@ bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds) {
     if (bm > 32 && bm > a.Mg) continue;
     if (bc > 32 && bc > ((a.Cg + 31) & ~31)) continue;
     c.WM = cand[i][0]; c.WC = cand[i][1]; c.WU = cand[i][2];
-    if (geometry(a, c, g, lds)) return true;
+    if (geometry(a, c, g, lds, PL)) return true;
   }
   return false;
 }
 
-}  // namespace
 
-// Scratch floats the launch wants (0: not eligible -> the caller uses vcv_conv_wgrad).  The kernel takes any scratch
-// >= Mg*Cg*K floats and splits the reduction as far as the scratch allows.
-extern "C" int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* a) {
+int64_t scratch_want(const VcvWgradArgs* a, int PL) {
   Cfg c;
   WbGeom g;
   size_t lds;
-  if (!a || !pick(*a, c, g, lds)) return 0;
+  if (!a || !pick(*a, c, g, lds, PL)) return 0;
   const long long total = (long long)a->B * g.nchunk_u;
   const long long tiles = (long long)g.nmt * g.nct * g.ntg;
   long long z = (512 + tiles - 1) / tiles;
@@ -433,14 +467,17 @@ extern "C" int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* a) {
 }
 
 #define WB_CASE(wm, wc, wu, kt) \
-  if (c.WM == wm && c.WC == wc && c.WU == wu && c.KT == kt) return launch<wm, wc, wu, kt>(*a, g, lds, scratch, scratch_floats, st)
-#define WB_KT(wm, wc, wu) WB_CASE(wm, wc, wu, 1); WB_CASE(wm, wc, wu, 3); WB_CASE(wm, wc, wu, 5); WB_CASE(wm, wc, wu, 6); WB_CASE(wm, wc, wu, 8)
+  if (c.WM == wm && c.WC == wc && c.WU == wu && c.KT == kt) return launch<wm, wc, wu, kt, NT>(*a, g, lds, scratch, scratch_floats, st)
+#define WB_KT(wm, wc, wu)                                                                        \
+  WB_CASE(wm, wc, wu, 1); WB_CASE(wm, wc, wu, 3); WB_CASE(wm, wc, wu, 5); WB_CASE(wm, wc, wu, 6); \
+  if constexpr (NT == 1) { WB_CASE(wm, wc, wu, 8); } else { WB_CASE(wm, wc, wu, 4); }
 
-extern "C" int vcv_wgrad_bf16(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* stream) {
+template <int NT>
+int run(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* stream) {
   Cfg c;
   WbGeom g;
   size_t lds;
-  if (!a || !scratch || !pick(*a, c, g, lds)) return VCV_EINVAL;
+  if (!a || !scratch || !pick(*a, c, g, lds, NT == 1 ? 1 : 3)) return VCV_EINVAL;
   if (scratch_floats < (int64_t)a->Mg * a->Cg * a->K) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   WB_KT(4, 2, 1);
@@ -450,4 +487,21 @@ extern "C" int vcv_wgrad_bf16(const VcvWgradArgs* a, float* scratch, int64_t scr
   WB_KT(1, 2, 4);
   WB_KT(1, 1, 8);
   return VCV_EINVAL;
+}
+
+}  // namespace
+
+// Scratch floats the launch wants (0: not eligible -> the caller uses vcv_conv_wgrad).  The kernel takes any scratch
+// >= Mg*Cg*K floats and splits the reduction as far as the scratch allows.
+extern "C" int64_t vcv_wgrad_bf16_scratch(const VcvWgradArgs* a) { return scratch_want(a, 1); }
+extern "C" int vcv_wgrad_bf16(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* stream) {
+  return run<1>(a, scratch, scratch_floats, stream);
+}
+
+// The same kernel on exact fp32 operands split into three bf16 terms each (the arithmetic of conv_x3.hip; the number of
+// product terms is the one set with vcv_conv_x3_set_terms): fp32 weight gradients at the bf16 MFMA rate.
+extern "C" int vcv_conv_x3_get_terms(void);
+extern "C" int64_t vcv_wgrad_x3_scratch(const VcvWgradArgs* a) { return scratch_want(a, 3); }
+extern "C" int vcv_wgrad_x3(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* stream) {
+  return vcv_conv_x3_get_terms() == 6 ? run<6>(a, scratch, scratch_floats, stream) : run<9>(a, scratch, scratch_floats, stream);
 }

@@ -47,12 +47,24 @@ _USE_PK = [__import__("os").environ.get("VCVITS_CONV_PK", "1") == "1"]
 _USE_X3 = [__import__("os").environ.get("VCVITS_CONV_X3", "1") == "1"]
 
 
-def set_f32_split(on, terms=None):
+# the weight gradient in the same arithmetic (vcv_wgrad_x3: wgrad_bf16.hip with three term planes).  Off by default: that
+# kernel stages in its MFMA waves and is staging-bound with three planes (63-66 TFLOP/s in the step against 88 for the
+# warp-specialised fp32 kernel, wgrad_dma.hip); it is kept for its determinism and for the day it gets producer waves.
+_USE_X3_WGRAD = [__import__("os").environ.get("VCVITS_WGRAD_X3", "0") == "1"]
+
+
+def set_f32_split(on, terms=None, all_shapes=None, wgrad=None):
     """fp32 GEMM-shaped launches on the bf16 matrix pipe by exact operand splitting (True, default) or on fp32-input MFMAs
-    (False: bit-for-bit an fmaf chain).  terms: 9 (all bf16 products) or 6 (the three below 2^-24 of the product left out)."""
+    (False: bit-for-bit an fmaf chain).  terms: 6 (default: the three products below 2^-24 of the fp32 product left out) or
+    9 (all bf16 products); all_shapes: take every eligible launch, not only the shapes where the split kernel is faster;
+    wgrad: weight gradients in the same arithmetic too."""
     _USE_X3[0] = bool(on)
     if terms is not None:
         check(lib().vcv_conv_x3_set_terms(int(terms)), "vcv_conv_x3_set_terms")
+    if all_shapes is not None:
+        check(lib().vcv_conv_x3_set_all(1 if all_shapes else 0), "vcv_conv_x3_set_all")
+    if wgrad is not None:
+        _USE_X3_WGRAD[0] = bool(wgrad)
 
 
 # Arithmetic of the GEMM-shaped kernels: "f32" (fp32-input MFMA, exact fp32) or "bf16" (operands rounded to bf16 on
@@ -62,7 +74,7 @@ _COMPUTE = ["f32"]
 
 
 # which kernel family each GEMM-shaped launch went to (tests assert that the bf16 path really ran)
-LAUNCH_COUNTS = {"bf16": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad": 0}
+LAUNCH_COUNTS = {"bf16": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad_x3": 0, "wgrad": 0}
 
 
 def set_compute_dtype(name):
@@ -131,13 +143,17 @@ def _launch_wgrad(a):
         n = min(nw * 512, max(nw * 4, 24 << 20))
         slab = torch.empty((n,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
         a.slab, a.slab_floats = ptr(slab), n
-    if _COMPUTE[0] == "bf16":
+    if _COMPUTE[0] == "bf16" or (_USE_X3[0] and _USE_X3_WGRAD[0]):
         L = lib()
-        n = L.vcv_wgrad_bf16_scratch(ctypes.byref(a))
+        bf = _COMPUTE[0] == "bf16"
+        n = (L.vcv_wgrad_bf16_scratch if bf else L.vcv_wgrad_x3_scratch)(ctypes.byref(a))
         if n > 0:
             scratch = torch.empty((n,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
-            check(L.vcv_wgrad_bf16(ctypes.byref(a), ptr(scratch), n, stream()), "vcv_wgrad_bf16")
-            LAUNCH_COUNTS["wgrad_bf16"] += 1
+            if bf:
+                check(L.vcv_wgrad_bf16(ctypes.byref(a), ptr(scratch), n, stream()), "vcv_wgrad_bf16")
+            else:
+                check(L.vcv_wgrad_x3(ctypes.byref(a), ptr(scratch), n, stream()), "vcv_wgrad_x3")
+            LAUNCH_COUNTS["wgrad_bf16" if bf else "wgrad_x3"] += 1
             return
     LAUNCH_COUNTS["wgrad"] += 1
     check(lib().vcv_conv_wgrad(ctypes.byref(a), stream()), "vcv_conv_wgrad")
