@@ -48,10 +48,12 @@ GFLOP_PER_UTT = {("base", "vocoder"): 400.0, ("base", "full"): 488.0, ("48k", "v
                  ("48k", "infer"): 770.0, ("base", "infer"): 788.0}
 # profiler classes of the library (csrc/prof.h) and the kernel families (rocprofv3 names) each one times
 PROF_CLASSES = ["conv_gemm_kernel (register-staged)", "conv_wgrad_kernel (register-staged)",
-                "packed-weight conv kernels: fwd + dgrad + convT (conv_pk_kernel<F32El | Bf16El>, conv_dma_kernel)",
-                "weight-gradient kernels (wgrad_dma_kernel, wgrad_bf16_kernel)"]
-PROF_FAMILIES = [["conv_gemm_kernel"], ["conv_wgrad_kernel"], ["conv_pk_kernel", "conv_dma_kernel"],
-                 ["wgrad_dma_kernel", "wgrad_bf16_kernel"]]
+                "packed-weight conv kernels: fwd + dgrad + convT (conv_x3_kernel, conv_pk_kernel<F32El | Bf16El>, conv_dma_kernel)",
+                "weight-gradient kernels (wgrad_dma_kernel, wgrad_bf16_kernel)",
+                "fused attention kernels (rel_attn_fwd / bwd_rows / bwd_cols)"]
+PROF_FAMILIES = [["conv_gemm_kernel"], ["conv_wgrad_kernel"], ["conv_x3_kernel", "conv_pk_kernel", "conv_dma_kernel"],
+                 ["wgrad_dma_kernel", "wgrad_bf16_kernel"], ["rel_attn_fwd_kernel", "rel_attn_bwd_rows_kernel", "rel_attn_bwd_cols_kernel"]]
+NCLS = len(PROF_CLASSES)
 
 
 def kernel_source_hash():
@@ -326,10 +328,10 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     peak = PEAK_TFLOPS[dtype]
     roof = None
     if prof:
-        out = (ctypes.c_double * 12)()
-        nbytes = (ctypes.c_double * 4)()
-        _lib.check(L.vcv_prof_end(out, 4), "vcv_prof_end")
-        _lib.check(L.vcv_prof_bytes(nbytes, 4), "vcv_prof_bytes")
+        out = (ctypes.c_double * (3 * NCLS))()
+        nbytes = (ctypes.c_double * NCLS)()
+        _lib.check(L.vcv_prof_end(out, NCLS), "vcv_prof_end")
+        _lib.check(L.vcv_prof_bytes(nbytes, NCLS), "vcv_prof_bytes")
         if os.environ.get("VCVITS_PROF_DUMP"):
             L.vcv_prof_dump(os.environ["VCVITS_PROF_DUMP"].encode())
 
@@ -343,7 +345,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
                     "gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms * 1e-3 / dt, 3),
                     "algorithmic_bytes_per_launch": round(nbytes[i] / n) if nbytes[i] > 0 else None}
 
-        fams = [c for c in (cls(i) for i in range(4)) if c]
+        fams = [c for c in (cls(i) for i in range(NCLS)) if c]
         if fams:
             # the dominant kernel family by time carries the roofline; the others ride along for the record
             dom = max(fams, key=lambda c: c["share_of_step_time"])

@@ -343,6 +343,24 @@ int vcv_rel_softmax_bwd(const float* P, const float* Pd, float* dP, const float*
                         const float* embk, const float* embv, const float* mask, float* dSt, float* dqband,
                         float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale,
                         void* stream);
+
+/*
+ * Fused relative-position self-attention (attention.hip), replacing the four / six launches above per layer
+ * (relative_attention_transformer.py:150-182 and its autograd): QK^T, banded relative-key logits, masked_fill(-1e4),
+ * softmax, dropout, P.V + banded relative values in ONE launch; the backward pass in two (row pass: dP, dS, dQ, table
+ * gradients; column pass: dV, dK).  Both contractions on the matrix cores (bf16 != 0: operands rounded to bf16, fp32
+ * accumulate).  q / k / v / out / dO / dq / dk / dv: [B, H*dk, T]; embk / embv: [2w+1, dk]; mask: [B, T]; P / Pd / dS:
+ * [B*H, T, T] (forward: P and Pd may each be NULL = not wanted; the backward pass regenerates the dropout mask from
+ * `seed`).  vcv_rel_attn_supported() == 0 for the shapes these kernels take (dk <= 64 and even, T <= 1024, 2w+1 <= 16).
+ */
+int vcv_rel_attn_supported(int B, int H, int dk, int T, int w);
+int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                     const float* mask, float* out, float* P, float* Pd, int B, int H, int dk, int T, int w, float qscale,
+                     float pdrop, uint64_t seed, int bf16, void* stream);
+int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                     const float* mask, const float* P, const float* dO, float* dS, float* dq, float* dk_out, float* dv,
+                     float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale, float pdrop,
+                     uint64_t seed, int bf16, void* stream);
 /* nn.Dropout (relative_attention_transformer.py:40,44,292): y = x * mask(seed, index) / (1-p); the
  * backward is the same call on dy with the same seed */
 int vcv_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
@@ -367,7 +385,7 @@ int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float* dx, int B
  * vcv_prof_begin arms a pool of `max_launches` event pairs; every vcv_conv_gemm / vcv_conv_dma /
  * vcv_conv_wgrad launch then records one pair around its MFMA kernel on its own stream.  vcv_prof_end
  * synchronises and fills out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic flops}, cls 0 =
- * conv_gemm_kernel, 1 = conv_wgrad_kernel, 2 = conv_dma_kernel, 3 = wgrad_dma_kernel (ncls >= 4). ---- */
+ * conv_gemm_kernel, 1 = conv_wgrad_kernel, 2 = packed-weight conv kernels, 3 = weight-gradient kernels, 4 = fused attention (ncls >= 5). ---- */
 int vcv_prof_begin(int max_launches);
 int vcv_prof_end(double* out, int ncls);
 /* out[cls] = algorithmic HBM bytes (operands read once + result written once) summed over the class's launches of the

@@ -67,10 +67,10 @@ def timeit(fn):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    out = (ctypes.c_double * 12)()
-    LIB.vcv_prof_end(out, 4)
-    n = sum(out[3 * i] for i in range(4))
-    ms = sum(out[3 * i + 1] for i in range(4))
+    out = (ctypes.c_double * 15)()
+    LIB.vcv_prof_end(out, 5)
+    n = sum(out[3 * i] for i in range(5))
+    ms = sum(out[3 * i + 1] for i in range(5))
     wall = e0.elapsed_time(e1) / a.reps
     return ms / a.reps if n >= a.reps else wall
 

@@ -1,0 +1,421 @@
+// attention.hip -- fused relative-position self-attention of the content encoder
+// (vits/model/transformer/relative_attention_transformer.py:150-182: scores = (q / sqrt(dk)) k^T + banded relative-key
+// logits, masked_fill(mask == 0, -1e4), softmax, dropout, p v + banded relative values), forward and backward, one
+// launch forward and two backward (row pass, column pass) per layer instead of four and six.
+//
+// Both contractions run on the matrix cores straight from the [B, C, T] activations -- fp32 inputs:
+// v_mfma_f32_32x32x2_f32 (exact fp32); bf16 mode: operands rounded to bf16 on the way in, v_mfma_f32_32x32x16_bf16,
+// fp32 accumulate -- with no packing and no materialised transposes:
+//   * QK^T (and dP = dO^T V in the backward pass): reduction over the head's channels d; both operands are read as
+//     x[d][t .. t + 31], one coalesced 128-byte run per half-wave and reduction step.
+//   * P V^T, dQ = dS K^T (reduction over keys j): the probability tile of the workgroup's 32 query rows lives in LDS
+//     ([32][TP], TP = 2 mod 64: the fragment reads of the 64 lanes hit 64 different banks), the other operand is read
+//     per channel row.
+//   * dV = Pd^T dO, dK = dS^T Q (reduction over queries i): column pass, P and dS re-read from HBM (T^2 floats per head).
+// Softmax, the banded relative terms, the -1e4 fill and dropout (counter-based mask regenerated from (seed, index): the
+// dropped probabilities are never stored for the backward pass) are VALU phases on the LDS tile between the two
+// contractions.  The probabilities go to HBM only when the caller wants them (training: the backward pass; `attn`).
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wsum_all(float s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+__device__ __forceinline__ float wmax_all(float s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s = fmaxf(s, __shfl_xor(s, o, 64));
+  return s;
+}
+// the dropout mask of vits_blocks.hip (vcv_dropout / the unfused attention path): same stream, same masks
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
+struct AttnArgs {
+  const float *q, *k, *v, *embk, *embv, *mask, *dO;
+  const float* Pin;       // saved probabilities (backward)
+  float *out, *P, *Pd;    // forward outputs (P / Pd may be null)
+  float *dS, *dq, *dk_, *dv, *dembk, *dembv;
+  int B, H, dk, T, w, TP;
+  float qscale, pdrop;
+  unsigned long long seed;
+};
+
+// One MFMA step: F32: 2 reduction elements (lane half h supplies element 2s + h); BF16: 16 (lane half h supplies
+// elements 16s + 8h .. + 7).  val(k) returns the operand element of reduction index k for this lane's row / column.
+template <bool BF> struct Op;
+template <> struct Op<false> {
+  typedef float frag;
+  static constexpr int KS = 2;
+  template <class F> static __device__ __forceinline__ frag make(int s, int h, F&& val) { return val(2 * s + h); }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+template <> struct Op<true> {
+  typedef bf16x8 frag;
+  static constexpr int KS = 16;
+  template <class F> static __device__ __forceinline__ frag make(int s, int h, F&& val) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)val(16 * s + 8 * h + e);
+    return v;
+  }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int RELP = 16;   // relative positions held per row (2w + 1 <= 16)
+constexpr int OP = 33;     // pitch of the partial-output tiles
+
+// row m of accumulator element e of lane half h (32x32 MFMA output layout; the lane's l31 is the column)
+__device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// T1[32][TP] = alpha * A^T B for the 32 rows i0.. of A: T1[m][j] = alpha * sum_d A[d][i0 + m] * Bm[d][j]  (phase 1 of the
+// forward and of the backward row pass).  Key tiles are dealt to the 4 waves.
+template <bool BF>
+__device__ __forceinline__ void rows_times_keys(const float* __restrict__ A, const float* __restrict__ Bm, float* T1, int i0, int T,
+                                                int dk, int TP, float alpha, int wave, int lane) {
+  typedef Op<BF> O;
+  const int l31 = lane & 31, h = lane >> 5;
+  constexpr int MAXS = 64 / O::KS;  // dk <= 64
+  const int nks = (dk + O::KS - 1) / O::KS;
+  typename O::frag fa[MAXS];
+  const int i = i0 + l31;
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < nks) fa[s] = O::make(s, h, [&](int d) { return (d < dk && i < T) ? A[(size_t)d * T + i] : 0.f; });
+  const int nkt = (T + 31) >> 5;
+  for (int jt = wave; jt < nkt; jt += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int j = jt * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+      if (s < nks) {
+        const typename O::frag fb = O::make(s, h, [&](int d) { return (d < dk && j < T) ? Bm[(size_t)d * T + j] : 0.f; });
+        acc = O::mma(fa[s], fb, acc);
+      }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) T1[acc_row(e, h) * TP + jt * 32 + l31] = acc[e] * alpha;
+  }
+}
+
+// out[d][i0 + m] = alpha * (sum_j T1[m][j] * Bm[d][j] + sum_r T1[m][i0 + m + r - w] * emb[r][d])  (phase 3 of the forward:
+// P V^T + relative values; of the backward row pass: dS K^T + relative keys).  The dk / 32 column tiles and the key range
+// are dealt to the 4 waves; partial tiles meet in `red`.
+template <bool BF>
+__device__ __forceinline__ void tile_times_rows(const float* T1, const float* __restrict__ Bm, const float* __restrict__ emb,
+                                                float* __restrict__ out, float* red, int i0, int T, int dk, int TP, int w,
+                                                float alpha, int wave, int lane, int tid) {
+  typedef Op<BF> O;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nt = (dk + 31) >> 5;         // column tiles (1 or 2)
+  const int wpt = nt == 1 ? 4 : 2;       // waves per column tile
+  const int tile = nt == 1 ? 0 : (wave & 1), kp = nt == 1 ? wave : (wave >> 1);
+  const int nsteps = (T + O::KS - 1) / O::KS;
+  const int s0 = kp * nsteps / wpt, s1 = (kp + 1) * nsteps / wpt;
+  const int d = tile * 32 + l31;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* Trow = T1 + l31 * TP;
+  const float* Brow = Bm + (size_t)(d < dk ? d : 0) * T;
+  for (int s = s0; s < s1; ++s) {
+    const typename O::frag fa = O::make(s, h, [&](int j) { return Trow[j]; });  // (columns >= T of the tile are zero)
+    const typename O::frag fb = O::make(s, h, [&](int j) { return (d < dk && j < T) ? Brow[j] : 0.f; });
+    acc = O::mma(fa, fb, acc);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 32 + acc_row(e, h)) * OP + l31] = acc[e];
+  __syncthreads();
+  const int nr = 2 * w + 1;
+  for (int idx = tid; idx < 32 * dk; idx += 256) {
+    const int m = idx & 31, dd = idx >> 5;
+    const int i = i0 + m;
+    if (i >= T) continue;
+    const int tl = dd >> 5, n = dd & 31;
+    float s = 0.f;
+    for (int k2 = 0; k2 < wpt; ++k2) s += red[((nt == 1 ? k2 : k2 * 2 + tl) * 32 + m) * OP + n];
+    for (int r = 0; r < nr; ++r) {
+      const int j = i + r - w;
+      if (j >= 0 && j < T) s += T1[m * TP + j] * emb[r * dk + dd];
+    }
+    out[(size_t)dd * T + i] = s * alpha;
+  }
+}
+
+// rel[m][r] = alpha * sum_d A[d][i0 + m] * emb[r][d]
+__device__ __forceinline__ void band_dots(const float* __restrict__ A, const float* __restrict__ emb, float* rel, int i0, int T, int dk,
+                                          int nr, float alpha, int tid) {
+  for (int idx = tid; idx < 32 * nr; idx += 256) {
+    const int m = idx & 31, r = idx >> 5;
+    float s = 0.f;
+    if (i0 + m < T)
+      for (int d = 0; d < dk; ++d) s += A[(size_t)d * T + i0 + m] * emb[r * dk + d];
+    rel[m * RELP + r] = s * alpha;
+  }
+}
+
+template <bool BF>
+__global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T, dk = p.dk, TP = p.TP, nr = 2 * p.w + 1;
+  float* S = sm;
+  float* rel = S + 32 * TP;
+  float* red = rel + 32 * RELP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.y, b = g / p.H, i0 = blockIdx.x * 32;
+  const float* qg = p.q + (size_t)g * dk * T;
+  const float* kg = p.k + (size_t)g * dk * T;
+  const float* vg = p.v + (size_t)g * dk * T;
+  const float* mrow = p.mask + (size_t)b * T;
+
+  band_dots(qg, p.embk, rel, i0, T, dk, nr, p.qscale, tid);
+  rows_times_keys<BF>(qg, kg, S, i0, T, dk, TP, p.qscale, wave, lane);
+  __syncthreads();
+  // softmax of the wave's 8 rows
+  const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
+  for (int rr = 0; rr < 8; ++rr) {
+    const int m = wave * 8 + rr, i = i0 + m;
+    float* Sr = S + m * TP;
+    if (i >= T) {
+      for (int j = lane; j < TP; j += 64) Sr[j] = 0.f;
+      continue;
+    }
+    const float mi = mrow[i];
+    float mx = -INFINITY;
+    for (int j = lane; j < T; j += 64) {
+      float v = Sr[j];
+      const int r = j - i + p.w;
+      if (r >= 0 && r < nr) v += rel[m * RELP + r];
+      if (mi * mrow[j] == 0.f) v = -1e4f;
+      Sr[j] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = wmax_all(mx);
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      const float e = expf(Sr[j] - mx);
+      Sr[j] = e;
+      sum += e;
+    }
+    sum = wsum_all(sum);
+    const float inv = 1.f / sum;
+    const size_t rowoff = ((size_t)g * T + i) * T;
+    for (int j = lane; j < TP; j += 64) {
+      float pd = 0.f;
+      if (j < T) {
+        const float pv = Sr[j] * inv;
+        if (p.P) p.P[rowoff + j] = pv;
+        pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, rowoff + j, p.pdrop, inv_keep) : pv;
+        if (p.Pd) p.Pd[rowoff + j] = pd;
+      }
+      Sr[j] = pd;
+    }
+  }
+  __syncthreads();
+  tile_times_rows<BF>(S, vg, p.embv, p.out + (size_t)g * dk * T, red, i0, T, dk, TP, p.w, 1.f, wave, lane, tid);
+}
+
+// Backward, row pass: per (head, 32 query rows): dPd = dO^T V + band, dS = Pd * dPd - P * sum_j(Pd * dPd) (zero where
+// masked), dS -> HBM, dQ = qscale * (dS K^T + band), and this tile's share of the two relative-position table gradients.
+template <bool BF>
+__global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T, dk = p.dk, TP = p.TP, nr = 2 * p.w + 1;
+  float* D = sm;
+  float* rel = D + 32 * TP;
+  float* red = rel + 32 * RELP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.y, b = g / p.H, i0 = blockIdx.x * 32;
+  const float* qg = p.q + (size_t)g * dk * T;
+  const float* kg = p.k + (size_t)g * dk * T;
+  const float* vg = p.v + (size_t)g * dk * T;
+  const float* og = p.dO + (size_t)g * dk * T;
+  const float* mrow = p.mask + (size_t)b * T;
+  const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
+
+  band_dots(og, p.embv, rel, i0, T, dk, nr, 1.f, tid);
+  rows_times_keys<BF>(og, vg, D, i0, T, dk, TP, 1.f, wave, lane);
+  __syncthreads();
+  for (int rr = 0; rr < 8; ++rr) {
+    const int m = wave * 8 + rr, i = i0 + m;
+    float* Dr = D + m * TP;
+    if (i >= T) {
+      for (int j = lane; j < TP; j += 64) Dr[j] = 0.f;
+      continue;
+    }
+    const size_t rowoff = ((size_t)g * T + i) * T;
+    float dot = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      float v = Dr[j];
+      const int r = j - i + p.w;
+      if (r >= 0 && r < nr) v += rel[m * RELP + r];
+      Dr[j] = v;
+      const float pv = p.Pin[rowoff + j];
+      const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, rowoff + j, p.pdrop, inv_keep) : pv;
+      dot += v * pd;
+    }
+    dot = wsum_all(dot);
+    const float mi = mrow[i];
+    for (int j = lane; j < TP; j += 64) {
+      float ds = 0.f;
+      if (j < T) {
+        const float pv = p.Pin[rowoff + j];
+        const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, rowoff + j, p.pdrop, inv_keep) : pv;
+        ds = pd * Dr[j] - pv * dot;
+        if (mi * mrow[j] == 0.f) ds = 0.f;
+        p.dS[rowoff + j] = ds;
+      }
+      Dr[j] = ds;
+    }
+  }
+  __syncthreads();
+  // table gradients of this row tile: dembk[r][d] += qscale * sum_i dS[i][i+r-w] q[d][i];  dembv[r][d] += sum_i Pd[i][i+r-w] dO[d][i]
+  for (int idx = tid; idx < nr * dk; idx += 256) {
+    const int r = idx / dk, d = idx - r * dk;
+    float ek = 0.f, ev = 0.f;
+    for (int m = 0; m < 32; ++m) {
+      const int i = i0 + m, j = i + r - p.w;
+      if (i >= T || j < 0 || j >= T) continue;
+      const size_t off = ((size_t)g * T + i) * T + j;
+      const float pv = p.Pin[off];
+      const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, off, p.pdrop, inv_keep) : pv;
+      ek += D[m * TP + j] * qg[(size_t)d * T + i];
+      ev += pd * og[(size_t)d * T + i];
+    }
+    unsafeAtomicAdd(p.dembk + idx, ek * p.qscale);
+    unsafeAtomicAdd(p.dembv + idx, ev);
+  }
+  tile_times_rows<BF>(D, kg, p.embk, p.dq + (size_t)g * dk * T, red, i0, T, dk, TP, p.w, p.qscale, wave, lane, tid);
+}
+
+// Backward, column pass: per (head, 32 keys): dV[d][j] = sum_i Pd[i][j] dO[d][i], dK[d][j] = qscale * sum_i dS[i][j] q[d][i].
+template <bool BF>
+__global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p) {
+  typedef Op<BF> O;
+  __shared__ float red[2][4 * 32 * OP];
+  const int T = p.T, dk = p.dk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int g = blockIdx.y, j0 = blockIdx.x * 32;
+  const float* qg = p.q + (size_t)g * dk * T;
+  const float* og = p.dO + (size_t)g * dk * T;
+  const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
+  const int nt = (dk + 31) >> 5;
+  const int wpt = nt == 1 ? 4 : 2;
+  const int tile = nt == 1 ? 0 : (wave & 1), kp = nt == 1 ? wave : (wave >> 1);
+  const int nsteps = (T + O::KS - 1) / O::KS;
+  const int s0 = kp * nsteps / wpt, s1 = (kp + 1) * nsteps / wpt;
+  const int d = tile * 32 + l31, j = j0 + l31;
+  const float* orow = og + (size_t)(d < dk ? d : 0) * T;
+  const float* qrow = qg + (size_t)(d < dk ? d : 0) * T;
+  f32x16 av, ak;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) av[e] = ak[e] = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    const typename O::frag fp = O::make(s, h, [&](int i) {
+      if (i >= T || j >= T) return 0.f;
+      const size_t off = ((size_t)g * T + i) * T + j;
+      const float pv = p.Pin[off];
+      return p.pdrop > 0.f ? pv * drop_scale(p.seed, off, p.pdrop, inv_keep) : pv;
+    });
+    const typename O::frag fs = O::make(s, h, [&](int i) { return (i < T && j < T) ? p.dS[((size_t)g * T + i) * T + j] : 0.f; });
+    const typename O::frag fo = O::make(s, h, [&](int i) { return (d < dk && i < T) ? orow[i] : 0.f; });
+    const typename O::frag fq = O::make(s, h, [&](int i) { return (d < dk && i < T) ? qrow[i] : 0.f; });
+    av = O::mma(fp, fo, av);
+    ak = O::mma(fs, fq, ak);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    red[0][(wave * 32 + acc_row(e, h)) * OP + l31] = av[e];
+    red[1][(wave * 32 + acc_row(e, h)) * OP + l31] = ak[e];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 32 * dk; idx += 256) {
+    const int m = idx & 31, dd = idx >> 5;
+    if (j0 + m >= T) continue;
+    const int tl = dd >> 5, n = dd & 31;
+    float sv = 0.f, sk = 0.f;
+    for (int k2 = 0; k2 < wpt; ++k2) {
+      const int wv = nt == 1 ? k2 : k2 * 2 + tl;
+      sv += red[0][(wv * 32 + m) * OP + n];
+      sk += red[1][(wv * 32 + m) * OP + n];
+    }
+    p.dv[((size_t)g * dk + dd) * T + j0 + m] = sv;
+    p.dk_[((size_t)g * dk + dd) * T + j0 + m] = sk * p.qscale;
+  }
+}
+
+size_t lds_bytes(int TP) { return sizeof(float) * ((size_t)32 * TP + 32 * RELP + 4 * 32 * OP); }
+
+bool ok_shape(int B, int H, int dk, int T, int w) {
+  return B > 0 && H > 0 && dk > 0 && dk <= 64 && (dk % 2) == 0 && T > 0 && T <= 1024 && w >= 0 && 2 * w + 1 <= RELP;
+}
+
+}  // namespace
+
+// 0: this shape runs on the fused kernels (dk <= 64 even, T <= 1024, window <= 7); else the caller keeps the unfused path
+extern "C" int vcv_rel_attn_supported(int B, int H, int dk, int T, int w) { return ok_shape(B, H, dk, T, w) ? 0 : VCV_EINVAL; }
+
+// out [B, H*dk, T] = attention(q, k, v) with relative keys / values `embk`, `embv` [2w+1, dk], mask [B, T].
+// P / Pd [B*H, T, T] (either may be null): softmax probabilities before / after dropout.
+extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                                const float* mask, float* out, float* P, float* Pd, int B, int H, int dk, int T, int w,
+                                float qscale, float pdrop, uint64_t seed, int bf16, void* stream) {
+  if (!q || !k || !v || !embk || !embv || !mask || !out || !ok_shape(B, H, dk, T, w) || pdrop < 0.f || pdrop >= 1.f) return VCV_EINVAL;
+  AttnArgs a = {};
+  a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.out = out, a.P = P, a.Pd = Pd;
+  a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
+  const size_t lds = lds_bytes(a.TP);
+  auto kern = bf16 ? rel_attn_fwd_kernel<true> : rel_attn_fwd_kernel<false>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  const double flops = 4.0 * B * H * (double)T * T * dk;
+  const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 100, 32 * 1000 + 32, 0};
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0);
+  hipExtLaunchKernelGGL(kern, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, (hipStream_t)stream, ev0, ev1, 0, a);
+  return vcv_check_launch();
+}
+
+// Gradients of vcv_rel_attn_fwd.  P: the probabilities the forward saved; dS: [B*H, T, T] workspace; dembk / dembv
+// [2w+1, dk] are overwritten.
+extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                                const float* mask, const float* P, const float* dO, float* dS, float* dq, float* dk_out,
+                                float* dv, float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale,
+                                float pdrop, uint64_t seed, int bf16, void* stream) {
+  if (!q || !k || !v || !embk || !embv || !mask || !P || !dO || !dS || !dq || !dk_out || !dv || !dembk || !dembv ||
+      !ok_shape(B, H, dk, T, w) || pdrop < 0.f || pdrop >= 1.f)
+    return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  AttnArgs a = {};
+  a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.Pin = P, a.dO = dO;
+  a.dS = dS, a.dq = dq, a.dk_ = dk_out, a.dv = dv, a.dembk = dembk, a.dembv = dembv;
+  a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
+  const size_t ne = sizeof(float) * (2 * w + 1) * dk;
+  if (hipMemsetAsync(dembk, 0, ne, st) != hipSuccess || hipMemsetAsync(dembv, 0, ne, st) != hipSuccess) return VCV_EHIP;
+  const size_t lds = lds_bytes(a.TP);
+  auto rows = bf16 ? rel_attn_bwd_rows_kernel<true> : rel_attn_bwd_rows_kernel<false>;
+  auto cols = bf16 ? rel_attn_bwd_cols_kernel<true> : rel_attn_bwd_cols_kernel<false>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  const double flops = 4.0 * B * H * (double)T * T * dk;
+  const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 101, 32 * 1000 + 32, 0};
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0);
+  hipExtLaunchKernelGGL(rows, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, st, ev0, ev1, 0, a);
+  const int tag2[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 102, 32 * 1000 + 32, 0};
+  vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0);
+  hipExtLaunchKernelGGL(cols, dim3((T + 31) / 32, B * H), dim3(256), 0, st, ev0, ev1, 0, a);
+  return vcv_check_launch();
+}

@@ -422,7 +422,8 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // the stride-3 layers (three times the span per position: 105 -> 87 TFLOP/s with four producers) and the
   // 128x320 / 128x128 twins measured slower and keep every wave staging
   static const bool no_ws = getenv("VCVITS_PK_NO_WS") != nullptr;
-  if (ok && !no_ws && a.Mg >= 128 && EL::ESZ == 4 && nph == 1 && a.s == 1) {
+  static const bool ws_bf16 = getenv("VCVITS_PK_WS_BF16") != nullptr;  // (experiment switch)
+  if (ok && !no_ws && a.Mg >= 128 && (EL::ESZ == 4 || ws_bf16) && nph == 1 && a.s == 1) {
     Plan p2;
     if (pl.variant == 0 && make_plan<EL>(a, 128, 256, 8, p2, 4)) pl = p2, pl.variant = 12;
     else if (pl.variant == 2 && make_plan<EL>(a, 128, 224, 4, p2, 4)) pl = p2, pl.variant = 13;

@@ -8,7 +8,8 @@
 #define VCV_PROF_WGRAD 1      /* conv_wgrad_kernel */
 #define VCV_PROF_CONV_DMA 2   /* conv_dma_kernel */
 #define VCV_PROF_WGRAD_DMA 3  /* wgrad_dma_kernel */
-#define VCV_PROF_NCLS 4
+#define VCV_PROF_ATTN 4       /* fused attention kernels (attention.hip) */
+#define VCV_PROF_NCLS 5
 
 // returns a slot (>= 0) when profiling is on and an event pair was recorded before the launch
 int vcv_prof_start(int cls, double flops, hipStream_t st, const int* tag = nullptr, int ntag = 0);

@@ -12,7 +12,7 @@ bool g_on = false;
 std::vector<hipEvent_t> g_start, g_stop;
 std::vector<int> g_cls;
 std::vector<double> g_flops, g_bytes;
-double g_last_bytes[VCV_PROF_NCLS] = {0, 0, 0, 0};
+double g_last_bytes[VCV_PROF_NCLS] = {};
 std::vector<int> g_tags;  // 12 ints per slot
 constexpr int NTAG = 12;
 size_t g_used = 0, g_last_used = 0;

@@ -53,14 +53,19 @@ __device__ __forceinline__ bf16x8 tr_pair(const lds_char* p0, const lds_char* p1
 // tiles per tap and KT tap accumulators.
 // NT = 1: operands rounded to bf16.  NT = 6 / 9: exact fp32 operands as three bf16 terms each (conv_x3.hip's arithmetic):
 // three image planes per operand, NT MFMAs per fragment pair.
-template <int WM, int WC, int WU, int KT, int MAXT, int NT>
-__global__ void __launch_bounds__(64 * WM * WC * WU)
+// NP = 0: every wave stages and multiplies.  NP > 0 (the split-operand launches): warp-specialised -- the NP waves after
+// the MFMA waves do all the staging (loads of stage s + 2 in flight while stage s + 1 is converted and stage s is
+// multiplied), as in wgrad_dma.hip / conv_x3.hip.
+template <int WM, int WC, int WU, int KT, int MAXT, int NT, int NP = 0>
+__global__ void __launch_bounds__(64 * (WM * WC * WU + NP))
 wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ slab) {
   constexpr int BM = 32 * WM, BC = 32 * WC, NW = WM * WC * WU;
+  constexpr int NS = NP ? NP : NW;  // staging waves
   constexpr int PL = NT == 1 ? 1 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sw = NP ? wave - NW : wave;  // index among the staging waves (negative: an MFMA wave of a specialised launch)
   const int wu = wave / (WM * WC), wmc = wave % (WM * WC);
   const int wm = wmc / WC, wc = wmc % WC;
   const int h = lane >> 5;
@@ -102,7 +107,7 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
     const int f0 = ((qa * p.s + p.off + tap_lo) * P) & ~3;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      const int task = wave + t * NW;
+      const int task = sw + t * NS;
       if (task < ntask) {
         const bool isA = task < ntA;
         const int tt = isA ? task : task - ntA;
@@ -135,7 +140,7 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
   };
   // bias gradient (p.dbias): row sums of `a`, taken from the fp32 staging registers of the A tasks by the blocks of the
   // first (channel tile, tap group); an A task = one 32-channel quad, always staged by the same wave (t == 0)
-  const bool do_bias = p.dbias != nullptr && blockIdx.x == 0 && wave < ntA;
+  const bool do_bias = p.dbias != nullptr && blockIdx.x == 0 && sw >= 0 && sw < ntA;
   float bsum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
@@ -148,7 +153,7 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
     }
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      const int task = wave + t * NW;
+      const int task = sw + t * NS;
       if (task < ntask) {
         const bool isA = task < ntA;
         const int tt = isA ? task : task - ntA;
@@ -185,7 +190,8 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
   // tab[u] = x row (relative to the staged span) that tap offset tap_lo of position u reads
   auto build_tab = [&](int ch, int buf) {
     int* tab = (int*)(smem + buf * tg.buf_bytes + tg.a_bytes + PL * tg.x_plane);
-    if (tid < BU) {
+    const int tid = (int)threadIdx.x - (NP ? NW * 64 : 0);  // the first staging wave builds it
+    if (tid >= 0 && tid < BU) {
       const int b = ch / tg.nchunk_u;
       const int uc0 = (ch - b * tg.nchunk_u) * BU;
       const int qa = uc0 / P;
@@ -206,14 +212,37 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
   const int colB = ((wc * 32 + 16 * g1 + 4 * lp) * 2);
   const int rowl = 8 * h + lq;  // the lane's row inside a 16-position step (second read: + 4)
 
-  if (z < total) {
-    load(z);
-    store(0);
-    build_tab(z, 0);
+  if (NP && wave >= NW) {
+    // ---- producer waves: stage ch + 1 is converted and written while stage ch is multiplied; the loads of stage
+    // ch + 2 are issued right after and have that whole stage to arrive
+    if (z < total) {
+      __builtin_amdgcn_s_setprio(3);
+      load(z);
+      store(0);
+      build_tab(z, 0);
+      if (z + tg.Z < total) load(z + tg.Z);
+      int bufi = 0;
+      for (int ch = z; ch < total; ch += tg.Z) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ch + tg.Z < total) {
+          store(bufi ^ 1);
+          build_tab(ch + tg.Z, bufi ^ 1);
+          if (ch + 2 * tg.Z < total) load(ch + 2 * tg.Z);
+        }
+        bufi ^= 1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else if (z < total) {
+    if (!NP) {
+      load(z);
+      store(0);
+      build_tab(z, 0);
+    }
     __syncthreads();
     int bufi = 0;
     for (int ch = z; ch < total; ch += tg.Z) {
-      const bool more = ch + tg.Z < total;
+      const bool more = !NP && ch + tg.Z < total;
       if (more) load(ch + tg.Z);
       const lds_char* Ya = (const lds_char*)smem + bufi * tg.buf_bytes;  // 32-bit LDS addresses from here on
       const lds_char* Xb = Ya + tg.a_bytes;
@@ -265,10 +294,11 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
     for (int e = 0; e < 8; ++e) {
       float v = bsum[e];
       v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-      const int ml = m0 + wave * 32 + lg8 * 8 + e;
+      const int ml = m0 + sw * 32 + lg8 * 8 + e;
       if (lpq == 0 && ml < Mg) unsafeAtomicAdd(p.dbias + ml, v);
     }
   }
+  if (NP && wave >= NW) return;
 
   // cross-wave reduction over the WU position-split waves (through LDS, one round per extra wave)
   if (WU > 1) {

@@ -23,6 +23,9 @@ class MultiHeadAttention(nn.Module):
         self.channels, self.out_channels, self.n_heads = channels, out_channels, n_heads
         self.p_dropout, self.window_size = p_dropout, window_size
         self.attn = None
+        # the reference keeps the attention probabilities of the last call in `self.attn` (:138); set False to skip the
+        # [B, H, T, T] write when nothing reads them (TransformerEncoder does so for its own layers)
+        self.store_attn = True
         self.k_channels = channels // n_heads
         self.conv_q = Conv(channels, channels, 1)
         self.conv_k = Conv(channels, channels, 1)
@@ -56,7 +59,7 @@ class MultiHeadAttention(nn.Module):
         k = self.conv_k(x)
         v = self.conv_v(x)
         out, self.attn = ops.rel_attention(q, k, v, self.emb_rel_k, self.emb_rel_v, mask2, self.n_heads,
-                                           self.window_size, self.p_dropout, self.training)
+                                           self.window_size, self.p_dropout, self.training, want_attn=self.store_attn)
         return self.conv_o(out)
 
 
@@ -95,6 +98,7 @@ class TransformerEncoder(nn.Module):
         for _ in range(n_layers):
             self.attn_layers.append(MultiHeadAttention(hidden_channels, hidden_channels, n_heads,
                                                        p_dropout=p_dropout, window_size=window_size))
+            self.attn_layers[-1].store_attn = False  # nothing reads the encoder layers' `attn` (set True to inspect it)
             self.norm_layers_1.append(LayerNorm(hidden_channels))
             self.ffn_layers.append(FFN(hidden_channels, hidden_channels, filter_channels, kernel_size,
                                        p_dropout=p_dropout))

@@ -74,7 +74,7 @@ _COMPUTE = ["f32"]
 
 
 # which kernel family each GEMM-shaped launch went to (tests assert that the bf16 path really ran)
-LAUNCH_COUNTS = {"bf16": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad_x3": 0, "wgrad": 0}
+LAUNCH_COUNTS = {"bf16": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad_x3": 0, "wgrad": 0, "attn_fused": 0}
 
 
 def set_compute_dtype(name):
@@ -1525,11 +1525,65 @@ class _RelAttnFn(torch.autograd.Function):
         return dq, dkk, dv, dembk, dembv, None, None, None, None, None
 
 
-def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, pdrop=0.0, training=False):
+class _RelAttnFusedFn(torch.autograd.Function):
+    """The whole attention of one layer as ONE launch forward and two backward (attention.hip): both contractions on the
+    matrix cores straight from the [B, C, T] activations, softmax / band terms / mask fill / dropout in between on the
+    LDS tile.  The probabilities are written only for the backward pass or when `attn` is asked for; the dropped
+    probabilities are never stored (the backward pass regenerates the mask from the seed)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, embk, embv, mask, n_heads, window, pdrop, seed, want_attn):
+        q, k, v, embk, embv, mask = (_f32c(t) for t in (q, k, v, embk, embv, mask))
+        B, C, T = q.shape
+        H = n_heads
+        dk = C // H
+        G = B * H
+        qscale = 1.0 / (dk ** 0.5)
+        dev = q.device
+        need_p = any(ctx.needs_input_grad[:5])
+        bf = 1 if _COMPUTE[0] == "bf16" else 0
+        P = torch.empty((G, T, T), device=dev, dtype=torch.float32) if (need_p or (want_attn and pdrop == 0)) else None
+        Pd = torch.empty((G, T, T), device=dev, dtype=torch.float32) if (want_attn and pdrop > 0) else None
+        out = torch.empty_like(q)
+        check(lib().vcv_rel_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(embk), ptr(embv), ptr(mask), ptr(out), ptr(P), ptr(Pd),
+                                     B, H, dk, T, window, qscale, pdrop, seed, bf, stream()), "vcv_rel_attn_fwd")
+        LAUNCH_COUNTS["attn_fused"] += 1
+        ctx.cfg = (H, window, qscale, pdrop, seed, bf)
+        ctx.save_for_backward(q, k, v, embk, embv, mask, P)
+        attn = None
+        if want_attn:
+            attn = (Pd if pdrop > 0 else P).view(B, H, T, T)
+            ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, _dattn):
+        q, k, v, embk, embv, mask, P = ctx.saved_tensors
+        H, window, qscale, pdrop, seed, bf = ctx.cfg
+        dout = _f32c(dout)
+        B, C, T = q.shape
+        dk = C // H
+        dS = torch.empty_like(P)
+        dq, dkk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dembk, dembv = torch.empty_like(embk), torch.empty_like(embv)
+        check(lib().vcv_rel_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(embk), ptr(embv), ptr(mask), ptr(P), ptr(dout), ptr(dS),
+                                     ptr(dq), ptr(dkk), ptr(dv), ptr(dembk), ptr(dembv), B, H, dk, T, window, qscale, pdrop,
+                                     seed, bf, stream()), "vcv_rel_attn_bwd")
+        return dq, dkk, dv, dembk, dembv, None, None, None, None, None, None
+
+
+# the fused attention kernels (attention.hip) take every shape they support; VCVITS_ATTN_FUSED=0 keeps the unfused path
+_ATTN_FUSED = [__import__("os").environ.get("VCVITS_ATTN_FUSED", "1") == "1"]
+
+
+def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, pdrop=0.0, training=False, want_attn=True):
     """Self-attention with shared-head windowed relative embeddings; mask [B,T] (key/query
-    validity).  Returns (out [B,C,T], attn [B,H,T,T])."""
+    validity).  Returns (out [B,C,T], attn [B,H,T,T] -- None when want_attn is False on the fused path)."""
     p = float(pdrop) if training else 0.0
     seed = next_seed() if p > 0 else 0
+    B, C, T = q.shape
+    if _ATTN_FUSED[0] and lib().vcv_rel_attn_supported(B, n_heads, C // n_heads, T, window) == 0:
+        return _RelAttnFusedFn.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, p, seed, bool(want_attn))
     return _RelAttnFn.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, p, seed)
 
 
