@@ -351,7 +351,7 @@ int vcv_rel_softmax_bwd(const float* P, const float* Pd, float* dP, const float*
  * gradients; column pass: dV, dK).  Both contractions on the matrix cores (bf16 != 0: operands rounded to bf16, fp32
  * accumulate).  q / k / v / out / dO / dq / dk / dv: [B, H*dk, T]; embk / embv: [2w+1, dk]; mask: [B, T]; P / Pd / dS:
  * [B*H, T, T] (forward: P and Pd may each be NULL = not wanted; the backward pass regenerates the dropout mask from
- * `seed`).  vcv_rel_attn_supported() == 0 for the shapes these kernels take (dk <= 64 and even, T <= 1024, 2w+1 <= 16).
+ * `seed`).  vcv_rel_attn_supported() == 0 for the shapes these kernels take (dk <= 64 and even, T <= 896, 2w+1 <= 16).
  */
 int vcv_rel_attn_supported(int B, int H, int dk, int T, int w);
 int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,

@@ -94,47 +94,88 @@ __device__ __forceinline__ void rows_times_keys(const float* __restrict__ A, con
   for (int s = 0; s < MAXS; ++s)
     if (s < nks) fa[s] = O::make(s, h, [&](int d) { return (d < dk && i < T) ? A[(size_t)d * T + i] : 0.f; });
   const int nkt = (T + 31) >> 5;
-  for (int jt = wave; jt < nkt; jt += 4) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  typename O::frag fb[MAXS], fn[MAXS];
+  auto loadB = [&](typename O::frag (&f)[MAXS], int jt) __attribute__((always_inline)) {
     const int j = jt * 32 + l31;
 #pragma unroll
     for (int s = 0; s < MAXS; ++s)
-      if (s < nks) {
-        const typename O::frag fb = O::make(s, h, [&](int d) { return (d < dk && j < T) ? Bm[(size_t)d * T + j] : 0.f; });
-        acc = O::mma(fa[s], fb, acc);
-      }
+      if (s < nks) f[s] = O::make(s, h, [&](int d) { return (d < dk && j < T) ? Bm[(size_t)d * T + j] : 0.f; });
+  };
+  if (wave < nkt) loadB(fb, wave);
+  for (int jt = wave; jt < nkt; jt += 4) {
+    if (jt + 4 < nkt) loadB(fn, jt + 4);  // the next tile's loads fly under this tile's MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+      if (s < nks) acc = O::mma(fa[s], fb[s], acc);
 #pragma unroll
     for (int e = 0; e < 16; ++e) T1[acc_row(e, h) * TP + jt * 32 + l31] = acc[e] * alpha;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) fb[s] = fn[s];
   }
 }
 
+constexpr int CK = 128;       // reduction elements of the row-strided operand staged per chunk
+constexpr int CKP = CK + 2;   // LDS pitch = 2 mod 64: the 64 lanes of a fragment read hit 64 banks
+
+// A chunk of the row-strided operand, Bs[d][0 .. CK) = Bm[d][c0 .. c0 + CK) (zero past T / past the dk rows), in two
+// halves so that the loads of chunk c + 1 fly under the MFMAs of chunk c: coalesced global reads along the row into
+// registers (NR = rows / 2 loads per thread, all in flight at once), then the LDS writes.
+template <int NR>
+__device__ __forceinline__ void load_rows(const float* __restrict__ Bm, float (&v)[NR], int c0, int T, int dk, int tid) {
+  const int jj = tid & (CK - 1), dbase = tid >> 7;  // 256 threads = 2 rows x 128 columns per pass
+  const int j = c0 + jj;
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int d = 2 * u + dbase;
+    v[u] = (d < dk && j < T) ? Bm[(size_t)d * T + j] : 0.f;
+  }
+}
+template <int NR>
+__device__ __forceinline__ void store_rows(float* Bs, const float (&v)[NR], int dk, int tid) {
+  const int jj = tid & (CK - 1), dbase = tid >> 7;
+  const int rows = (dk + 31) & ~31;
+#pragma unroll
+  for (int u = 0; u < NR; ++u)
+    if (2 * u + dbase < rows) Bs[(2 * u + dbase) * CKP + jj] = v[u];
+}
+
 // out[d][i0 + m] = alpha * (sum_j T1[m][j] * Bm[d][j] + sum_r T1[m][i0 + m + r - w] * emb[r][d])  (phase 3 of the forward:
-// P V^T + relative values; of the backward row pass: dS K^T + relative keys).  The dk / 32 column tiles and the key range
-// are dealt to the 4 waves; partial tiles meet in `red`.
+// P V^T + relative values; of the backward row pass: dS K^T + relative keys).  Bm is row-strided for the MFMA's lanes
+// (lane = channel d), so it goes through LDS in chunks of CK keys (`bs`: 64 * CKP floats; `red` may alias it).  The
+// dk / 32 column tiles and the steps of a chunk are dealt to the 4 waves; partial tiles meet in `red`.
 template <bool BF>
 __device__ __forceinline__ void tile_times_rows(const float* T1, const float* __restrict__ Bm, const float* __restrict__ emb,
-                                                float* __restrict__ out, float* red, int i0, int T, int dk, int TP, int w,
+                                                float* __restrict__ out, float* bs, float* red, int i0, int T, int dk, int TP, int w,
                                                 float alpha, int wave, int lane, int tid) {
   typedef Op<BF> O;
   const int l31 = lane & 31, h = lane >> 5;
   const int nt = (dk + 31) >> 5;         // column tiles (1 or 2)
   const int wpt = nt == 1 ? 4 : 2;       // waves per column tile
   const int tile = nt == 1 ? 0 : (wave & 1), kp = nt == 1 ? wave : (wave >> 1);
-  const int nsteps = (T + O::KS - 1) / O::KS;
-  const int s0 = kp * nsteps / wpt, s1 = (kp + 1) * nsteps / wpt;
   const int d = tile * 32 + l31;
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const float* Trow = T1 + l31 * TP;
-  const float* Brow = Bm + (size_t)(d < dk ? d : 0) * T;
-  for (int s = s0; s < s1; ++s) {
-    const typename O::frag fa = O::make(s, h, [&](int j) { return Trow[j]; });  // (columns >= T of the tile are zero)
-    const typename O::frag fb = O::make(s, h, [&](int j) { return (d < dk && j < T) ? Brow[j] : 0.f; });
-    acc = O::mma(fa, fb, acc);
+  const float* Brow = bs + d * CKP;
+  float stg[32];
+  load_rows(Bm, stg, 0, T, dk, tid);
+  for (int c0 = 0; c0 < T; c0 += CK) {
+    __syncthreads();  // the previous chunk's fragment reads are done
+    store_rows(bs, stg, dk, tid);
+    __syncthreads();
+    if (c0 + CK < T) load_rows(Bm, stg, c0 + CK, T, dk, tid);  // in flight under this chunk's MFMAs
+    const int nst = ((T - c0 < CK ? T - c0 : CK) + O::KS - 1) / O::KS;
+    for (int s = kp; s < nst; s += wpt) {
+      const typename O::frag fa = O::make(s, h, [&](int j) { return Trow[c0 + j]; });  // (columns >= T of the tile are zero)
+      const typename O::frag fb = O::make(s, h, [&](int j) { return Brow[j]; });
+      acc = O::mma(fa, fb, acc);
+    }
   }
+  __syncthreads();
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[(wave * 32 + acc_row(e, h)) * OP + l31] = acc[e];
   __syncthreads();
@@ -154,14 +195,27 @@ __device__ __forceinline__ void tile_times_rows(const float* T1, const float* __
   }
 }
 
-// rel[m][r] = alpha * sum_d A[d][i0 + m] * emb[r][d]
-__device__ __forceinline__ void band_dots(const float* __restrict__ A, const float* __restrict__ emb, float* rel, int i0, int T, int dk,
-                                          int nr, float alpha, int tid) {
-  for (int idx = tid; idx < 32 * nr; idx += 256) {
-    const int m = idx & 31, r = idx >> 5;
+constexpr int QP = 33;  // pitch of the staged 32-position operand tile
+
+// rel[m][r] = alpha * sum_d A[d][i0 + m] * emb[r][d], through LDS: `at` [dk][QP] takes the 32-position tile of A (coalesced
+// loads, all in flight at once), `es` [nr][dk] the table; then one thread per (m, r)
+__device__ __forceinline__ void band_dots(const float* __restrict__ A, const float* __restrict__ emb, float* rel, float* at, float* es,
+                                          int i0, int T, int dk, int nr, float alpha, int tid) {
+  const int m = tid & 31, dq = tid >> 5;  // 8 channel rows per pass
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int d = dq + 8 * u;
+    v[u] = (d < dk && i0 + m < T) ? A[(size_t)d * T + i0 + m] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (dq + 8 * u < dk) at[(dq + 8 * u) * QP + m] = v[u];
+  for (int idx = tid; idx < nr * dk; idx += 256) es[idx] = emb[idx];
+  __syncthreads();
+  for (int r = dq; r < nr; r += 8) {
     float s = 0.f;
-    if (i0 + m < T)
-      for (int d = 0; d < dk; ++d) s += A[(size_t)d * T + i0 + m] * emb[r * dk + d];
+    for (int d = 0; d < dk; ++d) s += at[d * QP + m] * es[r * dk + d];
     rel[m * RELP + r] = s * alpha;
   }
 }
@@ -172,15 +226,20 @@ __global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
   const int T = p.T, dk = p.dk, TP = p.TP, nr = 2 * p.w + 1;
   float* S = sm;
   float* rel = S + 32 * TP;
-  float* red = rel + 32 * RELP;
+  float* msk = rel + 32 * RELP;   // the batch element's mask row
+  float* etab = msk + TP;         // the table of the second contraction's band term
+  float* bs = etab + RELP * 64;   // staged chunk of the row-strided operand; before that the tile / table of the band
+                                  // logits, after it the partial-output tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.y, b = g / p.H, i0 = blockIdx.x * 32;
   const float* qg = p.q + (size_t)g * dk * T;
   const float* kg = p.k + (size_t)g * dk * T;
   const float* vg = p.v + (size_t)g * dk * T;
-  const float* mrow = p.mask + (size_t)b * T;
+  const float* mrow = msk;
+  for (int j = tid; j < T; j += 256) msk[j] = p.mask[(size_t)b * T + j];
+  for (int idx = tid; idx < nr * dk; idx += 256) etab[idx] = p.embv[idx];
 
-  band_dots(qg, p.embk, rel, i0, T, dk, nr, p.qscale, tid);
+  band_dots(qg, p.embk, rel, bs, bs + 64 * QP, i0, T, dk, nr, p.qscale, tid);
   rows_times_keys<BF>(qg, kg, S, i0, T, dk, TP, p.qscale, wave, lane);
   __syncthreads();
   // softmax of the wave's 8 rows
@@ -205,7 +264,7 @@ __global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
     mx = wmax_all(mx);
     float sum = 0.f;
     for (int j = lane; j < T; j += 64) {
-      const float e = expf(Sr[j] - mx);
+      const float e = __expf(Sr[j] - mx);
       Sr[j] = e;
       sum += e;
     }
@@ -224,7 +283,7 @@ __global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
     }
   }
   __syncthreads();
-  tile_times_rows<BF>(S, vg, p.embv, p.out + (size_t)g * dk * T, red, i0, T, dk, TP, p.w, 1.f, wave, lane, tid);
+  tile_times_rows<BF>(S, vg, etab, p.out + (size_t)g * dk * T, bs, bs, i0, T, dk, TP, p.w, 1.f, wave, lane, tid);
 }
 
 // Backward, row pass: per (head, 32 query rows): dPd = dO^T V + band, dS = Pd * dPd - P * sum_j(Pd * dPd) (zero where
@@ -235,17 +294,21 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p
   const int T = p.T, dk = p.dk, TP = p.TP, nr = 2 * p.w + 1;
   float* D = sm;
   float* rel = D + 32 * TP;
-  float* red = rel + 32 * RELP;
+  float* msk = rel + 32 * RELP;
+  float* etab = msk + TP;
+  float* bs = etab + RELP * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.y, b = g / p.H, i0 = blockIdx.x * 32;
   const float* qg = p.q + (size_t)g * dk * T;
   const float* kg = p.k + (size_t)g * dk * T;
   const float* vg = p.v + (size_t)g * dk * T;
   const float* og = p.dO + (size_t)g * dk * T;
-  const float* mrow = p.mask + (size_t)b * T;
+  const float* mrow = msk;
   const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
+  for (int j = tid; j < T; j += 256) msk[j] = p.mask[(size_t)b * T + j];
+  for (int idx = tid; idx < nr * dk; idx += 256) etab[idx] = p.embk[idx];
 
-  band_dots(og, p.embv, rel, i0, T, dk, nr, 1.f, tid);
+  band_dots(og, p.embv, rel, bs, bs + 64 * QP, i0, T, dk, nr, 1.f, tid);
   rows_times_keys<BF>(og, vg, D, i0, T, dk, TP, 1.f, wave, lane);
   __syncthreads();
   for (int rr = 0; rr < 8; ++rr) {
@@ -297,14 +360,18 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p
     unsafeAtomicAdd(p.dembk + idx, ek * p.qscale);
     unsafeAtomicAdd(p.dembv + idx, ev);
   }
-  tile_times_rows<BF>(D, kg, p.embk, p.dq + (size_t)g * dk * T, red, i0, T, dk, TP, p.w, p.qscale, wave, lane, tid);
+  tile_times_rows<BF>(D, kg, etab, p.dq + (size_t)g * dk * T, bs, bs, i0, T, dk, TP, p.w, p.qscale, wave, lane, tid);
 }
 
 // Backward, column pass: per (head, 32 keys): dV[d][j] = sum_i Pd[i][j] dO[d][i], dK[d][j] = qscale * sum_i dS[i][j] q[d][i].
 template <bool BF>
 __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p) {
   typedef Op<BF> O;
-  __shared__ float red[2][4 * 32 * OP];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* os = sm;               // dO chunk [64][CKP]
+  float* qs = sm + 64 * CKP;    // q chunk
+  float* red0 = sm;             // the partial tiles reuse the chunk buffers (4 * 32 * OP floats each)
+  float* red1 = sm + 64 * CKP;
   const int T = p.T, dk = p.dk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int g = blockIdx.y, j0 = blockIdx.x * 32;
@@ -314,31 +381,45 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p
   const int nt = (dk + 31) >> 5;
   const int wpt = nt == 1 ? 4 : 2;
   const int tile = nt == 1 ? 0 : (wave & 1), kp = nt == 1 ? wave : (wave >> 1);
-  const int nsteps = (T + O::KS - 1) / O::KS;
-  const int s0 = kp * nsteps / wpt, s1 = (kp + 1) * nsteps / wpt;
   const int d = tile * 32 + l31, j = j0 + l31;
-  const float* orow = og + (size_t)(d < dk ? d : 0) * T;
-  const float* qrow = qg + (size_t)(d < dk ? d : 0) * T;
+  const float* orow = os + d * CKP;
+  const float* qrow = qs + d * CKP;
   f32x16 av, ak;
 #pragma unroll
   for (int e = 0; e < 16; ++e) av[e] = ak[e] = 0.f;
-  for (int s = s0; s < s1; ++s) {
-    const typename O::frag fp = O::make(s, h, [&](int i) {
-      if (i >= T || j >= T) return 0.f;
-      const size_t off = ((size_t)g * T + i) * T + j;
-      const float pv = p.Pin[off];
-      return p.pdrop > 0.f ? pv * drop_scale(p.seed, off, p.pdrop, inv_keep) : pv;
-    });
-    const typename O::frag fs = O::make(s, h, [&](int i) { return (i < T && j < T) ? p.dS[((size_t)g * T + i) * T + j] : 0.f; });
-    const typename O::frag fo = O::make(s, h, [&](int i) { return (d < dk && i < T) ? orow[i] : 0.f; });
-    const typename O::frag fq = O::make(s, h, [&](int i) { return (d < dk && i < T) ? qrow[i] : 0.f; });
-    av = O::mma(fp, fo, av);
-    ak = O::mma(fs, fq, ak);
+  float so[32], sq[32];
+  load_rows(og, so, 0, T, dk, tid);
+  load_rows(qg, sq, 0, T, dk, tid);
+  for (int c0 = 0; c0 < T; c0 += CK) {
+    __syncthreads();
+    store_rows(os, so, dk, tid);
+    store_rows(qs, sq, dk, tid);
+    __syncthreads();
+    if (c0 + CK < T) {
+      load_rows(og, so, c0 + CK, T, dk, tid);
+      load_rows(qg, sq, c0 + CK, T, dk, tid);
+    }
+    const int nst = ((T - c0 < CK ? T - c0 : CK) + O::KS - 1) / O::KS;
+    for (int s = kp; s < nst; s += wpt) {
+      const typename O::frag fp = O::make(s, h, [&](int ii) {
+        const int i = c0 + ii;
+        if (i >= T || j >= T) return 0.f;
+        const size_t off = ((size_t)g * T + i) * T + j;
+        const float pv = p.Pin[off];
+        return p.pdrop > 0.f ? pv * drop_scale(p.seed, off, p.pdrop, inv_keep) : pv;
+      });
+      const typename O::frag fs = O::make(s, h, [&](int ii) { const int i = c0 + ii; return (i < T && j < T) ? p.dS[((size_t)g * T + i) * T + j] : 0.f; });
+      const typename O::frag fo = O::make(s, h, [&](int ii) { return orow[ii]; });
+      const typename O::frag fq = O::make(s, h, [&](int ii) { return qrow[ii]; });
+      av = O::mma(fp, fo, av);
+      ak = O::mma(fs, fq, ak);
+    }
   }
+  __syncthreads();
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    red[0][(wave * 32 + acc_row(e, h)) * OP + l31] = av[e];
-    red[1][(wave * 32 + acc_row(e, h)) * OP + l31] = ak[e];
+    red0[(wave * 32 + acc_row(e, h)) * OP + l31] = av[e];
+    red1[(wave * 32 + acc_row(e, h)) * OP + l31] = ak[e];
   }
   __syncthreads();
   for (int idx = tid; idx < 32 * dk; idx += 256) {
@@ -348,23 +429,25 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p
     float sv = 0.f, sk = 0.f;
     for (int k2 = 0; k2 < wpt; ++k2) {
       const int wv = nt == 1 ? k2 : k2 * 2 + tl;
-      sv += red[0][(wv * 32 + m) * OP + n];
-      sk += red[1][(wv * 32 + m) * OP + n];
+      sv += red0[(wv * 32 + m) * OP + n];
+      sk += red1[(wv * 32 + m) * OP + n];
     }
     p.dv[((size_t)g * dk + dd) * T + j0 + m] = sv;
     p.dk_[((size_t)g * dk + dd) * T + j0 + m] = sk * p.qscale;
   }
 }
 
-size_t lds_bytes(int TP) { return sizeof(float) * ((size_t)32 * TP + 32 * RELP + 4 * 32 * OP); }
+// (64 * CKP floats hold the band-logit staging (64 * QP + RELP * 64) and the partial-output tiles (4 * 32 * OP) too)
+size_t lds_bytes(int TP) { return sizeof(float) * ((size_t)32 * TP + 32 * RELP + TP + RELP * 64 + 64 * CKP); }
 
 bool ok_shape(int B, int H, int dk, int T, int w) {
-  return B > 0 && H > 0 && dk > 0 && dk <= 64 && (dk % 2) == 0 && T > 0 && T <= 1024 && w >= 0 && 2 * w + 1 <= RELP;
+  return B > 0 && H > 0 && dk > 0 && dk <= 64 && (dk % 2) == 0 && T > 0 && w >= 0 && 2 * w + 1 <= RELP &&
+         lds_bytes(((T + 63) & ~63) + 2) <= VCV_LDS_LIMIT;  // the 32-row probability tile must fit: T <= 896
 }
 
 }  // namespace
 
-// 0: this shape runs on the fused kernels (dk <= 64 even, T <= 1024, window <= 7); else the caller keeps the unfused path
+// 0: this shape runs on the fused kernels (dk <= 64 even, T <= 896, window <= 7); else the caller keeps the unfused path
 extern "C" int vcv_rel_attn_supported(int B, int H, int dk, int T, int w) { return ok_shape(B, H, dk, T, w) ? 0 : VCV_EINVAL; }
 
 // out [B, H*dk, T] = attention(q, k, v) with relative keys / values `embk`, `embv` [2w+1, dk], mask [B, T].
@@ -416,6 +499,9 @@ extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, 
   hipExtLaunchKernelGGL(rows, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, st, ev0, ev1, 0, a);
   const int tag2[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 102, 32 * 1000 + 32, 0};
   vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0);
-  hipExtLaunchKernelGGL(cols, dim3((T + 31) / 32, B * H), dim3(256), 0, st, ev0, ev1, 0, a);
+  const size_t lds2 = sizeof(float) * 2 * 64 * CKP;
+  if (lds2 > 64 * 1024 && hipFuncSetAttribute((const void*)cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+    return VCV_EHIP;
+  hipExtLaunchKernelGGL(cols, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds2, st, ev0, ev1, 0, a);
   return vcv_check_launch();
 }
