@@ -478,6 +478,7 @@ extern "C" int vcv_conv_x3_set_all(int all) {
   g_all = all ? 1 : 0;
   return VCV_OK;
 }
+extern "C" int vcv_conv_x3_get_all(void) { return g_all; }
 
 // Same calling convention as vcv_conv_pk_plan / vcv_conv_pk_run: out[0] = size of the packed-weight buffer in 4-byte
 // words, out[1] = floats of per-launch scratch, out[2] = signature of the pack layout.

@@ -19,6 +19,9 @@
 #include "common.h"
 #include "prof.h"
 
+extern "C" int vcv_conv_x3_get_terms(void);
+extern "C" int vcv_conv_x3_get_all(void);
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -26,7 +29,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
-constexpr int BU = 64;
+constexpr int BU64 = 64;  // positions per stage (the split-operand launches, whose images hold three planes, take 32)
 
 struct WbGeom {
   int nmt, nct, ntg;   // m tiles, c tiles, tap groups
@@ -56,7 +59,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const lds_char* p0, const lds_char* p1
 // NP = 0: every wave stages and multiplies.  NP > 0 (the split-operand launches): warp-specialised -- the NP waves after
 // the MFMA waves do all the staging (loads of stage s + 2 in flight while stage s + 1 is converted and stage s is
 // multiplied), as in wgrad_dma.hip / conv_x3.hip.
-template <int WM, int WC, int WU, int KT, int MAXT, int NT, int NP = 0>
+template <int WM, int WC, int WU, int KT, int MAXT, int NT, int NP = 0, int BU = BU64>
 __global__ void __launch_bounds__(64 * (WM * WC * WU + NP))
 wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ slab) {
   constexpr int BM = 32 * WM, BC = 32 * WC, NW = WM * WC * WU;
@@ -93,7 +96,7 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
   // staging tasks: (32-channel quad, 64-position block); A tasks first, then X tasks.  Lane: 8-channel group lane & 3,
   // positions 4 * (lane >> 2) .. + 3 -> 8 x 16-byte loads (256-byte runs per 16 lanes), 4 x 16-byte LDS writes
   const int nqa = BM / 32, nqb = BC / 32;
-  const int ntA = nqa * (BU / 64), ntB = nqb * (tg.XR / 64);
+  const int ntA = nqa, ntB = nqb * (tg.XR / 64);  // (an A task covers 64 positions; with BU = 32 its upper half idles)
   const int ntask = ntA + ntB;
   const int lpq = lane >> 2, lg8 = lane & 3;
   f32x4 xr[MAXT][8];
@@ -125,8 +128,9 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
         const unsigned rec = rows > 0 ? (unsigned)((long long)rows * rowlen * 4) : 0u;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)chan0 * (size_t)rowlen), 0, (int)rec, 0x00020000);
         bool ok[4];
+        const bool in_stage = !isA || lpq * 4 < BU;  // (BU = 32: positions 32 .. 63 of an A task belong to the next stage)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ok[j] = pos0 + j >= 0 && pos0 + j < rowlen;
+        for (int j = 0; j < 4; ++j) ok[j] = in_stage && pos0 + j >= 0 && pos0 + j < rowlen;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const unsigned voff = (unsigned)(((long long)(lg8 * 8 + e) * rowlen + pos0) * 4);
@@ -163,6 +167,7 @@ wgrad_bf16_kernel(const VcvWgradArgs p, const WbGeom tg, float* __restrict__ sla
         char* img = isA ? Ya : Xb;
         const int pitch = isA ? PA : PB;
         const int plane = isA ? tg.a_plane : tg.x_plane;  // bytes between the term planes of an image
+        if (isA && lpq * 4 >= BU) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           bf16x8 v, v1, v2;
@@ -389,10 +394,13 @@ __global__ void __launch_bounds__(256) wgrad_bf16_finish_kernel(const float* __r
 }
 
 constexpr int MAXT = 2;
+constexpr int MAXT_WS = 3;  // staging tasks per producer wave of a split-operand launch
 
 struct Cfg { int WM, WC, WU, KT; };
 
 bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
+  const int BU = PL == 1 ? BU64 : 32;
+  const int NS = PL == 1 ? c.WM * c.WC * c.WU : 4, maxt = PL == 1 ? MAXT : MAXT_WS;  // staging waves, tasks each
   const int BM = 32 * c.WM, BC = 32 * c.WC, NW = c.WM * c.WC * c.WU;
   g.nmt = vcv_cdiv(a.Mg, BM);
   g.nct = vcv_cdiv(a.Cg, BC);
@@ -413,8 +421,9 @@ bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds, int P
   const size_t red = c.WU > 1 ? (size_t)c.WM * c.WC * c.KT * 16 * 64 * 4 : 0;
   if (red > lds) lds = red;
   if (lds > VCV_LDS_LIMIT) return false;
-  const int ntask = (BM / 32) * (BU / 64) + (BC / 32) * (g.XR / 64);
-  if (ntask > MAXT * NW) return false;
+  const int ntask = (BM / 32) + (BC / 32) * (g.XR / 64);
+  if (ntask > maxt * NS) return false;
+  if (BU / 16 < c.WU) return false;  // every position-split wave needs a 16-position step
   const long long Uu = (long long)a.Ta * a.P;
   g.nchunk_u = (int)((Uu + BU - 1) / BU);
   return true;
@@ -437,10 +446,12 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
     if (cost < best - 1e-9) best = cost, Z = z;
   }
   g.Z = (int)Z;
-  auto kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT, NT>;
+  void (*kern)(const VcvWgradArgs, const WbGeom, float*);
+  if constexpr (NT == 1) kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT, NT>;
+  else kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT_WS, NT, 4, 32>;  // 4 producer waves, 32-position stages
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VCV_EHIP;
-  dim3 grid(g.nct * g.ntg, g.nmt, g.Z), block(64 * WM * WC * WU);
+  dim3 grid(g.nct * g.ntg, g.nmt, g.Z), block(64 * (WM * WC * WU + (NT == 1 ? 0 : 4)));
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
   const int tag[12] = {a.B, NT == 1 ? 2 : 3, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, WM * 32 * 1000 + WC * 32, NT * 100 + KT};
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
@@ -474,7 +485,14 @@ bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
     if (bm > 32 && bm > a.Mg) continue;
     if (bc > 32 && bc > ((a.Cg + 31) & ~31)) continue;
     c.WM = cand[i][0]; c.WC = cand[i][1]; c.WU = cand[i][2];
-    if (geometry(a, c, g, lds, PL)) return true;
+    if (geometry(a, c, g, lds, PL)) {
+      // split-operand launches: three planes per image leave the wide-period layers (long x spans) only 32-channel
+      // tiles, and K = 7 / 8 run as two tap groups: measured in the step (tools/prof_compare.py) the kernel is ahead of
+      // the fp32 one (wgrad_dma.hip) with 64-channel tiles and K = 5 or K >= 9 -- 161-168 vs 105-108 TFLOP/s on the
+      // 1024-channel period layers, 118-133 vs 77-97 on the generator's k = 11 layers -- and behind or level elsewhere
+      if (PL == 3 && !vcv_conv_x3_get_all() && !(c.WC == 2 && (a.K == 5 || a.K >= 9))) return false;
+      return true;
+    }
   }
   return false;
 }
@@ -530,7 +548,6 @@ extern "C" int vcv_wgrad_bf16(const VcvWgradArgs* a, float* scratch, int64_t scr
 
 // The same kernel on exact fp32 operands split into three bf16 terms each (the arithmetic of conv_x3.hip; the number of
 // product terms is the one set with vcv_conv_x3_set_terms): fp32 weight gradients at the bf16 MFMA rate.
-extern "C" int vcv_conv_x3_get_terms(void);
 extern "C" int64_t vcv_wgrad_x3_scratch(const VcvWgradArgs* a) { return scratch_want(a, 3); }
 extern "C" int vcv_wgrad_x3(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* stream) {
   return vcv_conv_x3_get_terms() == 6 ? run<6>(a, scratch, scratch_floats, stream) : run<9>(a, scratch, scratch_floats, stream);

@@ -47,10 +47,9 @@ _USE_PK = [__import__("os").environ.get("VCVITS_CONV_PK", "1") == "1"]
 _USE_X3 = [__import__("os").environ.get("VCVITS_CONV_X3", "1") == "1"]
 
 
-# the weight gradient in the same arithmetic (vcv_wgrad_x3: wgrad_bf16.hip with three term planes).  Off by default: that
-# kernel stages in its MFMA waves and is staging-bound with three planes (63-66 TFLOP/s in the step against 88 for the
-# warp-specialised fp32 kernel, wgrad_dma.hip); it is kept for its determinism and for the day it gets producer waves.
-_USE_X3_WGRAD = [__import__("os").environ.get("VCVITS_WGRAD_X3", "0") == "1"]
+# the weight gradient in the same arithmetic (vcv_wgrad_x3: wgrad_bf16.hip with three term planes and producer waves);
+# the library takes the shapes where it beats the fp32 kernel (wgrad_dma.hip) and declines the rest
+_USE_X3_WGRAD = [__import__("os").environ.get("VCVITS_WGRAD_X3", "1") == "1"]
 
 
 def set_f32_split(on, terms=None, all_shapes=None, wgrad=None):
