@@ -405,6 +405,11 @@ int vcv_istft(const float* spec, const float* window, const float* twiddle, floa
 
 /* returns a static string describing the build (arch, kernel variants) */
 const char* vcv_version(void);
+/* Deterministic mode (also VCVITS_DETERMINISTIC=1): every launcher that splits a reduction over workgroups and combines
+ * with fp32 atomics runs it unsplit, one writer per output element (slower; bit-reproducible run to run).  The MFMA
+ * weight-gradient kernels combine through VcvWgradArgs.slab instead; the caller passes it (and no dbias). */
+int vcv_set_deterministic(int on);
+int vcv_get_deterministic(void);
 
 #ifdef __cplusplus
 }

@@ -38,3 +38,5 @@ static inline int vcv_check_launch() {
 }
 
 static inline int vcv_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int vcv_get_deterministic(void);  // version.hip

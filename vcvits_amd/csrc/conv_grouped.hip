@@ -441,11 +441,17 @@ grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xq[boff[nt]], acc[nt], 0, 0, 0);
     }
   }
-  __syncthreads();
+  // the four waves' partial tiles meet in LDS one wave after the other: a fixed order (LDS atomics would add them in
+  // whatever order the waves arrive)
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(&racc[kk * 4 + r][nt * 16 + j16], acc[nt][r]);
+        for (int r = 0; r < 4; ++r) racc[kk * 4 + r][nt * 16 + j16] += acc[nt][r];
+    }
+  }
   __syncthreads();
   float* dwg = dw + (size_t)g * MG * NW;
   for (int i = tid; i < MG * NW; i += 256) {
@@ -466,16 +472,20 @@ extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const flo
     int wg_per_group = 512 / G;
     if (wg_per_group < 1) wg_per_group = 1;
     if (wg_per_group > nunit) wg_per_group = nunit;
+    if (vcv_get_deterministic()) wg_per_group = 1;  // one workgroup per group: a single writer per weight
     const int uper = vcv_cdiv(nunit, wg_per_group);
     hipLaunchKernelGGL(grouped_wgrad_mfma_kernel, dim3(G, vcv_cdiv(nunit, uper)), dim3(256), 0, (hipStream_t)stream, dy, yaux,
                        x, dw, G, Tin, Tout, dtf, slope, nstage, uper, nunit);
     return vcv_check_launch();
   }
   while ((long long)G * B * nchunk < 1024 && Tout / (nchunk * 2) >= 128) nchunk *= 2;
+  const bool det = vcv_get_deterministic() != 0;
+  if (det) nchunk = 1;
   const int tchunk = vcv_cdiv(vcv_cdiv(Tout, nchunk), 128) * 128;
   // batch elements per workgroup: as many as keep the grid at >= ~1024 workgroups (fewer atomics per weight)
   int bper = 1;
   while (bper * 2 <= B && (long long)G * vcv_cdiv(Tout, tchunk) * (B / (bper * 2)) >= 1024) bper *= 2;
+  if (det) bper = B;
   dim3 grid(G, vcv_cdiv(Tout, tchunk), vcv_cdiv(B, bper));
   if (Mg == 16) hipLaunchKernelGGL(grouped_wgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk, bper, B);
   else hipLaunchKernelGGL(grouped_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk, bper, B);

@@ -321,6 +321,7 @@ extern "C" int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias
   if (out_act == VCV_ACT_NONE) {
     while (splits < 64 && (long long)nt * B * splits < 1024 && C / (splits * 2) >= 8) splits *= 2;
   }
+  if (vcv_get_deterministic()) splits = 1;  // (the channel-range splits meet in fp32 atomics)
   const int cper = vcv_cdiv(C, splits);
   if (splits > 1) {
     const size_t n = (size_t)B * U;
@@ -341,12 +342,14 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   int splits = 1;
   while (splits < B && (long long)M * C * splits < 4096) splits *= 2;  // short serial batch loops: latency-bound
   if (splits > B) splits = B;
+  const bool det = vcv_get_deterministic() != 0;  // one workgroup per (m, c): a single writer per weight
+  if (det) splits = 1;
   const int bper = vcv_cdiv(B, splits);
   // long rows: also split the positions so that the grid has a few thousand workgroups of >= 1024 positions
   const int U = Ta * P;
   long long usplit = 8192 / ((long long)M * C * vcv_cdiv(B, bper));
   if (usplit > U / 1024) usplit = U / 1024;
-  if (usplit < 1) usplit = 1;
+  if (usplit < 1 || det) usplit = 1;
   const int uper = (vcv_cdiv(U, (int)usplit) + 255) & ~255;
   if (a_tf == VCV_TF_NONE && b_tf == VCV_TF_NONE)
     hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0,

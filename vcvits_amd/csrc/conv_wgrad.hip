@@ -272,6 +272,7 @@ int launch_wgrad_bu(const VcvWgradArgs& a, hipStream_t st, bool allow_sync) {
   long long Z = 1024 / tiles;
   if (Z < 1) Z = 1;
   if (Z > total) Z = total;
+  if (vcv_get_deterministic()) Z = 1;  // (the position splits meet in fp32 atomics)
   tg.Z = (int)Z;
   const size_t lds = ((size_t)tg.a_floats + (size_t)tg.x_floats + BU) * sizeof(float);
   if (lds > VCV_LDS_LIMIT) return VCV_ENOFIT;
@@ -412,7 +413,7 @@ extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, in
   const long long units = (long long)B * ((T + 1023) / 1024);
   long long nseg = (1024 + C - 1) / C;
   if (nseg > units / 8) nseg = units / 8;
-  if (nseg < 1) nseg = 1;
+  if (nseg < 1 || vcv_get_deterministic()) nseg = 1;
   if (nseg > 1 && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
   if (T % 4 == 0)
     hipLaunchKernelGGL(bias_grad_kernel<true>, dim3(C, (unsigned)nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,

@@ -389,7 +389,7 @@ extern "C" int vcv_act_grad_bias(const float* dy, const float* y, float* out, fl
   const long long units = (long long)B * ((T + 1023) / 1024);
   long long nseg = (2048 + C - 1) / C;
   if (nseg > units) nseg = units;
-  if (nseg < 1) nseg = 1;
+  if (nseg < 1 || vcv_get_deterministic()) nseg = 1;
   hipLaunchKernelGGL(act_grad_bias_kernel, dim3(C, (unsigned)nseg), dim3(256), 0, ST, dy, y, out, dbias, B, C, T, tf, slope,
                      (int)nseg);
   return vcv_check_launch();

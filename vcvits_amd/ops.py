@@ -133,7 +133,14 @@ _DETERMINISTIC = [__import__("os").environ.get("VCVITS_DETERMINISTIC", "0") == "
 
 
 def set_deterministic(on):
+    """Bit-reproducible gradients run to run: the MFMA weight-gradient kernels combine their split reductions through
+    slabs added in a fixed order, bias gradients are summed by one workgroup per channel instead of inside the
+    weight-gradient launch, and the library's other split reductions (thin / grouped / register-staged weight gradients,
+    activation-derivative bias sums, the one-output-channel forward) run unsplit (vcv_set_deterministic).  Covers the
+    GAN step of the vocoder workload (tests/test_determinism_gpu.py: two identical steps, gradients bit for bit); the
+    full model's LayerNorm-parameter and relative-position-table gradients still meet in fp32 atomics."""
     _DETERMINISTIC[0] = bool(on)
+    check(lib().vcv_set_deterministic(1 if on else 0), "vcv_set_deterministic")
 
 
 def _launch_wgrad(a):
@@ -314,7 +321,7 @@ def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=
     Cg, K = w_shape[1], w_shape[2]
     if out is None:
         out = _wgrad_zeros(w_shape, dy.device, arena)
-    if dbias is not None and (a_tf != TF_NONE or groups != 1 or min(M, C) == 1):
+    if dbias is not None and (_DETERMINISTIC[0] or a_tf != TF_NONE or groups != 1 or min(M, C) == 1):
         bias_grad(dy, aux=aaux, tf=a_tf, slope=slope, out=dbias)
         dbias = None
     if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
