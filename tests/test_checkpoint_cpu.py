@@ -188,7 +188,7 @@ def test_exponential_lr_matches_torch():
         ref = torch.optim.lr_scheduler.ExponentialLR(ref_opt, gamma=0.9)
         ref.last_epoch = start_epoch - 1
         opt = FlatAdamW([torch.nn.Parameter(torch.zeros(2))], 2e-4)
-        sch = ExponentialLR(opt, gamma=0.9)
+        sch = ExponentialLR(opt, gamma=0.9, reference_stack=False)  # the installed torch's semantics
         sch.last_epoch = start_epoch - 1
         for _ in range(5):
             assert opt.param_groups[0]["lr"] == pytest.approx(ref_opt.param_groups[0]["lr"], rel=1e-12)
@@ -197,3 +197,38 @@ def test_exponential_lr_matches_torch():
             sch.step()
             assert sch.last_epoch == ref.last_epoch
             assert sch.get_last_lr() == pytest.approx(ref.get_last_lr(), rel=1e-12)
+
+
+def test_exponential_lr_follows_the_reference_stack():
+    """Default mode = the reference's pinned torch 2.0.x scheduler: `get_lr` keeps the rate when `last_epoch == 0`, so on
+    a fresh run (re-seat to -1, vcvits.py:258-261) the first epoch-end step does not decay; a resumed run (re-seat to
+    current_epoch - 1 >= 0) decays at every step."""
+    from vcvits_amd.light.optim import ExponentialLR, FlatAdamW
+
+    def torch20(lr0, gamma, last_epoch, steps):  # the 2.0.x recurrence, restated
+        lr, out = lr0, []
+        for _ in range(steps):
+            last_epoch += 1
+            if last_epoch != 0:
+                lr *= gamma
+            out.append(lr)
+        return out
+
+    for start_epoch in (0, 1, 4):
+        opt = FlatAdamW([torch.nn.Parameter(torch.zeros(2))], 2e-4)
+        sch = ExponentialLR(opt, gamma=0.9)
+        sch.last_epoch = start_epoch - 1
+        got = []
+        for _ in range(5):
+            sch.step()
+            got.append(opt.param_groups[0]["lr"])
+        assert got == pytest.approx(torch20(2e-4, 0.9, start_epoch - 1, 5), rel=1e-12)
+    # fresh run: base, base*g, base*g^2 ...
+    opt = FlatAdamW([torch.nn.Parameter(torch.zeros(2))], 1.0)
+    sch = ExponentialLR(opt, gamma=0.5)
+    sch.last_epoch = -1
+    rates = []
+    for _ in range(3):
+        sch.step()
+        rates.append(opt.lr)
+    assert rates == [1.0, 0.5, 0.25]

@@ -179,3 +179,37 @@ def test_sinks_frozen_and_unused_parameters_two_ranks():
         touched = res0[pass_idx][1]
         # reversed order: [unused b, unused w, b3, w3, b2, w2, b1, w1]
         assert list(touched) == [0, 0, 1, 1, 1, 1, 0 if frozen else 1, 0 if frozen else 1]
+
+
+def _uneven_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcvits_amd.light.optim import FlatAdamW
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)  # `b` is a conditioning path only rank 0's batch exercises
+    opt = FlatAdamW(list(a.parameters()) + list(b.parameters()), 1e-2, bucket_mb=0.0001)
+    opt.broadcast_parameters()
+    g = torch.Generator().manual_seed(300 + rank)
+    x = torch.randn(3, 4, generator=g)
+    opt.zero_grad()
+    y = a(x) + (b(x) if rank == 0 else 0.0)
+    y.pow(2).mean().backward()
+    opt.finish_grad_sync()
+    out[rank] = (bytes(opt._touched), opt.grad.clone(), [r for r in opt._update_ranges()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_used_on_one_rank_is_updated_on_all():
+    """a parameter one rank used and another did not received the averaged gradient on both, so both must
+    step it -- the `touched` flags are OR-ed across the group before the update ranges are built."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_uneven_worker, args=(world, port, out), nprocs=world, join=True)
+    (t0, g0, r0), (t1, g1, r1) = out[0], out[1]
+    assert t0 == t1 and all(t0)          # every parameter counts as touched on BOTH ranks
+    assert torch.equal(g0, g1)           # the same averaged gradient ...
+    assert r0 == r1 and len(r0) == 1     # ... and the same single update range on both ranks

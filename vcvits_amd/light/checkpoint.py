@@ -132,32 +132,40 @@ def _read(path, map_location, allow_pickle):
         return torch.load(path, map_location=map_location, weights_only=False)
 
 
-def _load_torch_optim(module, opt, idx, ckpt, st):
-    """torch.optim.AdamW state (keyed by parameter index in the CHECKPOINT's parameter order) -> flat buffers.
-    Returns False (state left untouched) when the checkpoint's parameter list cannot be aligned by name."""
+def _plan_torch_optim(module, opt, idx, ckpt, st):
+    """Align a torch.optim.AdamW state (keyed by parameter index in the CHECKPOINT's parameter order) with the flat
+    buffers of `opt`, WITHOUT touching them.  Returns the list of (parameter slot, offset, numel, state entry) to copy,
+    or None when the checkpoint's parameter list cannot be aligned by name or a moment has the wrong shape."""
     pres = _optimizer_prefixes(idx)
     ck_names = [k for k in ckpt["state_dict"] if k.startswith(pres) and not k.endswith(_BUFFER_SUFFIXES)]
     pids = [pid for g in st["param_groups"] for pid in g["params"]]
     if len(ck_names) != len(pids):
         logging.info("optimizer %d: %d parameter indices but %d candidate tensors in state_dict; state dropped",
                      idx, len(pids), len(ck_names))
-        return False
+        return None
     name_of = dict(zip(pids, ck_names))
     params = dict(module.named_parameters())
     where = {id(p): (i, o) for i, (p, o) in enumerate(zip(opt.params, opt.offsets))}
+    plan = []
+    for pid, s in st["state"].items():
+        p = params.get(name_of.get(pid))
+        if p is None or id(p) not in where:
+            continue  # third-party (frozen HuBERT) entries
+        if tuple(s["exp_avg"].shape) != tuple(p.shape) or tuple(s["exp_avg_sq"].shape) != tuple(p.shape):
+            logging.info("optimizer %d: moment shape mismatch for %s; state dropped", idx, name_of.get(pid))
+            return None
+        i, o = where[id(p)]
+        plan.append((i, o, p.numel(), s))
+    return plan
+
+
+def _commit_torch_optim(opt, st, plan):
+    """Write a validated plan of _plan_torch_optim into the flat buffers."""
     opt.exp_avg.zero_()
     opt.exp_avg_sq.zero_()
     opt._pstep = [0] * len(opt.params)
     top = 0
-    for pid, s in st["state"].items():
-        name = name_of.get(pid)
-        p = params.get(name)
-        if p is None or id(p) not in where:
-            continue  # third-party (frozen HuBERT) entries
-        i, o = where[id(p)]
-        n = p.numel()
-        if tuple(s["exp_avg"].shape) != tuple(p.shape):
-            return False
+    for i, o, n, s in plan:
         opt.exp_avg[o:o + n].copy_(s["exp_avg"].reshape(-1).to(opt.exp_avg.device))
         opt.exp_avg_sq[o:o + n].copy_(s["exp_avg_sq"].reshape(-1).to(opt.exp_avg.device))
         opt._pstep[i] = int(float(s["step"]))
@@ -167,7 +175,6 @@ def _load_torch_optim(module, opt, idx, ckpt, st):
     opt.set_lr(g0["lr"])
     if "initial_lr" in g0:
         opt.base_lr = float(g0["initial_lr"])
-    return True
 
 
 def load_checkpoint(module, path: str, map_location="cpu", allow_pickle=False) -> dict:
@@ -195,18 +202,29 @@ def load_checkpoint(module, path: str, map_location="cpu", allow_pickle=False) -
     module.global_step = int(ckpt.get("global_step", 0))
     extra = ckpt.get("vcvits_amd") or {}
     if "dropout_seed_state" in extra:
-        ops.set_seed_state(extra["dropout_seed_state"])
+        # the saved stream position is rank 0's; every other data-parallel rank keeps its own offset (as
+        # configure_optimizers seeds it), or all ranks would draw identical dropout masks after a resume
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        ops.set_seed_state((int(extra["dropout_seed_state"]) + 0x9E3779B97F4A7C15 * rank) % (1 << 64))
     states = ckpt.get("optimizer_states")
     restored = False
     if states and module.optim_g is not None and len(states) == 2:
         if ckpt.get("format") == FORMAT_V1:
-            for opt, sd in zip((module.optim_g, module.optim_d), states):
-                if sd["exp_avg"].numel() == opt.numel:
+            opts = (module.optim_g, module.optim_d)
+            if all(sd["exp_avg"].numel() == opt.numel for opt, sd in zip(opts, states)):
+                for opt, sd in zip(opts, states):
                     opt.load_state_dict({k: (v.to(opt.flat.device) if torch.is_tensor(v) else v) for k, v in sd.items()})
-                    restored = True
+                restored = True
         elif all(isinstance(s, dict) and "param_groups" in s for s in states):
-            restored = all([_load_torch_optim(module, opt, i, ckpt, s)
-                            for i, (opt, s) in enumerate(zip((module.optim_g, module.optim_d), states))])
+            # both optimizers or neither: validate everything first, then write (a half-restored pair -- G with its
+            # moments and rate, D fresh -- would train with inconsistent state)
+            opts = (module.optim_g, module.optim_d)
+            plans = [_plan_torch_optim(module, opt, i, ckpt, s) for i, (opt, s) in enumerate(zip(opts, states))]
+            if all(pl is not None for pl in plans):
+                for opt, s, pl in zip(opts, states, plans):
+                    _commit_torch_optim(opt, s, pl)
+                restored = True
     # schedulers: vcvits.py:258-261 re-seats last_epoch to current_epoch - 1 in configure_optimizers (which Lightning
     # calls before it restores the loop state, i.e. with current_epoch still 0); a restored scheduler state then
     # overrides it.  Without restored optimizer state the rate stays what configure_optimizers set -- the reference's

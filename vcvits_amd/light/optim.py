@@ -140,6 +140,13 @@ class FlatAdamW:
             if view is not None:
                 view.div_(self.world)
         self._works = []
+        # A parameter one rank used and another did not (a batch-dependent conditioning path) still received the
+        # averaged gradient everywhere: every rank must apply the same update, so the "received a gradient" flags are
+        # OR-ed across the group (torch DDP reduces its used-parameter bitmap for the same reason).
+        if self.world > 1:
+            flags = torch.tensor(list(self._touched), dtype=torch.uint8, device=self.grad.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
+            self._touched[:] = bytes(flags.cpu().tolist())
 
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -219,14 +226,20 @@ class ExponentialLR:
     gamma, so after a resume the rate continues from whatever the restored optimizer state holds (and from the
     base rate when that state was dropped -- exactly what the reference does)."""
 
-    def __init__(self, optimizer, gamma, last_epoch=-1):
+    def __init__(self, optimizer, gamma, last_epoch=-1, reference_stack=True):
+        """reference_stack=True follows the scheduler of the reference's PINNED stack (requirements.txt: lightning 2.0.x on
+        torch 2.0.x), whose `get_lr` returns the rate unchanged when `last_epoch == 0`: after the reference re-seats
+        `last_epoch = current_epoch - 1 = -1` on a fresh run, the first epoch-end step therefore does NOT decay, and the
+        rate after e >= 1 epochs is base * gamma^(e - 1).  False: torch >= 2.2 (`_is_initial`), every step decays."""
         self.optimizer, self.gamma = optimizer, float(gamma)
+        self.reference_stack = bool(reference_stack)
         self.last_epoch = last_epoch + 1  # torch's constructor performs the initial step: rate unchanged
         self._last_lr = [optimizer.lr]
 
     def step(self):
         self.last_epoch += 1
-        self.optimizer.set_lr(self.optimizer.lr * self.gamma)
+        if not (self.reference_stack and self.last_epoch == 0):
+            self.optimizer.set_lr(self.optimizer.lr * self.gamma)
         self._last_lr = [self.optimizer.lr]
 
     def get_last_lr(self):
