@@ -32,6 +32,9 @@ class CpuTrainer:
         d = hparams["data"]
         self.melmat = torch.from_numpy(O.mel_filterbank(d["target_sampling_rate"], d["filter_length"],
                                                         d["n_mel_channels"], d["mel_fmin"], d["mel_fmax"]))
+        # dropout of the content encoder: None = identity; tests set a callable that multiplies by the masks the HIP
+        # step drew (same elements dropped on both sides), consumed in the reference's call order
+        self.drop = None
 
     def _mel(self, wav):
         d = self.hp["data"]
@@ -59,7 +62,7 @@ class CpuTrainer:
             y_spec_lengths = (batch["y_wav_lengths"] / d["hop_length"]).long()
         x, m_p, logs_p, x_mask = O.content_encoder_forward(
             sd, "net_g.enc_p", batch["x_hubert_features_values"], batch["x_hubert_features_lengths"],
-            batch["x_pitch_values"], C, m["n_heads"], m["n_layers"], m["kernel_size"])
+            batch["x_pitch_values"], C, m["n_heads"], m["n_layers"], m["kernel_size"], drop=self.drop)
         g = torch.nn.functional.embedding(batch["sid"], sd["net_g.emb_g.weight"]).unsqueeze(-1)
         z, m_q, logs_q, y_mask = O.posterior_encoder_forward(sd, "net_g.enc_q", y_spec, y_spec_lengths, g,
                                                             batch["noise"], C, H, 5, 1, 16)

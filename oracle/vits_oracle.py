@@ -158,11 +158,13 @@ def channel_layer_norm(x, gamma, beta, eps=1e-5):
     return xt.transpose(1, -1)
 
 
-def rel_attention(sd, prefix, x, attn_mask, n_heads, window_size):
+def rel_attention(sd, prefix, x, attn_mask, n_heads, window_size, drop=None):
     """vits/model/transformer/relative_attention_transformer.py:136-185 (self-attention with
     shared-head windowed relative key/value embeddings), written with explicit band indexing
     instead of the pad/reshape skew (:217-251): rel_logits[b,h,i,j] = q_i . E_k[j-i+w] for
-    |j-i| <= w, and out_i += sum_{|j-i|<=w} p[i,j] * E_v[j-i+w].  Dropout is identity (eval)."""
+    |j-i| <= w, and out_i += sum_{|j-i|<=w} p[i,j] * E_v[j-i+w].  `drop`: None = dropout is identity (eval); else a
+    callable applied to the probabilities where the reference applies `self.drop` (:173), returning them multiplied by
+    a dropout mask / (1 - p) -- the tests feed it the masks the HIP step drew, so both sides drop the same elements."""
     q = F.conv1d(x, sd[prefix + ".conv_q.weight"], sd[prefix + ".conv_q.bias"])
     k = F.conv1d(x, sd[prefix + ".conv_k.weight"], sd[prefix + ".conv_k.bias"])
     v = F.conv1d(x, sd[prefix + ".conv_v.weight"], sd[prefix + ".conv_v.bias"])
@@ -186,6 +188,8 @@ def rel_attention(sd, prefix, x, attn_mask, n_heads, window_size):
     scores = scores + local
     scores = scores.masked_fill(attn_mask == 0, -1e4)
     p = F.softmax(scores, dim=-1)
+    if drop is not None:
+        p = drop(p)
     out = torch.matmul(p, v)
     # relative values: weights[b,h,i,r] = p[b,h,i,i+r-w]
     pw = torch.zeros(b, n_heads, t, 2 * w + 1, dtype=p.dtype)
@@ -200,31 +204,38 @@ def rel_attention(sd, prefix, x, attn_mask, n_heads, window_size):
     return out, p
 
 
-def ffn_forward(sd, prefix, x, x_mask, kernel_size):
-    """relative_attention_transformer.py:285-311 (non-causal FFN, ReLU, same padding)."""
+def ffn_forward(sd, prefix, x, x_mask, kernel_size, drop=None):
+    """relative_attention_transformer.py:285-311 (non-causal FFN, ReLU, dropout (:304), same padding)."""
     pl, pr = (kernel_size - 1) // 2, kernel_size // 2
     h = F.conv1d(F.pad(x * x_mask, (pl, pr)), sd[prefix + ".conv_1.weight"], sd[prefix + ".conv_1.bias"])
     h = torch.relu(h)
+    if drop is not None:
+        h = drop(h)
     h = F.conv1d(F.pad(h * x_mask, (pl, pr)), sd[prefix + ".conv_2.weight"], sd[prefix + ".conv_2.bias"])
     return h * x_mask
 
 
-def transformer_encoder_forward(sd, prefix, x, x_mask, n_heads, n_layers, kernel_size, window_size=4):
-    """relative_attention_transformer.py:35-47 (post-LN encoder; dropout identity)."""
+def transformer_encoder_forward(sd, prefix, x, x_mask, n_heads, n_layers, kernel_size, window_size=4, drop=None):
+    """relative_attention_transformer.py:35-47 (post-LN encoder).  drop: see rel_attention (None: identity); called in
+    the reference's order per layer: attention probabilities, attention output (:40), FFN hidden (:304), FFN output (:44)."""
     attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     x = x * x_mask
     for i in range(n_layers):
-        y, _ = rel_attention(sd, "%s.attn_layers.%d" % (prefix, i), x, attn_mask, n_heads, window_size)
+        y, _ = rel_attention(sd, "%s.attn_layers.%d" % (prefix, i), x, attn_mask, n_heads, window_size, drop=drop)
+        if drop is not None:
+            y = drop(y)
         x = channel_layer_norm(x + y, sd["%s.norm_layers_1.%d.gamma" % (prefix, i)],
                                sd["%s.norm_layers_1.%d.beta" % (prefix, i)])
-        y = ffn_forward(sd, "%s.ffn_layers.%d" % (prefix, i), x, x_mask, kernel_size)
+        y = ffn_forward(sd, "%s.ffn_layers.%d" % (prefix, i), x, x_mask, kernel_size, drop=drop)
+        if drop is not None:
+            y = drop(y)
         x = channel_layer_norm(x + y, sd["%s.norm_layers_2.%d.gamma" % (prefix, i)],
                                sd["%s.norm_layers_2.%d.beta" % (prefix, i)])
     return x * x_mask
 
 
 def content_encoder_forward(sd, prefix, feats, x_lengths, pitch, out_channels, n_heads, n_layers,
-                            kernel_size, preload=False):
+                            kernel_size, preload=False, drop=None):
     """Post-HuBERT half of HubertContentEncoder.forward (content_encoder.py:58-73): `feats`
     [B, hubert, T] stands for x_encoded.  preload=True follows PreloadHubertContentEncoder
     (content_encoder.py:110-126: half-width projections concatenated)."""
@@ -239,7 +250,7 @@ def content_encoder_forward(sd, prefix, feats, x_lengths, pitch, out_channels, n
         out = hub + pe
     x_mask = sequence_mask(x_lengths.int(), out.size(2)).unsqueeze(1).to(feats.dtype)
     x_out = transformer_encoder_forward(sd, prefix + ".encoder", out * x_mask, x_mask, n_heads, n_layers,
-                                        kernel_size)
+                                        kernel_size, drop=drop)
     stats = F.conv1d(x_out, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"]) * x_mask
     m, logs = torch.split(stats, out_channels, dim=1)
     return x_out, m, logs, x_mask

@@ -1453,10 +1453,24 @@ def set_seed_state(state):
     _seed_state[0] = int(state) % (1 << 64)
 
 
+# test hook: when a list, every dropout draw of a step is appended as (kind, p, seed, shape) -- the masks are functions
+# of (seed, flat index), so a checker can regenerate them (tests/test_dropout_step_gpu.py)
+DROPOUT_TRACE = [None]
+
+
+def dropout_mask(shape, p, seed, device):
+    """The mask / (1 - p) tensor a dropout draw (p, seed) applies to a tensor of `shape` (flat-index hash, the same for
+    ops.dropout and for the attention probabilities [B*H, T, T])."""
+    return _DropoutFn.apply(torch.ones(tuple(shape), device=device, dtype=torch.float32), float(p), int(seed))
+
+
 def dropout(x, p, training=True):
     if not training or p <= 0.0:
         return x
-    return _DropoutFn.apply(x, float(p), next_seed())
+    seed = next_seed()
+    if DROPOUT_TRACE[0] is not None:
+        DROPOUT_TRACE[0].append(("drop", float(p), seed, tuple(x.shape)))
+    return _DropoutFn.apply(x, float(p), seed)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1588,6 +1602,8 @@ def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, pdrop=0.
     p = float(pdrop) if training else 0.0
     seed = next_seed() if p > 0 else 0
     B, C, T = q.shape
+    if p > 0 and DROPOUT_TRACE[0] is not None:
+        DROPOUT_TRACE[0].append(("attn", p, seed, (B * n_heads, T, T)))
     if _ATTN_FUSED[0] and lib().vcv_rel_attn_supported(B, n_heads, C // n_heads, T, window) == 0:
         return _RelAttnFusedFn.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, p, seed, bool(want_attn))
     return _RelAttnFn.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, p, seed)
