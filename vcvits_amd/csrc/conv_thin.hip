@@ -140,6 +140,12 @@ conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
                    float slope) {
   __shared__ float ws[C1_MMAX * KMAX];
   __shared__ float bs[C1_MMAX];
+  // blockIdx.z: chunk of C1_MMAX output channels (wide one-input-channel layers, e.g. the data gradient of a
+  // 1024 -> 1 conv_post, which is a one-input-channel convolution with flipped taps)
+  const int mfull = M, m0 = blockIdx.z * C1_MMAX;
+  M = M - m0 < C1_MMAX ? M - m0 : C1_MMAX;
+  w += (size_t)m0 * K;
+  if (bias) bias += m0;
   for (int i = threadIdx.x; i < M * K; i += 256) ws[i] = w[i];
   for (int i = threadIdx.x; i < M; i += 256) bs[i] = bias ? bias[i] : 0.f;
   __syncthreads();
@@ -155,7 +161,7 @@ conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     const int r = t * s + k * d - pad;
     xv[k] = (k < K && r >= 0 && r < Tin) ? xb[(size_t)r * P + pc] : 0.f;
   }
-  float* yb = y + (size_t)b * M * U + u;
+  float* yb = y + ((size_t)b * mfull + m0) * U + u;
   for (int m = 0; m < M; ++m) {
     float acc = bs[m];
     const float* wr = ws + m * K;
@@ -291,10 +297,9 @@ extern "C" int vcv_linear_t1_wgrad(const float* dy, const float* x, float* dw, i
 extern "C" int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin,
                                int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
                                void* stream) {
-  if (!x || !w || !y || B <= 0 || M <= 0 || M > C1_MMAX || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || K > KMAX ||
-      stride <= 0)
+  if (!x || !w || !y || B <= 0 || M <= 0 || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || K > KMAX || stride <= 0)
     return VCV_EINVAL;
-  hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(vcv_cdiv(Tout * P, 256), B), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+  hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(vcv_cdiv(Tout * P, 256), B, vcv_cdiv(M, C1_MMAX)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                      y, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope);
   return vcv_check_launch();
 }

@@ -239,6 +239,14 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         check(lib().vcv_conv_c1_dgrad(ptr(dy), ptr(w), ptr(out), B, M, Tin, Tout, P, K, stride, dil, pad, stream()),
               "vcv_conv_c1_dgrad")
         return out
+    if (M == 1 and groups == 1 and stride == 1 and C >= 16 and K <= 16 and kw.get("in_tf", TF_NONE) == TF_NONE
+            and set(kw) <= {"in_tf", "xaux", "slope"}):
+        # one OUTPUT channel (conv_post of the discriminators, 1024 -> 1): the data gradient is a one-input-channel
+        # convolution of dy with the flipped taps -- an HBM write stream, not a GEMM (was 35 us on the generic kernel)
+        wf = w.reshape(C, K).flip(-1).contiguous()
+        check(lib().vcv_conv_c1_fwd(ptr(dy), ptr(wf), None, ptr(out), B, C, Tout, Tin, P, K, 1, dil, (K - 1) * dil - pad,
+                                    ACT_NONE, kw.get("slope", 0.1), stream()), "vcv_conv_c1_fwd")
+        return out
     if stride == 1 and groups == 1 and M >= 32 and C >= 32:
         # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
         # staging path (row-major weight rows) is the faster one
@@ -1195,23 +1203,34 @@ def istft(spec, n_fft=2048, hop=512, center=True):
 
 
 class _MelLogFn(torch.autograd.Function):
-    """log(clamp(M @ spec, clamp)) as a 1x1 conv with the log-clamp fused in the epilogue."""
+    """log(clamp(M @ spec, clamp)) as a 1x1 conv with the log-clamp fused in the epilogue.  Short segments (the training
+    step's 32 frames) fold the batch into the column dimension, as the convs of short sequences do: one batch element's
+    32 columns cannot fill a GEMM tile (the launch ran at 1.7 TFLOP/s on the generic kernel)."""
 
     @staticmethod
     def forward(ctx, spec, melmat, clamp):
         spec, melmat = _f32c(spec), _f32c(melmat)
         w = melmat.view(melmat.shape[0], melmat.shape[1], 1)
-        y = conv_forward(spec, w, out_act=ACT_LOGCLAMP, slope=clamp)
+        ctx.bt = spec.dim() == 3 and spec.shape[0] > 1 and spec.shape[2] <= 64
+        if ctx.bt:
+            yf = conv_forward(_to_bt(spec), w, out_act=ACT_LOGCLAMP, slope=clamp)  # [1, n_mel, T, B]
+            y = _from_bt(yf)
+        else:
+            y = yf = conv_forward(spec, w, out_act=ACT_LOGCLAMP, slope=clamp)
         ctx.clamp = clamp
-        ctx.save_for_backward(w, y)
+        ctx.save_for_backward(w, yf)
         ctx.xshape = spec.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        w, y = ctx.saved_tensors
+        w, yf = ctx.saved_tensors
         dy = _f32c(dy)
-        dx = conv_dgrad(dy, w, ctx.xshape, in_tf=_lib.TF_DLOGCLAMP, xaux=y, slope=ctx.clamp)
+        if ctx.bt:
+            B, C, T = ctx.xshape
+            dx = _from_bt(conv_dgrad(_to_bt(dy), w, (1, C, T, B), in_tf=_lib.TF_DLOGCLAMP, xaux=yf, slope=ctx.clamp))
+        else:
+            dx = conv_dgrad(dy, w, ctx.xshape, in_tf=_lib.TF_DLOGCLAMP, xaux=yf, slope=ctx.clamp)
         return dx, None, None
 
 
