@@ -42,7 +42,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 constexpr int NPROD = 4;  // producer waves: 1 weight-DMA wave + 3 input-staging waves
 constexpr int NXW = 3;
 constexpr int MAXT = 2;   // pipelined staging tasks per input wave and stage
-constexpr int NRING = 4;  // weight-slab ring slots (a power of two)
+constexpr int NRING_DEF = 4;  // weight-slab ring slots (a power of two; the 256-row tile takes 2)
 
 // one term a_PA * b_PB of the split product on every accumulator tile of the wave (literal plane indices: a computed
 // index makes the compiler select fragment registers at run time)
@@ -107,7 +107,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // BfGeom fields as used here: nch = channel groups of 16, a_bytes = one weight slab (3 * 2 * BM * 16), buf_bytes = one
 // span buffer (3 * 2 * xw * 16), JA / phases / ks / vec / ntu / nmt / xw as in conv_pk.hip; BKC = 16, ncg = 1.
-template <int NTERM, int TM, int TN, int WM, int WN, bool LEAKY>
+template <int NTERM, int TM, int TN, int WM, int WN, bool LEAKY, int NRING = NRING_DEF>
 __global__ void __launch_bounds__(64 * (WM * WN + NPROD))
 conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
@@ -347,7 +347,7 @@ bool eligible(const VcvConvArgs& a) {
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);
 }
 
-bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
+bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring = NRING_DEF) {
   pl.BM = BM; pl.BN = BN; pl.NW = NW;
   BfGeom& g = pl.g;
   const int qspan = (BN - 1) / a.P + 1;
@@ -363,7 +363,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
   g.nmt = vcv_cdiv(a.Mg, BM);
   g.a_bytes = 3 * 2 * BM * 16;
   g.buf_bytes = 3 * 2 * g.xw * 16;
-  pl.lds_bytes = (size_t)NRING * g.a_bytes + 2ull * g.buf_bytes;
+  pl.lds_bytes = (size_t)nring * g.a_bytes + 2ull * g.buf_bytes;
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
   g.vec = 0;
@@ -372,7 +372,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl) {
   return true;
 }
 
-// variants: 0: 128x256 (8 MFMA waves of 2x2 tiles)   1: 128x128 (8 waves of 2x1)   3: 64x256 (8 waves of 1x2)
+// variants: 0: 128x256 (8 MFMA waves of 2x2 tiles)   1: 128x128 (8 waves of 2x1)   2: 256x128 (8 waves of 2x2)   3: 64x256 (8 waves of 1x2)
 //           4: 64x128 (8 waves of 1x1)   5: 32x256 (8 waves of 1x1)
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
@@ -389,6 +389,9 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   if (a.Mg >= 96) {
     const double e256 = U > 160 ? eff(128, 256) : 0.0, e128 = eff(128, 128);
     if (e256 >= e128 - 0.02 && e256 > 0.0 && make_plan(a, 128, 256, 8, pl)) pl.variant = 0, ok = true;
+    // 128 columns (the strided layers, whose input span is stride x as long, do not fit 256): 256 rows x 128 columns keeps
+    // the 2 x 2 accumulator tiles per wave (12 fragment reads per 24 MFMAs instead of 9 per 12) with a two-slot ring
+    else if (a.Mg >= 256 && eff(256, 128) >= e128 - 0.1 && make_plan(a, 256, 128, 8, pl, 2)) pl.variant = 2, ok = true;
     else if (make_plan(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
   } else if (a.Mg >= 48) {
     if (U > 160 && eff(64, 256) >= eff(64, 128) - 0.02 && make_plan(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
@@ -420,7 +423,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
 int g_all = getenv("VCVITS_X3_ALL") != nullptr ? 1 : 0;
 int g_terms = [] { const char* e = getenv("VCVITS_X3_TERMS"); return e && atoi(e) == 9 ? 9 : 6; }();
 
-template <int NTERM, int TM, int TN, int WM, int WN>
+template <int NTERM, int TM, int TN, int WM, int WN, int NRING = NRING_DEF>
 int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, NT = 64 * (WM * WN + NPROD);
   const BfGeom& g = pl.g;
@@ -431,7 +434,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip
                        a.K, BM, g.JA, g.nch, g.nmt, g.phases, mode, total);
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const char*, float*) =
-      a.in_tf == VCV_TF_LEAKY ? conv_x3_kernel<NTERM, TM, TN, WM, WN, true> : conv_x3_kernel<NTERM, TM, TN, WM, WN, false>;
+      a.in_tf == VCV_TF_LEAKY ? conv_x3_kernel<NTERM, TM, TN, WM, WN, true, NRING> : conv_x3_kernel<NTERM, TM, TN, WM, WN, false, NRING>;
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
@@ -458,6 +461,7 @@ int run_n(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip,
   switch (pl.variant) {
     case 0: return launch<NTERM, 2, 2, 2, 4>(a, pl, wp, part, flip, pv, st);
     case 1: return launch<NTERM, 2, 1, 2, 4>(a, pl, wp, part, flip, pv, st);
+    case 2: return launch<NTERM, 2, 2, 4, 2, 2>(a, pl, wp, part, flip, pv, st);  // 256 x 128
     case 3: return launch<NTERM, 1, 2, 2, 4>(a, pl, wp, part, flip, pv, st);
     case 4: return launch<NTERM, 1, 1, 2, 4>(a, pl, wp, part, flip, pv, st);
     default: return launch<NTERM, 1, 1, 1, 8>(a, pl, wp, part, flip, pv, st);
