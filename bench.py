@@ -277,13 +277,15 @@ def build_infer(cfg, B, T, dev):
     return step
 
 
-def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True):
+def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True, f32_split=None):
     """Build the workload, do `warmup` untimed steps, time exactly `steps` steps between barrier + synchronize on both
     sides, MAX over ranks.  Returns the pieces of the JSON line."""
     from vcvits_amd import _lib, configs, ops, synthetic
     from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS, VocoderGAN
     L = _lib.lib()
     ops.set_compute_dtype(dtype)
+    if f32_split is not None:  # (on, terms): the fp32 arithmetic variant of this leg; default = the library's default
+        ops.set_f32_split(f32_split[0], terms=f32_split[1])
     infer = workload == "infer"
     cfg = configs.base() if config == "base" else configs.base_48k()
     B = batch if batch is not None else (64 if infer else 16)
@@ -332,6 +334,8 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
         nbytes = (ctypes.c_double * NCLS)()
         _lib.check(L.vcv_prof_end(out, NCLS), "vcv_prof_end")
         _lib.check(L.vcv_prof_bytes(nbytes, NCLS), "vcv_prof_bytes")
+        roofs = (ctypes.c_double * NCLS)()
+        _lib.check(L.vcv_prof_roof(roofs, NCLS), "vcv_prof_roof")
         if os.environ.get("VCVITS_PROF_DUMP"):
             L.vcv_prof_dump(os.environ["VCVITS_PROF_DUMP"].encode())
 
@@ -340,7 +344,12 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
             if n <= 0 or ms <= 0:
                 return None
             ach = fl / (ms * 1e-3) / 1e12
-            return {"kernel": PROF_CLASSES[i], "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+            # roofline of a class whose launches run on different matrix pipes (fp32-input MFMA 157.3 TFLOP/s, bf16 MFMA
+            # 2.5 PFLOP/s; split-operand fp32 launches execute 6 or 9 bf16 products per fp32 product): time at the dense
+            # peak of each launch's own pipe, summed, over the measured time; `peak` = the algorithmic rate that sum allows
+            frac = roofs[i] / (ms * 1e-3)
+            return {"kernel": PROF_CLASSES[i], "achieved": round(ach, 2), "frac": round(frac, 4),
+                    "peak": round(fl / roofs[i] / 1e12, 1),
                     "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / n, 2),
                     "gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms * 1e-3 / dt, 3),
                     "algorithmic_bytes_per_launch": round(nbytes[i] / n) if nbytes[i] > 0 else None}
@@ -351,8 +360,12 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
             dom = max(fams, key=lambda c: c["share_of_step_time"])
             traffic, traffic_src, stale = profiled_traffic(PROF_FAMILIES[PROF_CLASSES.index(dom["kernel"])],
                                                            "%s/%s/%s" % (config, workload, dtype))
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
-                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
+                    "unit": "TFLOP/s", "frac": dom["frac"],
+                    "peak_note": "algorithmic TFLOP/s at the dense MFMA peak of the pipe each launch of the class runs on "
+                                 "(fp32-input MFMA 157.3; bf16 MFMA 2500, / 6 or / 9 for split-operand fp32 launches); "
+                                 "random-data bf16 MFMA loops sustain ~1250 of the 2500 on this chip (clock give-back, "
+                                 "MI355X_MICROARCH.md)", "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": traffic_src, "traffic_stale": stale,
                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                     "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
@@ -366,9 +379,23 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     del run, module
     ops.invalidate_weights()
     ops.set_compute_dtype("f32")
+    arith = f32_arithmetic(ops, L) if dtype == "f32" else None
+    if f32_split is not None:
+        ops.set_f32_split(True, terms=6)
     torch.cuda.empty_cache()
-    return {"dt": dt, "roof": roof, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
+    return {"arith": arith, "dt": dt, "roof": roof, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
             "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world}
+
+
+def f32_arithmetic(ops, L):
+    """How the fp32 GEMM-shaped launches of the leg just run were computed."""
+    if not ops._USE_X3[0]:
+        return "fp32 throughout: fp32-input MFMA (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain)"
+    n = L.vcv_conv_x3_get_terms()
+    return ("fp32 throughout; GEMM-shaped launches by exact operand splitting: every fp32 operand = 3 bf16 terms, %d of the 9 "
+            "bf16 MFMA products per fp32 product (%s), fp32 accumulate; the rest on fp32-input MFMA / fp32 VALU"
+            % (n, "all: exact operands" if n == 9 else "the 3 left out are each < 2^-24 of the product; error vs float64 "
+                                                        "equal to the 9-term and the fmaf-chain kernels': profiles/r3_x3_vs_f64.txt"))
 
 
 def make_line(r):
@@ -400,7 +427,7 @@ def make_line(r):
                             "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                             "utterances_per_s": round(utt_s, 3), "algorithmic_gflop_per_utterance": round(gfl, 1),
                             "algorithmic_tflops": round(utt_s * gfl / 1e3, 2),
-                            "arithmetic": ("fp32 throughout (fp32-input MFMA)" if dtype == "f32" else
+                            "arithmetic": (r["arith"] if dtype == "f32" else
                                            "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},
                  "roofline": r["roof"]})
     return line
@@ -470,11 +497,18 @@ def main(argv=None):
     if default_run:
         # BASELINE configs[2] and configs[4], a few steps each, so that the driver's line carries them too
         extra = {}
-        for key, (c, w, dt_, b) in {"configs[2]": ("base", "full", "bf16", 32),
-                                    "configs[4]": ("48k", "infer", "bf16", 64)}.items():
+        legs = {"configs[2]": ("base", "full", "bf16", 32, None),
+                "configs[4]": ("48k", "infer", "bf16", 64, None),
+                # the headline workload in the two other fp32 arithmetics the library offers
+                "configs[1], nine product terms (exact operands)": ("base", "vocoder", "f32", None, (True, 9)),
+                "configs[1], fp32-input MFMA kernels (fmaf chain, no operand splitting)": ("base", "vocoder", "f32", None, (False, None))}
+        for key, (c, w, dt_, b, split) in legs.items():
             try:
-                extra[key] = short(make_line(run_leg(c, w, dt_, b, 938, 4 if w != "infer" else 3, 2, dev, 1, 0,
-                                                     prof=not a.no_prof)))
+                ln = make_line(run_leg(c, w, dt_, b, 938, 4 if w != "infer" else 3, 2, dev, 1, 0, prof=not a.no_prof,
+                                       f32_split=split))
+                extra[key] = short(ln)
+                if split is not None:
+                    extra[key]["arithmetic"] = ln["config"]["arithmetic"]
             except Exception as e:  # a failed extra leg must not cost the headline line
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         line["config"]["extra_configs"] = extra

@@ -391,6 +391,11 @@ int vcv_prof_end(double* out, int ncls);
 /* out[cls] = algorithmic HBM bytes (operands read once + result written once) summed over the class's launches of the
  * window vcv_prof_end just closed */
 int vcv_prof_bytes(double* out, int ncls);
+/* out[cls] = sum over the class's launches in that window of their time at the DENSE PEAK of the matrix pipe each one
+ * runs on (seconds): MFMA flops the launch executes / peak of its pipe (fp32-input MFMA 157.3 TFLOP/s; bf16 MFMA 2.5
+ * PFLOP/s; a split-operand fp32 launch executes 6 or 9 bf16 products per fp32 product).  sum / measured time = the
+ * roofline fraction of a class that mixes pipes. */
+int vcv_prof_roof(double* out, int ncls);
 /* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */
 int vcv_prof_dump(const char* path);
 

@@ -1,26 +1,49 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): rocprofv3 kernel trace + the two PMC passes of the default bench (fp32, BASELINE configs[1])
-# and of the bf16 variant, raw CSVs under gpurun_out/<tag>/..., then condensed by tools/profile_summary.py into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/run_profiles.sh r2'
+# Run on the GPU box (gpurun): rocprofv3 kernel trace + the two HBM-traffic PMC passes (each in its own run, per
+# MI355X_MICROARCH.md) of the bench workloads, an MFMA-busy PMC pass of the dominant kernels, raw CSVs under
+# gpurun_out/<tag>_*/..., condensed by tools/profile_summary.py / tools/pmc_busy_summary.py into profiles/.
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r3'
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-run() {  # name, bench flags...
-  local name=$1; shift
+mkdir -p gpurun_out profiles
+run() {  # name, workload key, bench flags...
+  local name=$1 key=$2; shift 2
   local out=gpurun_out/$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out.trace.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof "$@" > $out.fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof "$@" > $out.write.log 2>&1
+  rm -rf $out
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $out.trace.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof "$@" > $out.fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof "$@" > $out.write.log 2>&1
+  python3 tools/profile_summary.py $out profiles/$name $key > $out.summary.log 2>&1
+  rm -rf $out/*/*/*.db $out/*/*_kernel_trace.csv $out/*/*/*_kernel_trace.csv $out/*/*counter_collection.csv $out/*/*/*counter_collection.csv
 }
-mkdir -p gpurun_out
-run ${TAG}_f32
-run ${TAG}_bf16 --dtype bf16
-run ${TAG}_full_f32 --workload full
-python3 bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
-python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_bf16.json 2>/dev/null
-python3 bench.py --dtype bf16 --workload full --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_cfg3.json 2>/dev/null
-python3 bench.py --dtype bf16 --config 48k --workload full --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_cfg4_1gpu.json 2>/dev/null
-python3 bench.py --dtype bf16 --config 48k --workload infer --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_line_cfg5.json 2>/dev/null
-python3 bench.py --config 48k --workload infer --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_cfg5_f32.json 2>/dev/null
-ls -la gpurun_out/${TAG}_f32/*/ gpurun_out/${TAG}_bf16/*/ 2>/dev/null | head -40
+run ${TAG}_f32 base/vocoder/f32
+run ${TAG}_bf16 base/vocoder/bf16 --dtype bf16
+run ${TAG}_full_bf16 base/full/bf16 --workload full --batch 32 --dtype bf16
+run ${TAG}_48k_full_bf16 48k/full/bf16 --config 48k --workload full --dtype bf16
+run ${TAG}_48k_infer_f32 48k/infer/f32 --config 48k --workload infer
+run ${TAG}_48k_infer_bf16 48k/infer/bf16 --config 48k --workload infer --dtype bf16
+# MFMA pipe busy of the dominant kernels (period-discriminator layers) and of the fused attention kernels
+for sp in 6 0; do
+  rm -rf gpurun_out/${TAG}_busy$sp
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_busy$sp -o m -- python3 tools/conv_layer_bench.py --reps 3 --only discP --split $sp > gpurun_out/${TAG}_busy$sp.log 2>&1
+  python3 tools/pmc_busy_summary.py gpurun_out/${TAG}_busy$sp profiles/${TAG}_mfma_busy_split$sp.txt "python3 tools/conv_layer_bench.py --reps 3 --only discP --split $sp" > /dev/null
+  rm -rf gpurun_out/${TAG}_busy$sp
+done
+rm -rf gpurun_out/${TAG}_busya
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_busya -o m -- python3 tools/attn_bench.py --reps 3 > gpurun_out/${TAG}_busya.log 2>&1
+python3 tools/pmc_busy_summary.py gpurun_out/${TAG}_busya profiles/${TAG}_attn_mfma_busy.txt "python3 tools/attn_bench.py --reps 3" > /dev/null
+rm -rf gpurun_out/${TAG}_busya
+# per-layer table and the bench lines of every configuration (after the traffic files exist: the lines carry `traffic`)
+python3 tools/conv_layer_bench.py --reps 10 > profiles/${TAG}_conv_layers.txt 2>/dev/null
+python3 tools/conv_layer_bench.py --reps 10 --split 0 > profiles/${TAG}_conv_layers_fp32_mfma.txt 2>/dev/null
+python3 tools/attn_bench.py > profiles/${TAG}_attn_bench.txt 2>/dev/null
+python3 bench.py --steps 10 --warmup 3 > profiles/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
+python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > profiles/${TAG}_bench_line_bf16.json 2>/dev/null
+python3 bench.py --dtype bf16 --workload full --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2.json 2>/dev/null
+python3 bench.py --dtype bf16 --config 48k --workload full --steps 5 --warmup 2 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg3_1gpu.json 2>/dev/null
+python3 bench.py --dtype bf16 --config 48k --workload infer --steps 3 --warmup 1 > profiles/${TAG}_bench_line_cfg4.json 2>/dev/null
+python3 bench.py --config 48k --workload infer --steps 3 --warmup 1 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg4_f32.json 2>/dev/null
+cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
+ls profiles/ | grep ${TAG}_ | head -80

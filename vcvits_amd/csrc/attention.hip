@@ -466,7 +466,7 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
   const double flops = 4.0 * B * H * (double)T * T * dk;
   const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 100, 32 * 1000 + 32, 0};
   hipEvent_t ev0, ev1;
-  vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0);
+  vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
   hipExtLaunchKernelGGL(kern, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, (hipStream_t)stream, ev0, ev1, 0, a);
   return vcv_check_launch();
 }
@@ -495,10 +495,10 @@ extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, 
   const double flops = 4.0 * B * H * (double)T * T * dk;
   const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 101, 32 * 1000 + 32, 0};
   hipEvent_t ev0, ev1;
-  vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0);
+  vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
   hipExtLaunchKernelGGL(rows, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, st, ev0, ev1, 0, a);
   const int tag2[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 102, 32 * 1000 + 32, 0};
-  vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0);
+  vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
   const size_t lds2 = sizeof(float) * 2 * 64 * CKP;
   if (lds2 > 64 * 1024 && hipFuncSetAttribute((const void*)cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
     return VCV_EHIP;

@@ -444,7 +444,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip
   const double abytes = 4.0 * ((double)a.B * a.Cg * a.Tin * a.P + (double)a.Mg * a.Cg * a.K +
                                (double)a.B * a.Mg * a.Tout * a.P * (1 + (a.res ? 1 : 0) + (a.oaux ? 1 : 0)));
   hipEvent_t ev0, ev1;
-  vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes);
+  vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes, NTERM * flops / VCV_PEAK_BF16_MFMA);
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, a, g, (const char*)wp, part);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;

@@ -18,4 +18,11 @@ void vcv_prof_stop(int slot, hipStream_t st);
 // start / completion timestamps: no marker packets in the queue, so profiling does not serialise the stream).
 // Both events are null when profiling is off.
 // `bytes`: algorithmic HBM bytes of the launch (operands read once + result written once), for the traffic line.
-void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop, double bytes = 0.0);
+// `roof_s`: the launch's time at the dense peak of the matrix pipe it runs on -- MFMA flops it EXECUTES / that pipe's peak
+// (fp32-input MFMA: flops / 157.3e12, the default when 0; bf16 MFMA: flops / 2.5e15; split-operand fp32 launches execute
+// NTERM bf16 products per fp32 product: NTERM * flops / 2.5e15).  bench.py reports sum(roof_s) / sum(measured) as the
+// roofline fraction of a class that mixes pipes.
+void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop, double bytes = 0.0,
+                     double roof_s = 0.0);
+#define VCV_PEAK_F32_MFMA 157.3e12
+#define VCV_PEAK_BF16_MFMA 2.5e15

@@ -11,8 +11,9 @@ std::mutex g_mu;
 bool g_on = false;
 std::vector<hipEvent_t> g_start, g_stop;
 std::vector<int> g_cls;
-std::vector<double> g_flops, g_bytes;
+std::vector<double> g_flops, g_bytes, g_roof;
 double g_last_bytes[VCV_PROF_NCLS] = {};
+double g_last_roof[VCV_PROF_NCLS] = {};
 std::vector<int> g_tags;  // 12 ints per slot
 constexpr int NTAG = 12;
 size_t g_used = 0, g_last_used = 0;
@@ -25,12 +26,14 @@ int vcv_prof_start(int cls, double flops, hipStream_t st, const int* tag, int nt
   const int slot = (int)g_used++;
   g_cls[slot] = cls;
   g_flops[slot] = flops;
+  g_roof[slot] = flops / VCV_PEAK_F32_MFMA;
   for (int i = 0; i < NTAG; ++i) g_tags[slot * NTAG + i] = (tag && i < ntag) ? tag[i] : 0;
   hipEventRecord(g_start[slot], st);
   return slot;
 }
 
-void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop, double bytes) {
+void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t* start, hipEvent_t* stop, double bytes,
+                     double roof_s) {
   *start = *stop = nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_on || g_used >= g_start.size()) return;
@@ -38,6 +41,7 @@ void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t
   g_cls[slot] = cls;
   g_flops[slot] = flops;
   g_bytes[slot] = bytes;
+  g_roof[slot] = roof_s > 0.0 ? roof_s : flops / VCV_PEAK_F32_MFMA;
   for (int i = 0; i < NTAG; ++i) g_tags[slot * NTAG + i] = (tag && i < ntag) ? tag[i] : 0;
   *start = g_start[slot];
   *stop = g_stop[slot];
@@ -60,6 +64,7 @@ extern "C" int vcv_prof_begin(int max_launches) {
   g_cls.assign(g_start.size(), 0);
   g_flops.assign(g_start.size(), 0.0);
   g_bytes.assign(g_start.size(), 0.0);
+  g_roof.assign(g_start.size(), 0.0);
   g_tags.assign(g_start.size() * NTAG, 0);
   g_used = 0;
   g_on = true;
@@ -73,7 +78,7 @@ extern "C" int vcv_prof_end(double* out, int ncls) {
   if (!out || ncls < VCV_PROF_NCLS) return VCV_EINVAL;
   g_on = false;
   for (int i = 0; i < ncls * 3; ++i) out[i] = 0.0;
-  for (int c = 0; c < VCV_PROF_NCLS; ++c) g_last_bytes[c] = 0.0;
+  for (int c = 0; c < VCV_PROF_NCLS; ++c) g_last_bytes[c] = g_last_roof[c] = 0.0;
   for (size_t i = 0; i < g_used; ++i) {
     if (hipEventSynchronize(g_stop[i]) != hipSuccess) return VCV_EHIP;
     float ms = 0.f;
@@ -82,7 +87,7 @@ extern "C" int vcv_prof_end(double* out, int ncls) {
     out[c * 3 + 0] += 1.0;
     out[c * 3 + 1] += ms;
     out[c * 3 + 2] += g_flops[i];
-    if (c >= 0 && c < VCV_PROF_NCLS) g_last_bytes[c] += g_bytes[i];
+    if (c >= 0 && c < VCV_PROF_NCLS) g_last_bytes[c] += g_bytes[i], g_last_roof[c] += g_roof[i];
   }
   g_last_used = g_used;
   g_ms.assign(g_used, 0.f);
@@ -96,6 +101,15 @@ extern "C" int vcv_prof_bytes(double* out, int ncls) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!out || ncls < VCV_PROF_NCLS) return VCV_EINVAL;
   for (int c = 0; c < VCV_PROF_NCLS; ++c) out[c] = g_last_bytes[c];
+  return VCV_OK;
+}
+
+// out[cls] = sum over the class's launches in the last window of their time at the dense peak of the matrix pipe each
+// one runs on (seconds; see prof.h)
+extern "C" int vcv_prof_roof(double* out, int ncls) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!out || ncls < VCV_PROF_NCLS) return VCV_EINVAL;
+  for (int c = 0; c < VCV_PROF_NCLS; ++c) out[c] = g_last_roof[c];
   return VCV_OK;
 }
 

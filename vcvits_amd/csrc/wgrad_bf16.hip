@@ -456,7 +456,7 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   const int tag[12] = {a.B, NT == 1 ? 2 : 3, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, WM * 32 * 1000 + WC * 32, NT * 100 + KT};
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   hipEvent_t ev0, ev1;
-  vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
+  vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes, NT * flops / VCV_PEAK_BF16_MFMA);
   hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g, scratch);
   if (g.Z <= 12)
     hipLaunchKernelGGL(wgrad_bf16_finish_kernel<true>, dim3((unsigned)vcv_cdiv(a.Cg, 32), (unsigned)vcv_cdiv(a.Mg, 8)), dim3(256), 0,
