@@ -66,7 +66,7 @@ def record_stats(kind, name, **kv):
             f.write("%s %s %s\n" % (kind, name, " ".join("%s=%.4g" % (k, v) for k, v in kv.items())))
 
 
-def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.015, frac4=0.004, cap=0.05, floor=0.0):
+def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.005, frac4=0.003, cap=0.05, floor=0.0):
     """Comparison for gradients that passed through (leaky-)ReLU layers at full size.
 
     A pre-activation within fp32 rounding of zero can land on different sides of the kink on the two machines; that
@@ -74,13 +74,15 @@ def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.015, frac4=0.004, cap
     row of a weight gradient, a little of every bias sum -- by up to a percent.  With ~1e8 activations per pass a
     handful of such flips is certain, so whole-model gradients cannot meet a 1e-4 max-norm bound element for element
     (the CPU reference run twice in different summation orders would not either).  The statistic used instead, re-based
-    in round 3 on what the full-width tests observe on the MI355X (profiles/r3_parity_stats_f32.txt: over 770 tensors of
-    >= 4096 elements the worst relative L2 is 4.1e-3, the worst share of elements beyond tol 0.93 %, the worst single
-    element 3.4 % of the scale; over 1952 small tensors the worst element is 1.1 % of the scale):
+    in round 3 on what the full-width tests observe on the MI355X (profiles/r3_parity_stats_f32.txt, two runs with
+    different kernel sets: tensors of >= 65536 elements: worst relative L2 4.1e-3, worst share of elements beyond tol
+    0.64 %, beyond 4 tol 0.12 %, worst single element 3.4 % of the scale; 4096 .. 65535 elements -- where ONE flip's cone is
+    a visible share of the tensor -- up to 1.55 % beyond tol and 0.45 % beyond 4 tol, worst element 0.46 %; small tensors:
+    worst element 1.1 % of the scale):
       * relative L2 error of the tensor <= tol_l2 (5e-3),
-      * all but `frac` (1.5 %) of the elements within tol * max|b| (+ floor) and all but `frac4` (0.4 %) within
-        4 tol * max|b|; tensors under 4096 elements (bias sums, which collect a little of EVERY flip) are held to
-        10 tol * max|b| instead, two elements excepted,
+      * all but `frac` (0.5 %; 3 % under 65536 elements) of the elements within tol * max|b| (+ floor) and all but `frac4`
+        (0.3 %; 1 %) within 4 tol * max|b|; tensors under 4096 elements (bias sums, which collect a little of EVERY
+        flip) are held to 10 tol * max|b| instead, two elements excepted,
       * no element further than `cap` (5 %) of max|b| (+ floor) away: a wrong edge tile -- a few percent of a tensor off
         by the size of the values -- fails this and the L2 bound.
     The same layer shapes are compared strictly -- as linear launches without activations -- in
@@ -104,6 +106,8 @@ def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.015, frac4=0.004, cap
         bad = int((err > 10 * tol * mx + slack).sum())  # a flip right under a bias moves that one sum
         assert bad <= 2, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad, err.numel(), 10 * tol)
         return
+    if err.numel() < 65536:
+        frac, frac4 = max(frac, 0.03), max(frac4, 0.01)
     bad = int((err > tol * mx + slack).sum())
     assert bad <= frac * err.numel() + 1, "%s: %d of %d elements off by more than %.1e of the scale" % (name, bad, err.numel(), tol)
     bad4 = int((err > 4 * tol * mx + slack).sum())

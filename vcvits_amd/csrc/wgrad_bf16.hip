@@ -423,7 +423,7 @@ bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds, int P
   if (lds > VCV_LDS_LIMIT) return false;
   const int ntask = (BM / 32) + (BC / 32) * (g.XR / 64);
   if (ntask > maxt * NS) return false;
-  if (BU / 16 < c.WU) return false;  // every position-split wave needs a 16-position step
+  if (PL == 3 && BU / 16 < c.WU) return false;  // (32-position stages: every position-split wave needs a 16-position step)
   const long long Uu = (long long)a.Ta * a.P;
   g.nchunk_u = (int)((Uu + BU - 1) / BU);
   return true;
