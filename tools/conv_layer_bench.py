@@ -15,7 +15,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 ap.add_argument("--batch", type=int, default=16)
-ap.add_argument("--split", type=int, default=9, choices=[0, 6, 9],
+ap.add_argument("--split", type=int, default=6, choices=[0, 6, 9],
                 help="fp32 mode: bf16 product terms of the split-operand kernel (0 = fp32-input MFMA kernels)")
 a = ap.parse_args()
 ops.set_compute_dtype(a.dtype)

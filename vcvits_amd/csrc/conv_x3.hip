@@ -107,10 +107,13 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // BfGeom fields as used here: nch = channel groups of 16, a_bytes = one weight slab (3 * 2 * BM * 16), buf_bytes = one
 // span buffer (3 * 2 * xw * 16), JA / phases / ks / vec / ntu / nmt / xw as in conv_pk.hip; BKC = 16, ncg = 1.
-template <int NTERM, int TM, int TN, int WM, int WN, bool LEAKY, int NRING = NRING_DEF>
+// JS: taps per stage (1 or 2).  Two taps double the MFMA work between barriers (the 2 x 1-tile waves of the 128 x 128 tile
+// have only 12 MFMAs per tap) at twice the weight-ring footprint; a group's last stage may hold one tap.
+template <int NTERM, int TM, int TN, int WM, int WN, bool LEAKY, int NRING = NRING_DEF, int JS = 1>
 __global__ void __launch_bounds__(64 * (WM * WN + NPROD))
 conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+  constexpr int TAPB = 3 * 2 * BM * 16;  // bytes of one tap of a weight slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -135,7 +138,8 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
   const int XW = tg.xw;
 
   const int g_begin = (int)((long long)kz * tg.nch / tg.ks), g_end = (int)((long long)(kz + 1) * tg.nch / tg.ks);
-  const int S = (g_end - g_begin) * K;  // stages
+  const int NSG = (K + JS - 1) / JS;      // stages per channel group
+  const int S = (g_end - g_begin) * NSG;  // stages
   char* const Aring = smem;
   char* const Xbuf = smem + NRING * tg.a_bytes;
 
@@ -147,19 +151,25 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
     if (pw == 0) {
       // ---- weight DMA wave: the slab of stage s + NRING - 1 is issued while stage s is multiplied (NRING-slot ring); it
       // passes the barrier of stage s as soon as the slab of stage s + 1 has landed, with later slabs still in flight
-      const char* wtile = wp + ((size_t)r * gridDim.y + mt) * (size_t)tg.nch * JA * tg.a_bytes;
-      constexpr int nA = (3 * 2 * BM * 16) >> 10;  // 1 KiB wave-instructions per slab
-      auto issue = [&](int g, int j, int slot) {
-        const char* slab = wtile + ((size_t)g * JA + j) * tg.a_bytes;
+      const char* wtile = wp + ((size_t)r * gridDim.y + mt) * (size_t)tg.nch * JA * TAPB;
+      constexpr int nT = TAPB >> 10;  // 1 KiB wave-instructions per tap
+      constexpr int nA = JS * nT;     // ... per slab: ALWAYS issued in full, so that the in-flight accounting below holds
+      auto issue = [&](int g, int sj, int slot) {
+        const int j0 = sj * JS;
         char* dst = Aring + slot * tg.a_bytes;
 #pragma unroll
-        for (int i = 0; i < nA; ++i)
-          __builtin_amdgcn_global_load_lds((const void*)(slab + i * 1024 + lane * 16), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+        for (int jj = 0; jj < JS; ++jj) {
+          const int j = j0 + jj < K ? j0 + jj : j0;  // (a group's odd last tap: its partner slot re-loads the same tap, unread)
+          const char* slab = wtile + ((size_t)g * JA + j) * TAPB;
+#pragma unroll
+          for (int i = 0; i < nT; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(slab + i * 1024 + lane * 16), (lds_ptr)(dst + jj * TAPB + i * 1024), 16, 0, 0);
+        }
       };
       int gn = g_begin, jn = 0, issued = 0;
       for (; issued < NRING - 1 && issued < S; ++issued) {
         issue(gn, jn, issued);
-        if (++jn == K) jn = 0, ++gn;
+        if (++jn == NSG) jn = 0, ++gn;
       }
       // (prologue barrier: slab 0 must be there)
       if (issued >= 3) wait_vm<2 * nA>(); else if (issued == 2) wait_vm<nA>(); else wait_vm<0>();
@@ -167,7 +177,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
       for (int s = 0; s < S; ++s) {
         if (issued < S) {
           issue(gn, jn, issued & (NRING - 1));
-          if (++jn == K) jn = 0, ++gn;
+          if (++jn == NSG) jn = 0, ++gn;
           ++issued;
         }
         // slabs <= s + 1 complete; `issued - (s + 2)` later ones may stay in flight
@@ -179,7 +189,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
     }
     // ---- input staging waves.  A task = (half h of the 16-channel group, block of 256 positions): 8 channels x 4
     // consecutive positions per lane.  Wave xi owns tasks xi, xi + 3, ...; local task i of group g + 1 is converted in
-    // stage (g, i mod K), and its loads are issued at the START of the stage before (two register sets), so they have a
+    // stage (g, i mod NSG), and its loads are issued at the START of the stage before (two register sets), so they have a
     // whole stage to arrive.
     const int xi = pw - 1;
     const int npb = (XW + 255) >> 8;
@@ -230,7 +240,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
       if (g + 1 >= g_end) return;
 #pragma unroll
       for (int q = 0; q < MAXT; ++q)
-        if (j + q * K < nt_w) loadT(g + 1, j + q * K, xr[PAR][q]);
+        if (j + q * NSG < nt_w) loadT(g + 1, j + q * NSG, xr[PAR][q]);
     };
     auto store_stage = [&](auto par, int g, int j) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par)::value;
@@ -238,9 +248,9 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
       const int nb = (g + 1 - g_begin) & 1;
 #pragma unroll
       for (int q = 0; q < MAXT; ++q)
-        if (j + q * K < nt_w) storeT(j + q * K, xr[PAR][q], nb);
+        if (j + q * NSG < nt_w) storeT(j + q * NSG, xr[PAR][q], nb);
       // (more tasks per stage than the pipelined slots hold: load and convert on the spot)
-      for (int i = j + MAXT * K; i < nt_w; i += K) {
+      for (int i = j + MAXT * NSG; i < nt_w; i += NSG) {
         loadT(g + 1, i, xr[PAR][0]);
         storeT(i, xr[PAR][0], nb);
       }
@@ -258,7 +268,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
     for (int s = 0; s < S; s += 2) {
       {  // even stage: its tasks sit in set 0; the next stage's loads go to set 1
         int g2 = g, j2 = j + 1;
-        if (j2 == K) j2 = 0, ++g2;
+        if (j2 == NSG) j2 = 0, ++g2;
         if (s + 1 < S) load_stage(P1(), g2, j2);
         store_stage(P0(), g, j);
         g = g2, j = j2;
@@ -266,7 +276,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
       }
       if (s + 1 < S) {  // odd stage
         int g2 = g, j2 = j + 1;
-        if (j2 == K) j2 = 0, ++g2;
+        if (j2 == NSG) j2 = 0, ++g2;
         if (s + 2 < S) load_stage(P0(), g2, j2);
         store_stage(P1(), g, j);
         g = g2, j = j2;
@@ -297,34 +307,41 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
   if (S > 0) {
     __syncthreads();
     const int aoff = (h * BM + wm * TM * 32 + l31) * 16;
-    int g = g_begin, j = 0;
+    int g = g_begin, sj = 0;
     for (int s = 0; s < S; ++s) {
-      const char* As = Aring + (s & (NRING - 1)) * tg.a_bytes + aoff;
-      const char* Xs = Xbuf + ((g - g_begin) & 1) * tg.buf_bytes + j * p.dj * P * 16;
-      bf16x8 a[TM][3], bb[TN][3];
+      const char* As0 = Aring + (s & (NRING - 1)) * tg.a_bytes + aoff;
+      const int j0 = sj * JS;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int jj = 0; jj < JS; ++jj) {
+        if (j0 + jj < K) {
+          const char* As = As0 + jj * TAPB;
+          const char* Xs = Xbuf + ((g - g_begin) & 1) * tg.buf_bytes + (j0 + jj) * p.dj * P * 16;
+          bf16x8 a[TM][3], bb[TN][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          a[tm][pl] = *reinterpret_cast<const bf16x8*>(As + ((size_t)pl * 2 * BM + tm * 32) * 16);
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+            for (int pl = 0; pl < 3; ++pl)
+              a[tm][pl] = *reinterpret_cast<const bf16x8*>(As + ((size_t)pl * 2 * BM + tm * 32) * 16);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          bb[tn][pl] = *reinterpret_cast<const bf16x8*>(Xs + laneoff[tn] + (size_t)pl * 2 * XW * 16);
-      // small terms first
-      if (NTERM == 9) {
-        mma_term<2, 2>(acc, a, bb);
-        mma_term<1, 2>(acc, a, bb);
-        mma_term<2, 1>(acc, a, bb);
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              bb[tn][pl] = *reinterpret_cast<const bf16x8*>(Xs + laneoff[tn] + (size_t)pl * 2 * XW * 16);
+          // small terms first
+          if (NTERM == 9) {
+            mma_term<2, 2>(acc, a, bb);
+            mma_term<1, 2>(acc, a, bb);
+            mma_term<2, 1>(acc, a, bb);
+          }
+          mma_term<0, 2>(acc, a, bb);
+          mma_term<2, 0>(acc, a, bb);
+          mma_term<1, 1>(acc, a, bb);
+          mma_term<0, 1>(acc, a, bb);
+          mma_term<1, 0>(acc, a, bb);
+          mma_term<0, 0>(acc, a, bb);
+        }
       }
-      mma_term<0, 2>(acc, a, bb);
-      mma_term<2, 0>(acc, a, bb);
-      mma_term<1, 1>(acc, a, bb);
-      mma_term<0, 1>(acc, a, bb);
-      mma_term<1, 0>(acc, a, bb);
-      mma_term<0, 0>(acc, a, bb);
-      if (++j == K) j = 0, ++g;
+      if (++sj == NSG) sj = 0, ++g;
       __syncthreads();  // publishes stage s + 1 (LDS writes + the weight DMA) and retires the reads of stage s
     }
   }
@@ -332,7 +349,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
 }
 
 struct Plan {
-  int variant;
+  int variant, js;
   int BM, BN, NW;
   BfGeom g;
   size_t scratch_floats, pack_bytes, lds_bytes;
@@ -347,7 +364,7 @@ bool eligible(const VcvConvArgs& a) {
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);
 }
 
-bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring = NRING_DEF) {
+bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring = NRING_DEF, int js = 1) {
   pl.BM = BM; pl.BN = BN; pl.NW = NW;
   BfGeom& g = pl.g;
   const int qspan = (BN - 1) / a.P + 1;
@@ -361,13 +378,14 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
   g.nch = vcv_cdiv(a.Cg, 16);
   g.ntu = vcv_cdiv(a.Q * a.P, BN);
   g.nmt = vcv_cdiv(a.Mg, BM);
-  g.a_bytes = 3 * 2 * BM * 16;
+  g.a_bytes = js * 3 * 2 * BM * 16;  // the weight slab of a stage (js taps)
+  pl.js = js;
   g.buf_bytes = 3 * 2 * g.xw * 16;
   pl.lds_bytes = (size_t)nring * g.a_bytes + 2ull * g.buf_bytes;
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
   g.vec = 0;
-  pl.pack_bytes = (size_t)g.phases * g.nmt * g.nch * g.JA * g.a_bytes;
+  pl.pack_bytes = (size_t)g.phases * g.nmt * g.nch * g.JA * (3 * 2 * BM * 16);
   pl.scratch_floats = 0;
   return true;
 }
@@ -400,6 +418,12 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     if (make_plan(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
   }
   if (!ok) return false;
+  // two taps per stage where the doubled weight ring fits (128-row tiles, K >= 2): half the barriers per MFMA
+  static const bool no_js2 = getenv("VCVITS_X3_NO_JS2") != nullptr;
+  if (!no_js2 && (pl.variant == 0 || pl.variant == 1) && vcv_cdiv(a.K, nph) >= 2) {
+    Plan p2;
+    if (make_plan(a, pl.BM, pl.BN, pl.NW, p2, NRING_DEF, 2)) { p2.variant = pl.variant; pl = p2; }
+  }
   // too few tiles for 256 CUs: split the channel groups over ks workgroups per tile (deterministic slabs + finishing pass)
   const long long nb = blocks(pl.BM, pl.BN);
   if (nph == 1 && nb < 192 && pl.g.nch >= 4) {
@@ -423,7 +447,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
 int g_all = getenv("VCVITS_X3_ALL") != nullptr ? 1 : 0;
 int g_terms = [] { const char* e = getenv("VCVITS_X3_TERMS"); return e && atoi(e) == 9 ? 9 : 6; }();
 
-template <int NTERM, int TM, int TN, int WM, int WN, int NRING = NRING_DEF>
+template <int NTERM, int TM, int TN, int WM, int WN, int NRING = NRING_DEF, int JS = 1>
 int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip, bool pack_valid, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, NT = 64 * (WM * WN + NPROD);
   const BfGeom& g = pl.g;
@@ -434,7 +458,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip
                        a.K, BM, g.JA, g.nch, g.nmt, g.phases, mode, total);
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const char*, float*) =
-      a.in_tf == VCV_TF_LEAKY ? conv_x3_kernel<NTERM, TM, TN, WM, WN, true, NRING> : conv_x3_kernel<NTERM, TM, TN, WM, WN, false, NRING>;
+      a.in_tf == VCV_TF_LEAKY ? conv_x3_kernel<NTERM, TM, TN, WM, WN, true, NRING, JS> : conv_x3_kernel<NTERM, TM, TN, WM, WN, false, NRING, JS>;
   if (pl.lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes) != hipSuccess)
     return VCV_EHIP;
@@ -459,8 +483,10 @@ int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip
 template <int NTERM>
 int run_n(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip, bool pv, hipStream_t st) {
   switch (pl.variant) {
-    case 0: return launch<NTERM, 2, 2, 2, 4>(a, pl, wp, part, flip, pv, st);
-    case 1: return launch<NTERM, 2, 1, 2, 4>(a, pl, wp, part, flip, pv, st);
+    case 0: return pl.js == 2 ? launch<NTERM, 2, 2, 2, 4, NRING_DEF, 2>(a, pl, wp, part, flip, pv, st)
+                              : launch<NTERM, 2, 2, 2, 4>(a, pl, wp, part, flip, pv, st);
+    case 1: return pl.js == 2 ? launch<NTERM, 2, 1, 2, 4, NRING_DEF, 2>(a, pl, wp, part, flip, pv, st)
+                              : launch<NTERM, 2, 1, 2, 4>(a, pl, wp, part, flip, pv, st);
     case 2: return launch<NTERM, 2, 2, 4, 2, 2>(a, pl, wp, part, flip, pv, st);  // 256 x 128
     case 3: return launch<NTERM, 1, 2, 2, 4>(a, pl, wp, part, flip, pv, st);
     case 4: return launch<NTERM, 1, 1, 2, 4>(a, pl, wp, part, flip, pv, st);
