@@ -396,6 +396,8 @@ int vcv_prof_bytes(double* out, int ncls);
  * PFLOP/s; a split-operand fp32 launch executes 6 or 9 bf16 products per fp32 product).  sum / measured time = the
  * roofline fraction of a class that mixes pipes. */
 int vcv_prof_roof(double* out, int ncls);
+/* sampling inside an open window: while paused != 0 launches carry no events (they run as plain launches) */
+int vcv_prof_pause(int paused);
 /* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */
 int vcv_prof_dump(const char* path);
 

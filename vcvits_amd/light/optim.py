@@ -143,7 +143,7 @@ class FlatAdamW:
         # A parameter one rank used and another did not (a batch-dependent conditioning path) still received the
         # averaged gradient everywhere: every rank must apply the same update, so the "received a gradient" flags are
         # OR-ed across the group (torch DDP reduces its used-parameter bitmap for the same reason).
-        if self.world > 1:
+        if self._ddp:  # (also in a forced 1-rank group, so that the single-GPU RCCL tests run this collective)
             flags = torch.tensor(list(self._touched), dtype=torch.uint8, device=self.grad.device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
             self._touched[:] = bytes(flags.cpu().tolist())
