@@ -59,8 +59,13 @@ class FlatAdamW:
         # the RCCL path on a single-GPU box)
         import os
         self._ddp = self.world > 1 or (os.environ.get("VCVITS_FORCE_DDP") == "1" and dist.is_initialized())
+        self._flag_pg = None
         if self._ddp:
             self._make_buckets(int(bucket_mb * 1024 * 1024 / 4))
+            # the per-parameter "received a gradient" flags are OR-ed across ranks on the HOST (finish_grad_sync): over
+            # RCCL that would be a device round trip -- a host sync in the middle of the step (measured: -5 % on one rank)
+            # -- so GPU groups get a gloo side channel for this 400-byte reduction; CPU (gloo) groups use their own
+            self._flag_pg = dist.new_group(backend="gloo") if dist.get_backend(process_group) == "nccl" else process_group
         # One post-accumulate hook per parameter: marks the parameter as "received a gradient in this pass"
         # (torch.optim.AdamW skips parameters whose .grad is None -- no decay, no moment update, no step count)
         # and, under data parallelism, counts its bucket down.  The handles are kept so a rebuilt optimizer can
@@ -143,10 +148,10 @@ class FlatAdamW:
         # A parameter one rank used and another did not (a batch-dependent conditioning path) still received the
         # averaged gradient everywhere: every rank must apply the same update, so the "received a gradient" flags are
         # OR-ed across the group (torch DDP reduces its used-parameter bitmap for the same reason).
-        if self._ddp:  # (also in a forced 1-rank group, so that the single-GPU RCCL tests run this collective)
-            flags = torch.tensor(list(self._touched), dtype=torch.uint8, device=self.grad.device)
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
-            self._touched[:] = bytes(flags.cpu().tolist())
+        if self._ddp:  # (also in a forced 1-rank group, so that the single-GPU tests run this collective)
+            flags = torch.tensor(list(self._touched), dtype=torch.uint8)  # host tensor, gloo: no device sync
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._flag_pg)
+            self._touched[:] = bytes(flags.tolist())
 
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
