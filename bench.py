@@ -140,6 +140,7 @@ def launch_ranks(a, argv):
     env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
                 "LOCAL_WORLD_SIZE": str(n), "VCVITS_BENCH_CHILD": "1"})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the optimizers' gloo side channel needs no hostname lookup
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     procs = []
     for r in range(n):
@@ -492,6 +493,7 @@ def main(argv=None):
     if world > 1 or os.environ.get("VCVITS_FORCE_DDP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         # training: gradient all-reduce over RCCL; inference: replicas, the group carries the timing barrier only
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != world:

@@ -400,7 +400,11 @@ struct Cfg { int WM, WC, WU, KT; };
 
 bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
   const int BU = PL == 1 ? BU64 : 32;
-  const int NS = PL == 1 ? c.WM * c.WC * c.WU : 4, maxt = PL == 1 ? MAXT : MAXT_WS;  // staging waves, tasks each
+  // producer waves for the bf16 launches too (round 3: 163 -> 176 TFLOP/s in the bf16 step); VCVITS_WGRAD_BF16_NO_WS keeps
+  // every wave staging
+  static const bool ws1 = getenv("VCVITS_WGRAD_BF16_NO_WS") == nullptr;
+  const bool ws = PL == 3 || ws1;
+  const int NS = ws ? 4 : c.WM * c.WC * c.WU, maxt = ws ? MAXT_WS : MAXT;  // staging waves, tasks each
   const int BM = 32 * c.WM, BC = 32 * c.WC, NW = c.WM * c.WC * c.WU;
   g.nmt = vcv_cdiv(a.Mg, BM);
   g.nct = vcv_cdiv(a.Cg, BC);
@@ -447,11 +451,12 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   }
   g.Z = (int)Z;
   void (*kern)(const VcvWgradArgs, const WbGeom, float*);
-  if constexpr (NT == 1) kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT, NT>;
+  static const bool ws1 = getenv("VCVITS_WGRAD_BF16_NO_WS") == nullptr;
+  if constexpr (NT == 1) kern = ws1 ? wgrad_bf16_kernel<WM, WC, WU, KT, MAXT_WS, NT, 4, BU64> : wgrad_bf16_kernel<WM, WC, WU, KT, MAXT, NT>;
   else kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT_WS, NT, 4, 32>;  // 4 producer waves, 32-position stages
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VCV_EHIP;
-  dim3 grid(g.nct * g.ntg, g.nmt, g.Z), block(64 * (WM * WC * WU + (NT == 1 ? 0 : 4)));
+  dim3 grid(g.nct * g.ntg, g.nmt, g.Z), block(64 * (WM * WC * WU + ((NT == 1 && !ws1) ? 0 : 4)));
   const double flops = 2.0 * a.B * a.Mg * a.Cg * a.K * a.P * (double)a.Ta;
   const int tag[12] = {a.B, NT == 1 ? 2 : 3, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, g.Z, 2, WM * 32 * 1000 + WC * 32, NT * 100 + KT};
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
