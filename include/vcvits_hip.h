@@ -132,6 +132,21 @@ int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws
  * 9 = all products.
  * vcv_conv_x3_set_all(1): take every eligible launch; 0 (default): only the shapes where the split kernel is the faster one.
  */
+/* Batched weight packs (conv_pack.hip): the layout of the pack a launch (args, flip) reads, as a job; vcv_pack_many packs
+ * any number of jobs (w = the weights, wp = a buffer of the size the matching *_plan returned) in ONE launch.  The host
+ * records the jobs of a module tree once and replays them whenever the tree's weights were re-normalised. */
+typedef struct VcvPackJob {
+  const float* w;   /* weights ([M, C, K], or [C, M, K] for mode 1 / 2) */
+  void* wp;         /* packed buffer */
+  int32_t kind;     /* 0: vcv_conv_x3_*, 1: vcv_conv_pk_*, 2: vcv_conv_bf16_* */
+  int32_t M, C, K, BM, BKC, JA, nch, nmt, phases, mode, reserved;
+  int64_t total;    /* pack threads */
+  int64_t block0;   /* (filled by vcv_pack_many) */
+} VcvPackJob;
+int vcv_conv_x3_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
+int vcv_conv_pk_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
+int vcv_conv_bf16_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
+int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* stream);
 int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out);
 int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream);
 int vcv_conv_x3_set_terms(int n);

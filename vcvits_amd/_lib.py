@@ -35,6 +35,13 @@ class VcvConvArgs(ctypes.Structure):
     ]
 
 
+class VcvPackJob(ctypes.Structure):
+    """mirrors include/vcvits_hip.h"""
+    _fields_ = [("w", ctypes.c_void_p), ("wp", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("kind", "M", "C", "K", "BM", "BKC", "JA", "nch", "nmt", "phases", "mode", "reserved")] + \
+               [("total", ctypes.c_int64), ("block0", ctypes.c_int64)]
+
+
 class VcvWgradArgs(ctypes.Structure):
     _fields_ = [
         ("a", _f32p), ("b", _f32p), ("aaux", _f32p), ("baux", _f32p), ("dw", _f32p),
@@ -85,7 +92,7 @@ EXPORTS = [
     "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_conv_c1_fwd", "vcv_conv_c1_dgrad", "vcv_linear_t1_fwd", "vcv_linear_t1_dgrad", "vcv_linear_t1_wgrad", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
     "vcv_act_grad", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_loss_many_sum", "vcv_loss_many_grad", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_dgrad", "vcv_grouped41_wgrad",
     "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16", "vcv_act_grad_bias", "vcv_conv_pk_plan", "vcv_conv_pk_run",
-    "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause",
+    "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause", "vcv_conv_x3_pack_job", "vcv_conv_pk_pack_job", "vcv_conv_bf16_pack_job", "vcv_pack_many",
 ]
 
 
@@ -176,6 +183,10 @@ _ARGTYPES = {
     "vcv_prof_bytes": [ctypes.POINTER(ctypes.c_double), _I],
     "vcv_prof_roof": [ctypes.POINTER(ctypes.c_double), _I],
     "vcv_prof_pause": [_I],
+    "vcv_conv_x3_pack_job": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(VcvPackJob)],
+    "vcv_conv_pk_pack_job": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(VcvPackJob)],
+    "vcv_conv_bf16_pack_job": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(VcvPackJob)],
+    "vcv_pack_many": [ctypes.POINTER(VcvPackJob), _I, _P, _P],
 }
 
 

@@ -545,7 +545,24 @@ int run_t(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, 
   }
 }
 
+template <class EL>
+int pack_job_t(const VcvConvArgs* args, int flip, VcvPackJob* out) {
+  if (!args || !out || !eligible(*args) || !wanted<EL>(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose<EL>(*args, pl)) return VCV_EINVAL;
+  const BfGeom& g = pl.g;
+  out->kind = EL::ESZ == 2 ? 2 : 1;
+  out->M = args->Mg, out->C = args->Cg, out->K = args->K;
+  out->BM = pl.BM, out->BKC = g.BKC, out->JA = g.JA, out->nch = g.nch, out->nmt = g.nmt, out->phases = g.phases;
+  out->mode = g.phases > 1 ? 2 : (flip ? 1 : 0);
+  out->total = (int64_t)(pl.pack_bytes / 16);
+  return VCV_OK;
+}
+
 }  // namespace
+
+extern "C" int vcv_conv_pk_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out) { return pack_job_t<F32El>(args, flip, out); }
+extern "C" int vcv_conv_bf16_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out) { return pack_job_t<Bf16El>(args, flip, out); }
 
 // Same calling convention as vcv_conv_dma_plan / vcv_conv_dma_run (include/vcvits_hip.h): out[0] = BYTES / 4 of the
 // packed-weight buffer (so callers allocate it as out[0] fp32 words), out[1] = floats of per-launch scratch, out[2] =

@@ -532,6 +532,19 @@ extern "C" int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out)
   return 0;
 }
 
+extern "C" int vcv_conv_x3_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out) {
+  if (!args || !out || !eligible(*args) || !wanted(*args)) return VCV_EINVAL;
+  Plan pl;
+  if (!choose(*args, pl)) return VCV_EINVAL;
+  const BfGeom& g = pl.g;
+  out->kind = 0;
+  out->M = args->Mg, out->C = args->Cg, out->K = args->K;
+  out->BM = pl.BM, out->BKC = 16, out->JA = g.JA, out->nch = g.nch, out->nmt = g.nmt, out->phases = g.phases;
+  out->mode = g.phases > 1 ? 2 : (flip ? 1 : 0);
+  out->total = (int64_t)g.phases * g.nmt * g.nch * g.JA * 2 * pl.BM;
+  return VCV_OK;
+}
+
 extern "C" int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream) {
   if (!args || !pack_ws || !eligible(*args) || !wanted(*args)) return VCV_EINVAL;
   Plan pl;

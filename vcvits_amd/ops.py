@@ -109,7 +109,8 @@ def _launch_conv(a, flip_w=None):
             if plan_fn(ctypes.byref(a), flip, plan) != 0:
                 continue
             dev = torch.device("cuda", torch.cuda.current_device())
-            packs = _stable_packs(a.w)
+            ent = _stable_entry(a.w)
+            packs = ent["packs"] if ent is not None else None
             key = (a.w, plan[0], plan[2])
             pack = packs.get(key) if packs is not None else None
             valid = 1 if pack is not None else 0
@@ -117,6 +118,12 @@ def _launch_conv(a, flip_w=None):
                 pack = torch.empty((plan[0],), device=dev, dtype=torch.float32)
                 if packs is not None:
                     packs[key] = pack
+                    # remember the job: the next time this tree's weights are re-normalised all of its packs are made
+                    # in one launch (_replay_packs)
+                    if len(_PACK_JOBS) > 64:
+                        _PACK_JOBS.clear()
+                    _PACK_JOBS.setdefault(ent["key"], {})[(a.w - ent["lo"], int(plan[0]), int(plan[2]), name)] = \
+                        (bytes(a), flip)
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
             check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
             LAUNCH_COUNTS[{"vcv_conv_bf16_run": "bf16", "vcv_conv_x3_run": "x3", "vcv_conv_pk_run": "pk"}.get(name, "dma")] += 1
@@ -808,14 +815,65 @@ def invalidate_weights(lo=None, hi=None):
         del _WN_CACHE[k]
 
 
-def _stable_packs(w_ptr):
-    """The pack cache of the cached weight-norm buffer that contains address w_ptr, if any."""
+def _stable_entry(w_ptr):
+    """The cached weight-norm buffer (its cache entry) that contains address w_ptr, if any."""
     if w_ptr is None:
         return None
     for e in _WN_CACHE.values():
         if e["lo"] <= w_ptr < e["hi"]:
-            return e["packs"]
+            return e
     return None
+
+
+def _stable_packs(w_ptr):
+    """The pack cache of the cached weight-norm buffer that contains address w_ptr, if any."""
+    e = _stable_entry(w_ptr)
+    return e["packs"] if e is not None else None
+
+
+# Packed-weight jobs per parameter set: {wn key: {(offset of w in the buffer, pack words, layout signature, family): (launch
+# arguments, flip)}} -- recorded when a launch had to pack (_launch_conv), replayed in ONE launch when the set is
+# re-normalised (vcv_pack_many): 180-270 pack launches per step otherwise.
+_PACK_JOBS = {}
+_PACK_BATCH = [__import__("os").environ.get("VCVITS_PACK_BATCH", "1") == "1"]
+_PACK_FILL = {"vcv_conv_x3_run": "vcv_conv_x3_pack_job", "vcv_conv_pk_run": "vcv_conv_pk_pack_job",
+              "vcv_conv_bf16_run": "vcv_conv_bf16_pack_job"}
+
+
+def _replay_packs(key, ent):
+    """Make every recorded pack of parameter set `key` for its freshly normalised weights `ent` (one launch)."""
+    jobs = _PACK_JOBS.get(key)
+    if not jobs or not _PACK_BATCH[0]:
+        return
+    from ._lib import VcvPackJob
+    L = lib()
+    todo = [(k, v) for k, v in jobs.items() if k[3] in _PACK_FILL]
+    if not todo:
+        return
+    arr = (VcvPackJob * len(todo))()
+    total = sum(k[1] for k, _ in todo)
+    dev = ent["wbuf"].device
+    arena = torch.empty((total + 32 * len(todo),), device=dev, dtype=torch.float32)
+    n = off = 0
+    reg = []
+    for (woff, words, sig, fam), (abytes, flip) in todo:
+        a = VcvConvArgs.from_buffer_copy(abytes)
+        a.w = ent["lo"] + woff
+        if getattr(L, _PACK_FILL[fam])(ctypes.byref(a), flip, ctypes.byref(arr[n])) != 0:
+            continue  # (the plan no longer takes this launch, e.g. a mode switch: it will pack lazily)
+        view = arena[off:off + words]
+        arr[n].w, arr[n].wp = a.w, view.data_ptr()
+        reg.append(((a.w, words, sig), view))
+        off += (words + 31) & ~31  # 128-byte aligned slices
+        n += 1
+    if n == 0:
+        return
+    table = torch.empty((n * ctypes.sizeof(VcvPackJob) // 4 + 8,), device=dev, dtype=torch.float32)
+    check(L.vcv_pack_many(arr, n, ptr(table), stream()), "vcv_pack_many")
+    ent["pack_table"] = table  # (kept alive with the entry)
+    for k, view in reg:
+        ent["packs"][k] = view
+    LAUNCH_COUNTS["pack_many"] = LAUNCH_COUNTS.get("pack_many", 0) + 1
 
 
 class _WnHolder:
@@ -861,8 +919,10 @@ def _wn_forward_all(vg, n):
             if len(_WN_CACHE) > 64:
                 _WN_CACHE.clear()
             import weakref
-            _WN_CACHE[key] = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
-                                  lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={})
+            ent = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
+                       lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={}, key=key)
+            _WN_CACHE[key] = ent
+            _replay_packs(key, ent)
     h = _WnHolder()
     h.wbuf, h.norm, h.tab, h.total, h.rows = wbuf, norm, tab, total, rows
     return h
