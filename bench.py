@@ -319,13 +319,15 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     sync()
     if prof:
         _lib.check(L.vcv_prof_begin(8192 * max(steps, 1)), "vcv_prof_begin")
-    # per-launch events on every other step of the timed region (steps 0, 2, ...): they cost ~4 % of a step, so sampling
-    # half of them halves what the measurement takes from the measured value; the roofline figures are per profiled step
-    psteps = (steps + 1) // 2 if prof else 0
+    # per-launch events on every fourth step of the timed region (steps 0, 4, ...): dispatch-attached events cost ~4 % of
+    # a step (consecutive kernels no longer overlap their launch latencies), so the measurement samples instead of taking
+    # that from the measured value; the roofline figures are per profiled step (383 launches of the dominant class each)
+    PEVERY = 4
+    psteps = (steps + PEVERY - 1) // PEVERY if prof else 0
     t0 = time.perf_counter()
     for i in range(steps):
         if prof:
-            L.vcv_prof_pause(i & 1)
+            L.vcv_prof_pause(0 if i % PEVERY == 0 else 1)
         run()
     sync()
     dt = time.perf_counter() - t0
@@ -376,7 +378,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                     "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                     "gflop_per_launch": dom["gflop_per_launch"], "share_of_step_time": dom["share_of_step_time"],
-                    "profiled_steps": "%d of the %d timed steps (every other one)" % (psteps, steps),
+                    "profiled_steps": "%d of the %d timed steps (every fourth)" % (psteps, steps),
                     "kernel_source_hash": kernel_source_hash(),
                     "other_kernels": [c for c in fams if c is not dom]}
     periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
