@@ -102,7 +102,7 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
     llvm = "/opt/rocm/lib/llvm/bin"
     if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
         pytest.skip("no ROCm LLVM tools")
-    for name in ("conv_pk", "wgrad_dma"):
+    for name in ("conv_pk", "wgrad_dma", "conv_x3", "wgrad_bf16"):
         obj = os.path.join(build_ext.CSRC, name + ".o")
         fat, co = str(tmp_path / (name + ".fat")), str(tmp_path / (name + ".co"))
         subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
@@ -111,5 +111,5 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
                                text=True).stdout
         sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
-        assert len(sizes) > 20, "no kernel metadata found in %s" % obj
+        assert len(sizes) > 10, "no kernel metadata found in %s" % obj
         assert max(sizes) == 0, "%s: a kernel uses %d bytes of scratch per lane" % (name, max(sizes))
