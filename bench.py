@@ -370,6 +370,8 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
                                                            "%s/%s/%s" % (config, workload, dtype))
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
                     "unit": "TFLOP/s", "frac": dom["frac"],
+                    # for reference only: the same achieved rate against the dtype's own MFMA peak (fp32-input MFMA 157.3)
+                    "frac_vs_dtype_mfma_peak": round(dom["achieved"] / peak, 4),
                     "peak_note": "algorithmic TFLOP/s at the dense MFMA peak of the pipe each launch of the class runs on "
                                  "(fp32-input MFMA 157.3; bf16 MFMA 2500, / 6 or / 9 for split-operand fp32 launches); "
                                  "random-data bf16 MFMA loops sustain ~1250 of the 2500 on this chip (clock give-back, "
