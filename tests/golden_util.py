@@ -66,7 +66,7 @@ def record_stats(kind, name, **kv):
             f.write("%s %s %s\n" % (kind, name, " ".join("%s=%.4g" % (k, v) for k, v in kv.items())))
 
 
-def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.005, frac4=0.003, cap=0.05, floor=0.0):
+def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.01, frac4=0.005, cap=0.05, floor=0.0):
     """Comparison for gradients that passed through (leaky-)ReLU layers at full size.
 
     A pre-activation within fp32 rounding of zero can land on different sides of the kink on the two machines; that
@@ -80,8 +80,9 @@ def close_kinked(name, a, b, tol=3e-4, tol_l2=5e-3, frac=0.005, frac4=0.003, cap
     a visible share of the tensor -- up to 1.55 % beyond tol and 0.45 % beyond 4 tol, worst element 0.46 %; small tensors:
     worst element 1.1 % of the scale):
       * relative L2 error of the tensor <= tol_l2 (5e-3),
-      * all but `frac` (0.5 %; 3 % under 65536 elements) of the elements within tol * max|b| (+ floor) and all but `frac4`
-        (0.3 %; 1 %) within 4 tol * max|b|; tensors under 4096 elements (bias sums, which collect a little of EVERY
+      * all but `frac` (1 %: the 0.64 % above with 1.5x margin -- which flips occur depends on the kernels' summation
+        order, and the driver runs this suite with `-x`; 3 % under 65536 elements) of the elements within tol * max|b|
+        (+ floor) and all but `frac4` (0.5 %; 1 %) within 4 tol * max|b|; tensors under 4096 elements (bias sums, which collect a little of EVERY
         flip) are held to 10 tol * max|b| instead, two elements excepted,
       * no element further than `cap` (5 %) of max|b| (+ floor) away: a wrong edge tile -- a few percent of a tensor off
         by the size of the values -- fails this and the L2 bound.
