@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvcvits_hip.so")
+LIB_PATH = os.environ.get("VCVITS_HIP_LIB") or os.path.join(_HERE, "csrc", "libvcvits_hip.so")  # (env: A/B builds)
 
 VCV_OK = 0
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 2, 3, 4
