@@ -32,17 +32,24 @@ for name, B, H, dk, T in (("base B16", 16, 4, 64, 204), ("base B32", 32, 4, 64, 
         o, _ = ops.rel_attention(q, k, v, ek, ev, mask, H, 4, 0.1, training=True, want_attn=False)
         o.backward(gy)
 
+    import ctypes
+    from vcvits_amd import _lib
+    LIB = _lib.lib()
     res = []
     for f, mult in ((fwd, 1.0), (fb, 3.0)):
         for _ in range(3):
             f()
         torch.cuda.synchronize()
+        LIB.vcv_prof_begin(8 * a.reps + 8)
         t0 = time.perf_counter()
         for _ in range(a.reps):
             f()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.reps
+        out = (ctypes.c_double * 15)()
+        LIB.vcv_prof_end(out, 5)
+        kern = (out[1] + out[13]) / a.reps * 1e-3 if (out[0] + out[12]) > 0 else float("nan")  # GPU time of the GEMM-shaped launches
         flops = mult * 4.0 * B * H * T * T * dk
-        res.append((dt * 1e6, flops / dt / 1e12))
-    print("%-10s B=%d H=%d dk=%d T=%d | fwd %7.1f us %6.1f TFLOP/s | fwd+bwd %7.1f us %6.1f TFLOP/s" % (
-        name, B, H, dk, T, res[0][0], res[0][1], res[1][0], res[1][1]))
+        res.append((dt * 1e6, flops / dt / 1e12, kern * 1e6, flops / kern / 1e12))
+    print("%-10s B=%d H=%d dk=%d T=%d | fwd %7.1f us wall, %7.1f us in the kernels: %6.1f TFLOP/s | fwd+bwd %7.1f us wall, %7.1f us in the kernels: %6.1f TFLOP/s" % (
+        name, B, H, dk, T, res[0][0], res[0][2], res[0][3], res[1][0], res[1][2], res[1][3]))

@@ -73,6 +73,26 @@ template <> struct Op<true> {
   static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
+// A row-major fp32 matrix [rows][ld] read through a range-checked buffer descriptor: rows past the end fall outside the
+// descriptor and read 0, columns past `cols` are sent out of range by a select -- no branch per load (the first version's
+// `cond ? ptr[...] : 0.f` compiled to a branch around every one of a fragment's 32 loads: 28 of the forward kernel's 54 us)
+struct Mat {
+  __amdgpu_buffer_rsrc_t rs;
+  int ld, cols;
+};
+__device__ __forceinline__ Mat mat(const float* p, int rows, int ld, int cols) {
+  Mat m;
+  m.rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, rows * ld * 4, 0x00020000);
+  m.ld = ld, m.cols = cols;
+  return m;
+}
+__device__ __forceinline__ float ldm(const Mat& m, int r, int c) {
+  const unsigned off = c < m.cols ? (unsigned)(r * m.ld + c) * 4u : 0x80000000u;
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(m.rs, off, 0, 0));
+}
+
+constexpr int NWV = 8;     // waves per workgroup
+constexpr int NTH = 64 * NWV;
 constexpr int RELP = 16;   // relative positions held per row (2w + 1 <= 16)
 constexpr int OP = 33;     // pitch of the partial-output tiles
 
@@ -80,7 +100,7 @@ constexpr int OP = 33;     // pitch of the partial-output tiles
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
 // T1[32][TP] = alpha * A^T B for the 32 rows i0.. of A: T1[m][j] = alpha * sum_d A[d][i0 + m] * Bm[d][j]  (phase 1 of the
-// forward and of the backward row pass).  Key tiles are dealt to the 4 waves.
+// forward and of the backward row pass).  Key tiles are dealt to the NWV waves.
 template <bool BF>
 __device__ __forceinline__ void rows_times_keys(const float* __restrict__ A, const float* __restrict__ Bm, float* T1, int i0, int T,
                                                 int dk, int TP, float alpha, int wave, int lane) {
@@ -90,20 +110,21 @@ __device__ __forceinline__ void rows_times_keys(const float* __restrict__ A, con
   const int nks = (dk + O::KS - 1) / O::KS;
   typename O::frag fa[MAXS];
   const int i = i0 + l31;
+  const Mat mA = mat(A, dk, T, T), mB = mat(Bm, dk, T, T);
 #pragma unroll
   for (int s = 0; s < MAXS; ++s)
-    if (s < nks) fa[s] = O::make(s, h, [&](int d) { return (d < dk && i < T) ? A[(size_t)d * T + i] : 0.f; });
+    if (s < nks) fa[s] = O::make(s, h, [&](int d) { return ldm(mA, d, i); });
   const int nkt = (T + 31) >> 5;
   typename O::frag fb[MAXS], fn[MAXS];
   auto loadB = [&](typename O::frag (&f)[MAXS], int jt) __attribute__((always_inline)) {
     const int j = jt * 32 + l31;
 #pragma unroll
     for (int s = 0; s < MAXS; ++s)
-      if (s < nks) f[s] = O::make(s, h, [&](int d) { return (d < dk && j < T) ? Bm[(size_t)d * T + j] : 0.f; });
+      if (s < nks) f[s] = O::make(s, h, [&](int d) { return ldm(mB, d, j); });
   };
   if (wave < nkt) loadB(fb, wave);
-  for (int jt = wave; jt < nkt; jt += 4) {
-    if (jt + 4 < nkt) loadB(fn, jt + 4);  // the next tile's loads fly under this tile's MFMAs
+  for (int jt = wave; jt < nkt; jt += NWV) {
+    if (jt + NWV < nkt) loadB(fn, jt + NWV);  // the next tile's loads fly under this tile's MFMAs
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -119,19 +140,20 @@ __device__ __forceinline__ void rows_times_keys(const float* __restrict__ A, con
 
 constexpr int CK = 128;       // reduction elements of the row-strided operand staged per chunk
 constexpr int CKP = CK + 2;   // LDS pitch = 2 mod 64: the 64 lanes of a fragment read hit 64 banks
+constexpr int RPP = NTH / CK;  // rows of a chunk staged per pass of the workgroup
+constexpr int NRS = 64 / RPP;  // staging registers per thread and chunk
+constexpr int BSF = (64 * CKP > NWV * 32 * 33) ? 64 * CKP : NWV * 32 * 33;  // floats of the chunk / partial-tile region
 
 // A chunk of the row-strided operand, Bs[d][0 .. CK) = Bm[d][c0 .. c0 + CK) (zero past T / past the dk rows), in two
 // halves so that the loads of chunk c + 1 fly under the MFMAs of chunk c: coalesced global reads along the row into
-// registers (NR = rows / 2 loads per thread, all in flight at once), then the LDS writes.
+// registers (NR = 64 / RPP loads per thread, all in flight at once), then the LDS writes.
 template <int NR>
 __device__ __forceinline__ void load_rows(const float* __restrict__ Bm, float (&v)[NR], int c0, int T, int dk, int tid) {
-  const int jj = tid & (CK - 1), dbase = tid >> 7;  // 256 threads = 2 rows x 128 columns per pass
+  const int jj = tid & (CK - 1), dbase = tid >> 7;  // NTH threads = RPP rows x 128 columns per pass
   const int j = c0 + jj;
+  const Mat mB = mat(Bm, dk, T, T);
 #pragma unroll
-  for (int u = 0; u < NR; ++u) {
-    const int d = 2 * u + dbase;
-    v[u] = (d < dk && j < T) ? Bm[(size_t)d * T + j] : 0.f;
-  }
+  for (int u = 0; u < NR; ++u) v[u] = ldm(mB, RPP * u + dbase, j);
 }
 template <int NR>
 __device__ __forceinline__ void store_rows(float* Bs, const float (&v)[NR], int dk, int tid) {
@@ -139,13 +161,13 @@ __device__ __forceinline__ void store_rows(float* Bs, const float (&v)[NR], int 
   const int rows = (dk + 31) & ~31;
 #pragma unroll
   for (int u = 0; u < NR; ++u)
-    if (2 * u + dbase < rows) Bs[(2 * u + dbase) * CKP + jj] = v[u];
+    if (RPP * u + dbase < rows) Bs[(RPP * u + dbase) * CKP + jj] = v[u];
 }
 
 // out[d][i0 + m] = alpha * (sum_j T1[m][j] * Bm[d][j] + sum_r T1[m][i0 + m + r - w] * emb[r][d])  (phase 3 of the forward:
 // P V^T + relative values; of the backward row pass: dS K^T + relative keys).  Bm is row-strided for the MFMA's lanes
 // (lane = channel d), so it goes through LDS in chunks of CK keys (`bs`: 64 * CKP floats; `red` may alias it).  The
-// dk / 32 column tiles and the steps of a chunk are dealt to the 4 waves; partial tiles meet in `red`.
+// dk / 32 column tiles and the steps of a chunk are dealt to the NWV waves; partial tiles meet in `red`.
 template <bool BF>
 __device__ __forceinline__ void tile_times_rows(const float* T1, const float* __restrict__ Bm, const float* __restrict__ emb,
                                                 float* __restrict__ out, float* bs, float* red, int i0, int T, int dk, int TP, int w,
@@ -153,15 +175,15 @@ __device__ __forceinline__ void tile_times_rows(const float* T1, const float* __
   typedef Op<BF> O;
   const int l31 = lane & 31, h = lane >> 5;
   const int nt = (dk + 31) >> 5;         // column tiles (1 or 2)
-  const int wpt = nt == 1 ? 4 : 2;       // waves per column tile
-  const int tile = nt == 1 ? 0 : (wave & 1), kp = nt == 1 ? wave : (wave >> 1);
+  const int wpt = NWV / nt;              // waves per column tile
+  const int tile = wave % nt, kp = wave / nt;
   const int d = tile * 32 + l31;
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const float* Trow = T1 + l31 * TP;
   const float* Brow = bs + d * CKP;
-  float stg[32];
+  float stg[NRS];
   load_rows(Bm, stg, 0, T, dk, tid);
   for (int c0 = 0; c0 < T; c0 += CK) {
     __syncthreads();  // the previous chunk's fragment reads are done
@@ -180,13 +202,13 @@ __device__ __forceinline__ void tile_times_rows(const float* T1, const float* __
   for (int e = 0; e < 16; ++e) red[(wave * 32 + acc_row(e, h)) * OP + l31] = acc[e];
   __syncthreads();
   const int nr = 2 * w + 1;
-  for (int idx = tid; idx < 32 * dk; idx += 256) {
+  for (int idx = tid; idx < 32 * dk; idx += NTH) {
     const int m = idx & 31, dd = idx >> 5;
     const int i = i0 + m;
     if (i >= T) continue;
     const int tl = dd >> 5, n = dd & 31;
     float s = 0.f;
-    for (int k2 = 0; k2 < wpt; ++k2) s += red[((nt == 1 ? k2 : k2 * 2 + tl) * 32 + m) * OP + n];
+    for (int k2 = 0; k2 < wpt; ++k2) s += red[((k2 * nt + tl) * 32 + m) * OP + n];
     for (int r = 0; r < nr; ++r) {
       const int j = i + r - w;
       if (j >= 0 && j < T) s += T1[m * TP + j] * emb[r * dk + dd];
@@ -201,19 +223,18 @@ constexpr int QP = 33;  // pitch of the staged 32-position operand tile
 // loads, all in flight at once), `es` [nr][dk] the table; then one thread per (m, r)
 __device__ __forceinline__ void band_dots(const float* __restrict__ A, const float* __restrict__ emb, float* rel, float* at, float* es,
                                           int i0, int T, int dk, int nr, float alpha, int tid) {
-  const int m = tid & 31, dq = tid >> 5;  // 8 channel rows per pass
-  float v[8];
+  constexpr int RP = NTH / 32, NU = 64 / RP;  // channel rows per pass, passes
+  const int m = tid & 31, dq = tid >> 5;
+  float v[NU];
+  const Mat mA = mat(A, dk, T, T);
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int d = dq + 8 * u;
-    v[u] = (d < dk && i0 + m < T) ? A[(size_t)d * T + i0 + m] : 0.f;
-  }
+  for (int u = 0; u < NU; ++u) v[u] = ldm(mA, dq + RP * u, i0 + m);
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (dq + 8 * u < dk) at[(dq + 8 * u) * QP + m] = v[u];
-  for (int idx = tid; idx < nr * dk; idx += 256) es[idx] = emb[idx];
+  for (int u = 0; u < NU; ++u)
+    if (dq + RP * u < dk) at[(dq + RP * u) * QP + m] = v[u];
+  for (int idx = tid; idx < nr * dk; idx += NTH) es[idx] = emb[idx];
   __syncthreads();
-  for (int r = dq; r < nr; r += 8) {
+  for (int r = dq; r < nr; r += RP) {
     float s = 0.f;
     for (int d = 0; d < dk; ++d) s += at[d * QP + m] * es[r * dk + d];
     rel[m * RELP + r] = s * alpha;
@@ -221,7 +242,7 @@ __device__ __forceinline__ void band_dots(const float* __restrict__ A, const flo
 }
 
 template <bool BF>
-__global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
+__global__ void __launch_bounds__(NTH) rel_attn_fwd_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = p.T, dk = p.dk, TP = p.TP, nr = 2 * p.w + 1;
   float* S = sm;
@@ -236,16 +257,16 @@ __global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
   const float* kg = p.k + (size_t)g * dk * T;
   const float* vg = p.v + (size_t)g * dk * T;
   const float* mrow = msk;
-  for (int j = tid; j < T; j += 256) msk[j] = p.mask[(size_t)b * T + j];
-  for (int idx = tid; idx < nr * dk; idx += 256) etab[idx] = p.embv[idx];
+  for (int j = tid; j < T; j += NTH) msk[j] = p.mask[(size_t)b * T + j];
+  for (int idx = tid; idx < nr * dk; idx += NTH) etab[idx] = p.embv[idx];
 
   band_dots(qg, p.embk, rel, bs, bs + 64 * QP, i0, T, dk, nr, p.qscale, tid);
   rows_times_keys<BF>(qg, kg, S, i0, T, dk, TP, p.qscale, wave, lane);
   __syncthreads();
-  // softmax of the wave's 8 rows
+  // softmax of the wave's 32 / NWV rows
   const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
-  for (int rr = 0; rr < 8; ++rr) {
-    const int m = wave * 8 + rr, i = i0 + m;
+  for (int rr = 0; rr < 32 / NWV; ++rr) {
+    const int m = wave * (32 / NWV) + rr, i = i0 + m;
     float* Sr = S + m * TP;
     if (i >= T) {
       for (int j = lane; j < TP; j += 64) Sr[j] = 0.f;
@@ -289,7 +310,7 @@ __global__ void __launch_bounds__(256) rel_attn_fwd_kernel(const AttnArgs p) {
 // Backward, row pass: per (head, 32 query rows): dPd = dO^T V + band, dS = Pd * dPd - P * sum_j(Pd * dPd) (zero where
 // masked), dS -> HBM, dQ = qscale * (dS K^T + band), and this tile's share of the two relative-position table gradients.
 template <bool BF>
-__global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p) {
+__global__ void __launch_bounds__(NTH) rel_attn_bwd_rows_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = p.T, dk = p.dk, TP = p.TP, nr = 2 * p.w + 1;
   float* D = sm;
@@ -305,14 +326,14 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p
   const float* og = p.dO + (size_t)g * dk * T;
   const float* mrow = msk;
   const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
-  for (int j = tid; j < T; j += 256) msk[j] = p.mask[(size_t)b * T + j];
-  for (int idx = tid; idx < nr * dk; idx += 256) etab[idx] = p.embk[idx];
+  for (int j = tid; j < T; j += NTH) msk[j] = p.mask[(size_t)b * T + j];
+  for (int idx = tid; idx < nr * dk; idx += NTH) etab[idx] = p.embk[idx];
 
   band_dots(og, p.embv, rel, bs, bs + 64 * QP, i0, T, dk, nr, 1.f, tid);
   rows_times_keys<BF>(og, vg, D, i0, T, dk, TP, 1.f, wave, lane);
   __syncthreads();
-  for (int rr = 0; rr < 8; ++rr) {
-    const int m = wave * 8 + rr, i = i0 + m;
+  for (int rr = 0; rr < 32 / NWV; ++rr) {
+    const int m = wave * (32 / NWV) + rr, i = i0 + m;
     float* Dr = D + m * TP;
     if (i >= T) {
       for (int j = lane; j < TP; j += 64) Dr[j] = 0.f;
@@ -345,7 +366,7 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p
   }
   __syncthreads();
   // table gradients of this row tile: dembk[r][d] += qscale * sum_i dS[i][i+r-w] q[d][i];  dembv[r][d] += sum_i Pd[i][i+r-w] dO[d][i]
-  for (int idx = tid; idx < nr * dk; idx += 256) {
+  for (int idx = tid; idx < nr * dk; idx += NTH) {
     const int r = idx / dk, d = idx - r * dk;
     float ek = 0.f, ev = 0.f;
     for (int m = 0; m < 32; ++m) {
@@ -365,13 +386,13 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_rows_kernel(const AttnArgs p
 
 // Backward, column pass: per (head, 32 keys): dV[d][j] = sum_i Pd[i][j] dO[d][i], dK[d][j] = qscale * sum_i dS[i][j] q[d][i].
 template <bool BF>
-__global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p) {
+__global__ void __launch_bounds__(NTH) rel_attn_bwd_cols_kernel(const AttnArgs p) {
   typedef Op<BF> O;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* os = sm;               // dO chunk [64][CKP]
-  float* qs = sm + 64 * CKP;    // q chunk
-  float* red0 = sm;             // the partial tiles reuse the chunk buffers (4 * 32 * OP floats each)
-  float* red1 = sm + 64 * CKP;
+  float* qs = sm + BSF;         // q chunk
+  float* red0 = sm;             // the partial tiles reuse the chunk buffers (NWV * 32 * OP floats each)
+  float* red1 = sm + BSF;
   const int T = p.T, dk = p.dk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int g = blockIdx.y, j0 = blockIdx.x * 32;
@@ -379,15 +400,16 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p
   const float* og = p.dO + (size_t)g * dk * T;
   const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
   const int nt = (dk + 31) >> 5;
-  const int wpt = nt == 1 ? 4 : 2;
-  const int tile = nt == 1 ? 0 : (wave & 1), kp = nt == 1 ? wave : (wave >> 1);
+  const int wpt = NWV / nt;
+  const int tile = wave % nt, kp = wave / nt;
   const int d = tile * 32 + l31, j = j0 + l31;
   const float* orow = os + d * CKP;
   const float* qrow = qs + d * CKP;
   f32x16 av, ak;
 #pragma unroll
   for (int e = 0; e < 16; ++e) av[e] = ak[e] = 0.f;
-  float so[32], sq[32];
+  const Mat mP = mat(p.Pin + (size_t)g * T * T, T, T, T), mS = mat(p.dS + (size_t)g * T * T, T, T, T);
+  float so[NRS], sq[NRS];
   load_rows(og, so, 0, T, dk, tid);
   load_rows(qg, sq, 0, T, dk, tid);
   for (int c0 = 0; c0 < T; c0 += CK) {
@@ -403,12 +425,10 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p
     for (int s = kp; s < nst; s += wpt) {
       const typename O::frag fp = O::make(s, h, [&](int ii) {
         const int i = c0 + ii;
-        if (i >= T || j >= T) return 0.f;
-        const size_t off = ((size_t)g * T + i) * T + j;
-        const float pv = p.Pin[off];
-        return p.pdrop > 0.f ? pv * drop_scale(p.seed, off, p.pdrop, inv_keep) : pv;
+        const float pv = ldm(mP, i, j);  // (0 past the matrix)
+        return p.pdrop > 0.f ? pv * drop_scale(p.seed, ((size_t)g * T + i) * T + j, p.pdrop, inv_keep) : pv;
       });
-      const typename O::frag fs = O::make(s, h, [&](int ii) { const int i = c0 + ii; return (i < T && j < T) ? p.dS[((size_t)g * T + i) * T + j] : 0.f; });
+      const typename O::frag fs = O::make(s, h, [&](int ii) { return ldm(mS, c0 + ii, j); });
       const typename O::frag fo = O::make(s, h, [&](int ii) { return orow[ii]; });
       const typename O::frag fq = O::make(s, h, [&](int ii) { return qrow[ii]; });
       av = O::mma(fp, fo, av);
@@ -422,13 +442,13 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p
     red1[(wave * 32 + acc_row(e, h)) * OP + l31] = ak[e];
   }
   __syncthreads();
-  for (int idx = tid; idx < 32 * dk; idx += 256) {
+  for (int idx = tid; idx < 32 * dk; idx += NTH) {
     const int m = idx & 31, dd = idx >> 5;
     if (j0 + m >= T) continue;
     const int tl = dd >> 5, n = dd & 31;
     float sv = 0.f, sk = 0.f;
     for (int k2 = 0; k2 < wpt; ++k2) {
-      const int wv = nt == 1 ? k2 : k2 * 2 + tl;
+      const int wv = k2 * nt + tl;
       sv += red0[(wv * 32 + m) * OP + n];
       sk += red1[(wv * 32 + m) * OP + n];
     }
@@ -437,8 +457,8 @@ __global__ void __launch_bounds__(256) rel_attn_bwd_cols_kernel(const AttnArgs p
   }
 }
 
-// (64 * CKP floats hold the band-logit staging (64 * QP + RELP * 64) and the partial-output tiles (4 * 32 * OP) too)
-size_t lds_bytes(int TP) { return sizeof(float) * ((size_t)32 * TP + 32 * RELP + TP + RELP * 64 + 64 * CKP); }
+// (the BSF floats hold the band-logit staging (64 * QP + RELP * 64) and the partial-output tiles (NWV * 32 * OP) too)
+size_t lds_bytes(int TP) { return sizeof(float) * ((size_t)32 * TP + 32 * RELP + TP + RELP * 64 + BSF); }
 
 bool ok_shape(int B, int H, int dk, int T, int w) {
   return B > 0 && H > 0 && dk > 0 && dk <= 64 && (dk % 2) == 0 && T > 0 && w >= 0 && 2 * w + 1 <= RELP &&
@@ -467,7 +487,7 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
   const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 100, 32 * 1000 + 32, 0};
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
-  hipExtLaunchKernelGGL(kern, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, (hipStream_t)stream, ev0, ev1, 0, a);
+  hipExtLaunchKernelGGL(kern, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds, (hipStream_t)stream, ev0, ev1, 0, a);
   return vcv_check_launch();
 }
 
@@ -496,12 +516,12 @@ extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, 
   const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 101, 32 * 1000 + 32, 0};
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
-  hipExtLaunchKernelGGL(rows, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds, st, ev0, ev1, 0, a);
+  hipExtLaunchKernelGGL(rows, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds, st, ev0, ev1, 0, a);
   const int tag2[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 102, 32 * 1000 + 32, 0};
   vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
-  const size_t lds2 = sizeof(float) * 2 * 64 * CKP;
+  const size_t lds2 = sizeof(float) * 2 * BSF;
   if (lds2 > 64 * 1024 && hipFuncSetAttribute((const void*)cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
     return VCV_EHIP;
-  hipExtLaunchKernelGGL(cols, dim3((T + 31) / 32, B * H), dim3(256), (unsigned)lds2, st, ev0, ev1, 0, a);
+  hipExtLaunchKernelGGL(cols, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds2, st, ev0, ev1, 0, a);
   return vcv_check_launch();
 }
