@@ -52,6 +52,15 @@ CONV_CASES = [
     (2, 256, 256, 256, 11, 1, 5, 1, 1),
     (2, 256, 192, 200, 3, 1, 3, 3, 1),
     (1, 300, 130, 150, 7, 1, 3, 1, 1),
+    # one output channel, LDS-staged: rows of 2..5 positions (pooled DiscriminatorS heads), several position
+    # tiles with a dilated halo, a row that is not a multiple of the tile
+    (64, 1024, 1, 2, 3, 1, 1, 1, 1),
+    (3, 1024, 1, 5, 3, 1, 1, 1, 1),
+    (3, 40, 1, 1000, 7, 1, 9, 3, 1),
+    (2, 32, 1, 8192, 7, 1, 3, 1, 1),
+    (5, 256, 1, 111, 3, 1, 1, 1, 1),
+    (2, 24, 1, 300, 5, 1, 0, 1, 1),
+    (3, 1, 16, 3000, 15, 1, 7, 1, 1),  # one input channel: several row chunks per batch element
 ]
 
 
@@ -84,6 +93,10 @@ PERIOD_CASES = [
     (2, 512, 1024, 9, 37, 5, 3, 2),
     (2, 1024, 1024, 6, 37, 5, 1, 2),
     (2, 1024, 1, 6, 11, 3, 1, 1),
+    (3, 1024, 1, 51, 2, 3, 1, 1),
+    (3, 1024, 1, 3, 37, 3, 1, 1),
+    (2, 1, 32, 700, 37, 5, 3, 2),
+    (2, 1, 32, 1400, 3, 5, 3, 2),
     (2, 32, 128, 911, 2, 5, 3, 2),
 ]
 

@@ -18,6 +18,56 @@ namespace {
 
 constexpr int CG = 4, K = 41, S = 4, PAD = 20, KP = 44;  // taps padded to a multiple of 4
 
+// Stage N (compile-time) elements with the 256 lanes of a workgroup: LB loads are issued before the first of them
+// is consumed.  A plain `for (i = tid; i < N; i += 256) lds[i] = src[...]` loop is compiled to one load, one wait,
+// one LDS write per iteration -- 17 serial memory latencies per 256-time stage, which was 3/4 of these kernels' time.
+template <int N, int LB, class Src, class Dst>
+__device__ __forceinline__ void stage_n(int tid, Src src, Dst dst) {
+  constexpr int IT = (N + 255) / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < IT; i0 += LB) {
+    float v[LB];
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int i = tid + (i0 + l) * 256;
+      v[l] = (i0 + l < IT && i < N) ? src(i) : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int i = tid + (i0 + l) * 256;
+      if (i0 + l < IT && i < N) dst(i, v[l]);
+    }
+  }
+}
+
+// the same with a second operand (the activation output of a fused derivative), loaded in its own batch when wanted
+template <int N, int LB, class Src, class Aux, class Dst>
+__device__ __forceinline__ void stage_n2(int tid, bool want_aux, Src src, Aux aux, Dst dst) {
+  constexpr int IT = (N + 255) / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < IT; i0 += LB) {
+    float v[LB], a[LB];
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int i = tid + (i0 + l) * 256;
+      v[l] = (i0 + l < IT && i < N) ? src(i) : 0.f;
+      a[l] = 1.f;
+    }
+    if (want_aux) {
+#pragma unroll
+      for (int l = 0; l < LB; ++l) {
+        const int i = tid + (i0 + l) * 256;
+        if (i0 + l < IT && i < N) a[l] = aux(i);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int i = tid + (i0 + l) * 256;
+      if (i0 + l < IT && i < N) dst(i, v[l], a[l]);
+    }
+  }
+}
+
 // ---- forward: block = 256 lanes = GB groups x TT output times (TT = 256 / GB: short pooled scales would leave
 // three quarters of a 256-time tile idle); lane = one output time of one group, all Mg outputs ----
 template <int MG, int TT>
@@ -32,18 +82,21 @@ grouped_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   const int gl = tid / TT, tl = tid - gl * TT;
   const int t0 = blockIdx.x * TT, g0 = blockIdx.y * GB, b = blockIdx.z;
   const int in0 = t0 * S - PAD;
-  for (int i = tid; i < GB * CG * SPAN; i += 256) {
-    const int gg = i / (CG * SPAN), r = i - gg * (CG * SPAN);
-    const int ci = r / SPAN, j = r - ci * SPAN;
-    const int ti = in0 + j;
-    const bool ok = g0 + gg < G && ti >= 0 && ti < Tin;
-    xs[gg][ci][j] = ok ? x[((size_t)b * G * CG + (size_t)(g0 + gg) * CG + ci) * Tin + ti] : 0.f;
-  }
-  for (int i = tid; i < GB * CG * KP * MG; i += 256) {
-    const int gg = i / (CG * KP * MG), r = i - gg * (CG * KP * MG);
-    const int m = r % MG, k = (r / MG) % KP, ci = r / (MG * KP);
-    ws[gg][ci][k][m] = (k < K && g0 + gg < G) ? w[((size_t)((g0 + gg) * MG + m) * CG + ci) * K + k] : 0.f;
-  }
+  stage_n<GB * CG * SPAN, 10>(tid,
+      [&](int i) {
+        const int gg = i / (CG * SPAN), r = i - gg * (CG * SPAN);
+        const int ci = r / SPAN, ti = in0 + r - ci * SPAN;
+        const bool ok = g0 + gg < G && ti >= 0 && ti < Tin;
+        return ok ? x[((size_t)b * G * CG + (size_t)(g0 + gg) * CG + ci) * Tin + ti] : 0.f;
+      },
+      [&](int i, float v) { (&xs[0][0][0])[i] = v; });
+  stage_n<GB * CG * KP * MG, 11>(tid,
+      [&](int i) {
+        const int gg = i / (CG * KP * MG), r = i - gg * (CG * KP * MG);
+        const int m = r % MG, k = (r / MG) % KP, ci = r / (MG * KP);
+        return (k < K && g0 + gg < G) ? w[((size_t)((g0 + gg) * MG + m) * CG + ci) * K + k] : 0.f;
+      },
+      [&](int i, float v) { (&ws[0][0][0][0])[i] = v; });
   __syncthreads();
   float acc[MG];
 #pragma unroll
@@ -89,22 +142,25 @@ grouped_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
   const int tid = threadIdx.x;
   const int gl = tid / QT, ql = tid - gl * QT;
   const int q0 = blockIdx.x * QT, g0 = blockIdx.y * GB, b = blockIdx.z;
-  for (int i = tid; i < GB * MG * DSPAN; i += 256) {
-    const int gg = i / (MG * DSPAN), r = i - gg * (MG * DSPAN);
-    const int m = r / DSPAN, j = r - m * DSPAN;
-    const int t = q0 - 5 + j;
-    float v = 0.f;
-    if (t >= 0 && t < Tout && g0 + gg < G) {
-      const size_t gi = ((size_t)b * G * MG + (size_t)(g0 + gg) * MG + m) * Tout + t;
-      v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
-    }
-    ds[gg][m][j] = v;
+  {
+    auto at = [&](int i, bool& ok) {
+      const int gg = i / (MG * DSPAN), r = i - gg * (MG * DSPAN);
+      const int m = r / DSPAN, t = q0 - 5 + r - m * DSPAN;
+      ok = t >= 0 && t < Tout && g0 + gg < G;
+      return ((size_t)b * G * MG + (size_t)(g0 + gg) * MG + m) * Tout + t;
+    };
+    stage_n2<GB * MG * DSPAN, 8>(tid, dtf == VCV_TF_DLEAKY,
+        [&](int i) { bool ok; const size_t gi = at(i, ok); return ok ? dy[gi] : 0.f; },
+        [&](int i) { bool ok; const size_t gi = at(i, ok); return ok ? yaux[gi] : 1.f; },
+        [&](int i, float v, float a) { (&ds[0][0][0])[i] = v * vcv_dleaky(a, slope); });
   }
-  for (int i = tid; i < GB * MG * KP * CG; i += 256) {
-    const int gg = i / (MG * KP * CG), r = i - gg * (MG * KP * CG);
-    const int ci = r % CG, k = (r / CG) % KP, m = r / (CG * KP);
-    ws[gg][m][k][ci] = (k < K && g0 + gg < G) ? w[((size_t)((g0 + gg) * MG + m) * CG + ci) * K + k] : 0.f;
-  }
+  stage_n<GB * MG * KP * CG, 11>(tid,
+      [&](int i) {
+        const int gg = i / (MG * KP * CG), r = i - gg * (MG * KP * CG);
+        const int ci = r % CG, k = (r / CG) % KP, m = r / (CG * KP);
+        return (k < K && g0 + gg < G) ? w[((size_t)((g0 + gg) * MG + m) * CG + ci) * K + k] : 0.f;
+      },
+      [&](int i, float v) { (&ws[0][0][0][0])[i] = v; });
   __syncthreads();
   float acc[4][CG];  // [r][ci]
 #pragma unroll
@@ -167,21 +223,22 @@ grouped_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ yau
   for (int t0 = tlo; t0 < thi; t0 += TT) {
     __syncthreads();
     const int in0 = t0 * S - PAD;
-    for (int i = tid; i < CG * SPAN; i += 256) {
-      const int ci = i / SPAN, j = i - ci * SPAN;
-      const int ti = in0 + j;
-      xs[ci][j] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
-    }
-    for (int i = tid; i < MG * TT; i += 256) {
-      const int m = i / TT, j = i - m * TT;
-      const int t = t0 + j;
-      float v = 0.f;
-      if (t < thi) {
-        const size_t gi = ybase + (size_t)m * Tout + t;
-        v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
-      }
-      ds[m][j] = v;
-    }
+    stage_n<CG * SPAN, 10>(tid,
+        [&](int i) {
+          const int ci = i / SPAN, ti = in0 + i - ci * SPAN;
+          return (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+        },
+        [&](int i, float v) { (&xs[0][0])[i] = v; });
+    stage_n2<MG * TT, 8>(tid, dtf == VCV_TF_DLEAKY,
+        [&](int i) {
+          const int m = i / TT, t = t0 + i - m * TT;
+          return t < thi ? dy[ybase + (size_t)m * Tout + t] : 0.f;
+        },
+        [&](int i) {
+          const int m = i / TT, t = t0 + i - m * TT;
+          return t < thi ? yaux[ybase + (size_t)m * Tout + t] : 1.f;
+        },
+        [&](int i, float v, float a) { ds[i / TT][i % TT] = v * vcv_dleaky(a, slope); });
     __syncthreads();
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
@@ -234,16 +291,21 @@ grouped_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w
   const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
   const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
   const int in0 = t0 * S - PAD;  // a multiple of 4
-  for (int i = tid; i < CG * 4 * QN; i += 256) {
-    const int ci = i / (4 * QN), j = i - ci * (4 * QN);  // j: offset inside the span, coalesced global reads
-    const int ti = in0 + j;
-    xs[ci][j & 3][j >> 2] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
-  }
+  stage_n<CG * 4 * QN, 9>(tid,
+      [&](int i) {
+        const int ci = i / (4 * QN), ti = in0 + i - ci * (4 * QN);  // offset inside the span: coalesced global reads
+        return (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+      },
+      [&](int i, float v) {
+        const int ci = i / (4 * QN), j = i - ci * (4 * QN);
+        xs[ci][j & 3][j >> 2] = v;
+      });
   const float* wg = w + (size_t)g * MG * CG * K;  // the group's [m][ci][k] block is contiguous: coalesced reads
-  for (int i = tid; i < K * CG * MG; i += 256) {
-    const int k = i % K, ci = (i / K) % CG, m = i / (K * CG);
-    ws[k][ci * MG + m] = wg[i];
-  }
+  stage_n<K * CG * MG, 11>(tid, [&](int i) { return wg[i]; },
+      [&](int i, float v) {
+        const int k = i % K, ci = (i / K) % CG, m = i / (K * CG);
+        ws[k][ci * MG + m] = v;
+      });
   __syncthreads();
   const int n = lane & 15, kq = lane >> 4;  // column / k index of this lane's A and B elements
   f32x4_t acc[4];
@@ -304,23 +366,25 @@ grouped_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = blockIdx.x * QT, g = blockIdx.y, b = blockIdx.z;
   const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
-  for (int i = tid; i < MG * DSP; i += 256) {
-    const int m = i / DSP, j = i - m * DSP;
-    const int t = q0 - 5 + j;
-    float v = 0.f;
-    if (t >= 0 && t < Tout) {
-      const size_t gi = ybase + (size_t)m * Tout + t;
-      v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
-    }
-    ds[m][j] = v;
+  {
+    auto at = [&](int i, bool& ok) {
+      const int m = i / DSP, t = q0 - 5 + i - m * DSP;
+      ok = t >= 0 && t < Tout;
+      return ybase + (size_t)m * Tout + t;
+    };
+    stage_n2<MG * DSP, 9>(tid, dtf == VCV_TF_DLEAKY,
+        [&](int i) { bool ok; const size_t gi = at(i, ok); return ok ? dy[gi] : 0.f; },
+        [&](int i) { bool ok; const size_t gi = at(i, ok); return ok ? yaux[gi] : 1.f; },
+        [&](int i, float v, float a) { (&ds[0][0])[i] = v * vcv_dleaky(a, slope); });
   }
   for (int i = tid; i < NJ * 4 * 64; i += 256) (&wsd[0][0])[i] = 0.f;
   __syncthreads();
   const float* wg = w + (size_t)g * MG * CG * K;
-  for (int i = tid; i < MG * CG * K; i += 256) {
-    const int k = i % K, ci = (i / K) % CG, m = i / (K * CG);
-    wsd[(k >> 2) * 4 + (m >> 2)][(m & 3) * 16 + ci * 4 + (k & 3)] = wg[i];
-  }
+  stage_n<MG * CG * K, 11>(tid, [&](int i) { return wg[i]; },
+      [&](int i, float v) {
+        const int k = i % K, ci = (i / K) % CG, m = i / (K * CG);
+        wsd[(k >> 2) * 4 + (m >> 2)][(m & 3) * 16 + ci * 4 + (k & 3)] = v;
+      });
   __syncthreads();
   const int n = lane & 15, kq = lane >> 4;
   f32x4_t acc[4];
@@ -415,21 +479,22 @@ grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
     const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
     __syncthreads();
     const int in0 = t0 * S - PAD;
-    for (int i = tid; i < CG * SPAN; i += 256) {
-      const int ci = i / SPAN, j = i - ci * SPAN;
-      const int ti = in0 + j;
-      xs[ci][j] = (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
-    }
-    for (int i = tid; i < MG * TT; i += 256) {
-      const int m = i / TT, j = i - m * TT;
-      const int t = t0 + j;
-      float v = 0.f;
-      if (t < Tout) {
-        const size_t gi = ybase + (size_t)m * Tout + t;
-        v = vcv_tf(dy[gi], dtf, yaux, gi, slope);
-      }
-      ds[m][j] = v;
-    }
+    stage_n<CG * SPAN, 9>(tid,
+        [&](int i) {
+          const int ci = i / SPAN, ti = in0 + i - ci * SPAN;
+          return (ti >= 0 && ti < Tin) ? xb[(size_t)ci * Tin + ti] : 0.f;
+        },
+        [&](int i, float v) { (&xs[0][0])[i] = v; });
+    stage_n2<MG * TT, 8>(tid, dtf == VCV_TF_DLEAKY,
+        [&](int i) {
+          const int m = i / TT, t = t0 + i - m * TT;
+          return t < Tout ? dy[ybase + (size_t)m * Tout + t] : 0.f;
+        },
+        [&](int i) {
+          const int m = i / TT, t = t0 + i - m * TT;
+          return t < Tout ? yaux[ybase + (size_t)m * Tout + t] : 1.f;
+        },
+        [&](int i, float v, float a) { ds[i / TT][i % TT] = v * vcv_dleaky(a, slope); });
     __syncthreads();
     const float* xf = &xs[0][0];
 #pragma unroll 2

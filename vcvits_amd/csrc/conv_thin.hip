@@ -69,6 +69,101 @@ conv_m1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   }
 }
 
+// stride 1: the input block of a (batch element, position tile, channel chunk) is staged in LDS with independent
+// coalesced loads (eight rows in flight per lane), then every lane reduces its position over the chunk out of
+// LDS.  The register version above issues C*K dependent-latency loads per lane and is latency-bound on the
+// discriminators' Conv(1024 -> 1, k3) heads (rows of 30..250 positions) and on the generator's Conv(32 -> 1, k7).
+// Short rows: R = 256 / TU channel sub-rows share a workgroup and meet in LDS.
+// grid: (position tiles of TU, B, channel splits); dynamic LDS: cch * (W + K) + 256 floats
+__global__ void __launch_bounds__(256)
+conv_m1_lds_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int C, int Uin, int U, int K, int tapstep, int shift, int in_leaky,
+                   int out_act, float slope, int cper, int cch, int TU, int R, int W, int atomic, int flat) {
+  extern __shared__ float sm[];
+  float* xs = sm;             // [cch][W]
+  float* wsm = sm + cch * W;  // [cch][K]
+  float* red = wsm + cch * K; // [256]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int u0 = blockIdx.x * TU;
+  const int c_lo = blockIdx.z * cper;
+  const int c_hi = c_lo + cper < C ? c_lo + cper : C;
+  const int cl = tid / TU, ul = tid - cl * TU;
+  const bool live = cl < R && u0 + ul < U;
+  const int in_lo = u0 - shift;
+  const int j0 = tid, j1 = tid + 256;  // W <= 512 (checked by the launcher)
+  const int ui0 = in_lo + j0, ui1 = in_lo + j1;
+  const bool ok0 = j0 < W && ui0 >= 0 && ui0 < Uin, ok1 = j1 < W && ui1 >= 0 && ui1 < Uin;
+  float acc = 0.f;
+  for (int c0 = c_lo; c0 < c_hi; c0 += cch) {
+    const int nc = cch < c_hi - c0 ? cch : c_hi - c0;
+    const float* xb = x + ((size_t)b * C + c0) * Uin;
+    if (flat) {
+      // the tile holds whole rows: the chunk's rows are one contiguous block -- a flat copy, eight loads in flight
+      const int tot = nc * Uin, hw = W - Uin;
+      for (int i = tid; i < nc * hw; i += 256) {
+        const int c = i / hw, h = i - c * hw;
+        xs[c * W + (h < shift ? h : Uin + h)] = 0.f;
+      }
+      for (int i0 = tid; i0 < tot; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = i0 + i * 256 < tot ? xb[i0 + i * 256] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = i0 + i * 256;
+          if (idx < tot) {
+            const int c = idx / Uin, ui = idx - c * Uin;
+            xs[c * W + shift + ui] = in_leaky ? vcv_leaky(v[i], slope) : v[i];
+          }
+        }
+      }
+    } else
+    for (int r0 = 0; r0 < nc; r0 += 8) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool rok = r0 + i < nc;
+        const float* xr = xb + (size_t)(r0 + i) * Uin;
+        v0[i] = rok && ok0 ? xr[ui0] : 0.f;
+        v1[i] = rok && ok1 ? xr[ui1] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (r0 + i < nc) {
+          if (j0 < W) xs[(r0 + i) * W + j0] = in_leaky ? vcv_leaky(v0[i], slope) : v0[i];
+          if (j1 < W) xs[(r0 + i) * W + j1] = in_leaky ? vcv_leaky(v1[i], slope) : v1[i];
+        }
+      }
+    }
+    for (int i = tid; i < nc * K; i += 256) wsm[i] = w[(size_t)c0 * K + i];
+    __syncthreads();
+    if (live) {
+      for (int c = cl; c < nc; c += R) {
+        const float* xr = xs + c * W + ul;
+        const float* wr = wsm + c * K;
+        for (int k = 0; k < K; ++k) acc += wr[k] * xr[k * tapstep];
+      }
+    }
+    __syncthreads();
+  }
+  if (R > 1) {
+    red[tid] = live ? acc : 0.f;
+    __syncthreads();
+    if (cl == 0 && live)
+      for (int r = 1; r < R; ++r) acc += red[r * TU + ul];
+  }
+  if (cl == 0 && live) {
+    const size_t oi = (size_t)b * U + u0 + ul;
+    if (atomic) {
+      unsafeAtomicAdd(y + oi, acc);
+    } else {
+      if (bias) acc += bias[0];
+      y[oi] = vcv_act(acc, out_act, slope);
+    }
+  }
+}
+
 __global__ void fill_bias_kernel(float* __restrict__ y, const float* __restrict__ bias, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] = bias ? bias[0] : 0.f;
@@ -90,6 +185,35 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
   const int b_lo = blockIdx.y * bper;
   int b_hi = b_lo + bper;
   if (b_hi > B) b_hi = B;
+  const int u_lo0 = blockIdx.z * uper, ulen = (u_lo0 + uper < U ? u_lo0 + uper : U) - u_lo0;
+  if (ulen < 512) {
+    // short rows (the discriminator heads: 2..250 positions): lanes along the flattened (batch element, position)
+    // range, so that a wavefront is full and the loop is a few independent iterations instead of one per element
+    const int tot = (b_hi - b_lo) * ulen;
+    const int kstep = d * P;
+    for (int j = threadIdx.x; j < tot; j += 256) {
+      const int bl = j / ulen, u = u_lo0 + j - bl * ulen, b = b_lo + bl;
+      const size_t abase = ((size_t)b * M + m) * (size_t)U;
+      const size_t bbase = ((size_t)b * C + c) * (size_t)Tb * P;
+      const float* brow = bsh + bbase;
+      float av = a[abase + u];
+      if (!PLAIN) av = vcv_tf(av, a_tf, aaux, abase + u, slope);
+      const int q = u / P, pc = u - q * P;
+      const int r0 = q * s + off;
+      const int i0 = r0 * P + pc;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const int r = r0 + k * d;
+          if (r >= 0 && r < Tb) {
+            const int bi = i0 + k * kstep;
+            const float bv = PLAIN ? brow[bi] : vcv_tf(brow[bi], b_tf, baux, bbase + bi, slope);
+            acc[k] += av * bv;
+          }
+        }
+      }
+    }
+  } else
   for (int b = b_lo; b < b_hi; ++b) {
     const size_t abase = ((size_t)b * M + m) * (size_t)U;
     const size_t bbase = ((size_t)b * C + c) * (size_t)Tb * P;
@@ -127,6 +251,62 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
     const int k = threadIdx.x;
     unsafeAtomicAdd(dw + ((size_t)m * C + c) * K + k, alpha * (red[0][k] + red[1][k] + red[2][k] + red[3][k]));
   }
+}
+
+// ---- weight gradient of a one-input-channel layer with M*K <= 256 weights: lane = one weight (m, k) ---------
+// dw[m,k] = sum_{b,q,p} dy[b,m,q,p] * x[b,0,q*s+off+k*d,p].  The workgroup walks a (batch element, row chunk): the
+// x window of the chunk and [M][tile] slices of dy are staged in LDS with coalesced loads, and every position then
+// costs a lane two LDS reads and one FMA -- no per-element tap loads from memory (K+1 loads per element made the
+// row-per-workgroup kernel above texture-address-bound at K = 15) and no cross-lane reduction.
+// grid: (row chunks of qper, B); dynamic LDS: xw + M*TUP floats
+__global__ void __launch_bounds__(256)
+c1_wgrad_pairs_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int M, int Ta,
+                      int Tb, int P, int K, int s, int d, int off, float alpha, int qper, int tq, int TUP, int xw) {
+  extern __shared__ float sm[];
+  float* xs = sm;        // [xw]: rows q_lo*s+off .. of x[b], zero outside the row
+  float* dyt = sm + xw;  // [M][TUP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int q_lo = blockIdx.x * qper;
+  const int q_hi = q_lo + qper < Ta ? q_lo + qper : Ta;
+  const int m = tid / K, k = tid - m * K;
+  const bool own = tid < M * K;
+  {
+    const long long lo = (long long)(q_lo * s + off) * P, n = (long long)Tb * P;
+    const float* xb = x + (size_t)b * n;
+    for (int i = tid; i < xw; i += 256) {
+      const long long g = lo + i;
+      xs[i] = g >= 0 && g < n ? xb[g] : 0.f;
+    }
+  }
+  float acc = 0.f;
+  const size_t U = (size_t)Ta * P;
+  const float* ar = dyt + (own ? m : 0) * TUP;
+  for (int q0 = q_lo; q0 < q_hi; q0 += tq) {
+    const int nq = tq < q_hi - q0 ? tq : q_hi - q0;
+    const int tl = nq * P;
+    __syncthreads();  // the previous tile is consumed (and, first time round, xs is written)
+    for (int mm = wave; mm < M; mm += 4) {
+      const float* src = dy + ((size_t)b * M + mm) * U + (size_t)q0 * P;
+      for (int j = lane; j < tl; j += 64) dyt[mm * TUP + j] = src[j];
+    }
+    __syncthreads();
+    if (own) {
+      const float* xr = xs + ((q0 - q_lo) * s + k * d) * P;
+      if (s == 1) {
+#pragma unroll 8
+        for (int j = 0; j < tl; ++j) acc += ar[j] * xr[j];
+      } else {
+        for (int ql = 0; ql < nq; ++ql) {
+          const float* a2 = ar + ql * P;
+          const float* x2 = xr + ql * s * P;
+#pragma unroll 4
+          for (int pc = 0; pc < P; ++pc) acc += a2[pc] * x2[pc];
+        }
+      }
+    }
+  }
+  if (own) unsafeAtomicAdd(dw + tid, alpha * acc);
 }
 
 // ---- one INPUT channel (first layers of the discriminators: 1 -> 16 k15, 1 -> 32 k5 stride 3) -------------
@@ -327,6 +507,32 @@ extern "C" int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias
     while (splits < 64 && (long long)nt * B * splits < 1024 && C / (splits * 2) >= 8) splits *= 2;
   }
   if (vcv_get_deterministic()) splits = 1;  // (the channel-range splits meet in fp32 atomics)
+  static const bool no_lds = getenv("VCVITS_M1_NO_LDS") != nullptr;
+  const long long halo = (long long)(K - 1) * dil * P;
+  const bool lds = stride == 1 && halo <= 256 && !no_lds && (long long)Tin * P < (1ll << 31);
+  if (lds) {
+    // short rows: several channel sub-rows per workgroup
+    const int TU = U < 256 ? U : 256;
+    const int R = 256 / TU;
+    const int ntl = vcv_cdiv(U, TU);
+    splits = 1;
+    if (out_act == VCV_ACT_NONE && !vcv_get_deterministic())
+      while (splits < 64 && (long long)ntl * B * splits < 1024 && C / (splits * 2) >= 8 * R) splits *= 2;
+    const int cperl = vcv_cdiv(C, splits);
+    const int W = TU + (int)halo;
+    int cch = (40 * 1024 / 4 - 256) / (W + K);
+    if (cch > cperl) cch = cperl;
+    cch = (cch + 7) & ~7;
+    const size_t smem = sizeof(float) * ((size_t)cch * (W + K) + 256);
+    if (splits > 1) {
+      const size_t n = (size_t)B * U;
+      hipLaunchKernelGGL(fill_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, bias, n);
+    }
+    hipLaunchKernelGGL(conv_m1_lds_kernel, dim3(ntl, B, vcv_cdiv(C, cperl)), dim3(256), smem, st, x, w, bias, y, C, Tin * P,
+                       U, K, dil * P, pad * P, in_leaky, out_act, slope, cperl, cch, TU, R, W, splits > 1 ? 1 : 0,
+                       ntl == 1 && Tout == Tin + 2 * pad - dil * (K - 1) ? 1 : 0);
+    return vcv_check_launch();
+  }
   const int cper = vcv_cdiv(C, splits);
   if (splits > 1) {
     const size_t n = (size_t)B * U;
@@ -344,6 +550,26 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
     return VCV_EINVAL;
   if ((a_tf >= VCV_TF_DLEAKY && !aaux) || (b_tf >= VCV_TF_DLEAKY && !baux)) return VCV_EINVAL;
   if ((long long)Ta * P >= (1ll << 31) || (long long)Tb * P >= (1ll << 31)) return VCV_EINVAL;
+  static const bool no_pairs = getenv("VCVITS_C1_WGRAD_NO_PAIRS") != nullptr;
+  // (stride 1 only: with a stride the x index is not linear in the flattened position and the two-level loop it
+  // needs measured slower than the row-per-workgroup kernel on the period discriminators' 1 -> 32 k5 s3 layers)
+  if (C == 1 && s == 1 && M * K <= 256 && a_tf == VCV_TF_NONE && b_tf == VCV_TF_NONE && !vcv_get_deterministic() &&
+      !no_pairs && P <= 256) {
+    // row tile of <= 256 positions, chunk of ~1024 positions per workgroup
+    int tq = 256 / P;
+    if (tq > Ta) tq = Ta;
+    int qper = tq * (1024 / (tq * P) > 0 ? 1024 / (tq * P) : 1);
+    if (qper > Ta) qper = vcv_cdiv(Ta, tq) * tq;
+    const int xw = ((qper - 1) * s + (K - 1) * d + 1) * P;
+    int TUP = tq * P;
+    if (TUP % 32 == 0) TUP += 1;
+    const size_t smem = sizeof(float) * ((size_t)xw + (size_t)M * TUP);
+    if (smem <= 60 * 1024) {
+      hipLaunchKernelGGL(c1_wgrad_pairs_kernel, dim3(vcv_cdiv(Ta, qper), B), dim3(256), smem, (hipStream_t)stream, a, bsh, dw,
+                         M, Ta, Tb, P, K, s, d, off, alpha, qper, tq, TUP, xw);
+      return vcv_check_launch();
+    }
+  }
   int splits = 1;
   while (splits < B && (long long)M * C * splits < 4096) splits *= 2;  // short serial batch loops: latency-bound
   if (splits > B) splits = B;
@@ -352,7 +578,8 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   const int bper = vcv_cdiv(B, splits);
   // long rows: also split the positions so that the grid has a few thousand workgroups of >= 1024 positions
   const int U = Ta * P;
-  long long usplit = 8192 / ((long long)M * C * vcv_cdiv(B, bper));
+  static const int wg_target = getenv("VCVITS_THIN_WGRAD_WGS") ? atoi(getenv("VCVITS_THIN_WGRAD_WGS")) : 2048;
+  long long usplit = wg_target / ((long long)M * C * vcv_cdiv(B, bper));
   if (usplit > U / 1024) usplit = U / 1024;
   if (usplit < 1 || det) usplit = 1;
   const int uper = (vcv_cdiv(U, (int)usplit) + 255) & ~255;
