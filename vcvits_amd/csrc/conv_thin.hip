@@ -171,17 +171,20 @@ __global__ void fill_bias_kernel(float* __restrict__ y, const float* __restrict_
 
 // one workgroup per weight row (m, c); a: [B, M, Ta, P] (un-shifted), bsh: [B, C, Tb, P] (shifted)
 // PLAIN: no operand transforms (the usual case: dy arrives pre-masked) -- no per-element transform switch
-template <bool PLAIN>
+// KT > 0: the tap count at compile time -- the tap loop is then straight-line code, its loads are issued together and
+// out-of-row taps are clamped reads with a zero weight instead of branches
+template <bool PLAIN, int KT>
 __global__ void __launch_bounds__(256)
 thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, const float* __restrict__ aaux,
                   const float* __restrict__ baux, float* __restrict__ dw, int B, int M, int C, int Ta, int Tb,
                   int P, int K, int s, int d, int off, int a_tf, int b_tf, float slope, float alpha, int bper, int uper) {
+  constexpr int KK = KT > 0 ? KT : KMAX;
   __shared__ float red[4][KMAX];
   const int m = blockIdx.x / C, c = blockIdx.x % C;
   const int U = Ta * P;  // < 2^31 (checked by the launcher)
-  float acc[KMAX];
+  float acc[KK];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  for (int k = 0; k < KK; ++k) acc[k] = 0.f;
   const int b_lo = blockIdx.y * bper;
   int b_hi = b_lo + bper;
   if (b_hi > B) b_hi = B;
@@ -191,6 +194,7 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
     // range, so that a wavefront is full and the loop is a few independent iterations instead of one per element
     const int tot = (b_hi - b_lo) * ulen;
     const int kstep = d * P;
+#pragma unroll 4
     for (int j = threadIdx.x; j < tot; j += 256) {
       const int bl = j / ulen, u = u_lo0 + j - bl * ulen, b = b_lo + bl;
       const size_t abase = ((size_t)b * M + m) * (size_t)U;
@@ -201,8 +205,20 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
       const int q = u / P, pc = u - q * P;
       const int r0 = q * s + off;
       const int i0 = r0 * P + pc;
+      if (PLAIN && KT > 0) {
+        float bv[KK];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KK; ++k) {
+          const int r = r0 + k * d;
+          const bool ok = r >= 0 && r < Tb;
+          bv[k] = brow[ok ? i0 + k * kstep : 0];
+          bv[k] = ok ? bv[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc[k] += av * bv[k];
+      } else {
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
         if (k < K) {
           const int r = r0 + k * d;
           if (r >= 0 && r < Tb) {
@@ -211,6 +227,7 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
             acc[k] += av * bv;
           }
         }
+      }
       }
     }
   } else
@@ -220,14 +237,27 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
     const int u_lo = blockIdx.z * uper, u_hi = u_lo + uper < U ? u_lo + uper : U;
     const float* brow = bsh + bbase;
     const int kstep = d * P;
+#pragma unroll 4
     for (int u = u_lo + threadIdx.x; u < u_hi; u += 256) {
       float av = a[abase + u];
       if (!PLAIN) av = vcv_tf(av, a_tf, aaux, abase + u, slope);
       const int q = u / P, pc = u - q * P;
       const int r0 = q * s + off;
       const int i0 = r0 * P + pc;  // element offset of tap 0 inside the (b, c) row (fits 32 bits: checked by the launcher)
+      if (PLAIN && KT > 0) {
+        float bv[KK];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KK; ++k) {
+          const int r = r0 + k * d;
+          const bool ok = r >= 0 && r < Tb;
+          bv[k] = brow[ok ? i0 + k * kstep : 0];
+          bv[k] = ok ? bv[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc[k] += av * bv[k];
+      } else {
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
         if (k < K) {
           const int r = r0 + k * d;
           if (r >= 0 && r < Tb) {
@@ -237,11 +267,12 @@ thin_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ bsh, co
           }
         }
       }
+      }
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
+  for (int k = 0; k < KK; ++k) {
     if (k >= K) break;  // uniform
     const float v = wsum(acc[k]);
     if (lane == 0) red[wv][k] = v;
@@ -583,13 +614,20 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   if (usplit > U / 1024) usplit = U / 1024;
   if (usplit < 1 || det) usplit = 1;
   const int uper = (vcv_cdiv(U, (int)usplit) + 255) & ~255;
-  if (a_tf == VCV_TF_NONE && b_tf == VCV_TF_NONE)
-    hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0,
-                       (hipStream_t)stream, a, bsh, aaux, baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha,
-                       bper, uper);
-  else
-    hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper)), dim3(256), 0,
-                       (hipStream_t)stream, a, bsh, aaux, baux, dw, B, M, C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha,
-                       bper, uper);
+  const dim3 grid(M * C, vcv_cdiv(B, bper), vcv_cdiv(U, uper));
+#define VCV_THIN_WGRAD(PLAIN, KT)                                                                                        \
+  hipLaunchKernelGGL((thin_wgrad_kernel<PLAIN, KT>), grid, dim3(256), 0, (hipStream_t)stream, a, bsh, aaux, baux, dw, B, M, \
+                     C, Ta, Tb, P, K, s, d, off, a_tf, b_tf, slope, alpha, bper, uper)
+  if (a_tf == VCV_TF_NONE && b_tf == VCV_TF_NONE) {
+    switch (K) {
+      case 3: VCV_THIN_WGRAD(true, 3); break;
+      case 5: VCV_THIN_WGRAD(true, 5); break;
+      case 7: VCV_THIN_WGRAD(true, 7); break;
+      default: VCV_THIN_WGRAD(true, 0); break;
+    }
+  } else {
+    VCV_THIN_WGRAD(false, 0);
+  }
+#undef VCV_THIN_WGRAD
   return vcv_check_launch();
 }
