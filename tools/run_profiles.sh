@@ -39,6 +39,7 @@ rm -rf gpurun_out/${TAG}_busya
 python3 tools/conv_layer_bench.py --reps 10 > profiles/${TAG}_conv_layers.txt 2>/dev/null
 python3 tools/conv_layer_bench.py --reps 10 --split 0 > profiles/${TAG}_conv_layers_fp32_mfma.txt 2>/dev/null
 python3 tools/attn_bench.py > profiles/${TAG}_attn_bench.txt 2>/dev/null
+python3 tools/thin_bench.py > profiles/${TAG}_thin_bench.txt 2>/dev/null
 python3 bench.py --steps 10 --warmup 3 > profiles/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > profiles/${TAG}_bench_line_bf16.json 2>/dev/null
 python3 bench.py --dtype bf16 --workload full --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2.json 2>/dev/null

@@ -49,8 +49,8 @@ for p in (2, 37):
 for i in (0, 2):
     cases.append(("discS/%d.conv0" % (1 << i), 64, 1, 16, 8192 >> i, 1, 15, 1, 7, TF_NONE, ACT_NONE))
 
-tot = [0.0, 0.0]
-print("%-16s %5s %5s %3s %6s %3s | %8s %8s %8s  (us per launch)" % ("layer", "C", "M", "K", "rows", "P", "fwd", "wgrad", "MB"))
+tot = [0.0, 0.0, 0.0]
+print("%-16s %5s %5s %3s %6s %3s | %8s %8s %8s %8s  (us per launch)" % ("layer", "C", "M", "K", "rows", "P", "fwd", "wgrad", "dgrad", "MB"))
 for name, B, C, M, H, P, K, s, pad, in_tf, act in cases:
     x = torch.randn(B, C, H, P, device=dev) if P > 1 else torch.randn(B, C, H, device=dev)
     w = torch.randn(M, C, K, device=dev)
@@ -59,7 +59,9 @@ for name, B, C, M, H, P, K, s, pad, in_tf, act in cases:
     gy = torch.randn_like(y)
     tf = timed(lambda: ops.conv_forward(x, w, bias, stride=s, pad=pad, in_tf=in_tf, out_act=act))
     tw = timed(lambda: ops.conv_wgrad(gy, x, (M, C, K), stride=s, pad=pad))
+    td = timed(lambda: ops.conv_dgrad(gy, w, x.shape, stride=s, pad=pad))
     tot[0] += tf
     tot[1] += tw
-    print("%-16s %5d %5d %3d %6d %3d | %8.1f %8.1f %8.1f" % (name, C, M, K, H, P, tf, tw, (x.numel() + y.numel()) * 4 / 1e6))
-print("sum fwd %.1f us, wgrad %.1f us" % tuple(tot))
+    tot[2] += td
+    print("%-16s %5d %5d %3d %6d %3d | %8.1f %8.1f %8.1f %8.1f" % (name, C, M, K, H, P, tf, tw, td, (x.numel() + y.numel()) * 4 / 1e6))
+print("sum fwd %.1f us, wgrad %.1f us, dgrad %.1f us" % tuple(tot))

@@ -361,8 +361,12 @@ conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   for (int i = threadIdx.x; i < M; i += 256) bs[i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int U = Tout * P;
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= U) return;
+  // rows shorter than a workgroup (the heads' data gradients: 30..250 positions, 1024 channels): R = 256 / U lanes share a
+  // position and take every R-th channel of the chunk
+  const int TU = U < 256 ? U : 256, R = 256 / TU;
+  const int mr = threadIdx.x / TU;
+  const int u = blockIdx.x * TU + threadIdx.x - mr * TU;
+  if (u >= U || mr >= R) return;
   const int b = blockIdx.y;
   const int t = u / P, pc = u - t * P;
   const float* xb = x + (size_t)b * Tin * P;
@@ -373,7 +377,7 @@ conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     xv[k] = (k < K && r >= 0 && r < Tin) ? xb[(size_t)r * P + pc] : 0.f;
   }
   float* yb = y + ((size_t)b * mfull + m0) * U + u;
-  for (int m = 0; m < M; ++m) {
+  for (int m = mr; m < M; m += R) {
     float acc = bs[m];
     const float* wr = ws + m * K;
 #pragma unroll
