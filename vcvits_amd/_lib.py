@@ -201,7 +201,16 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current HIP stream of the current device as a void*.  torch.cuda.current_stream() builds a Stream object
+    through four python layers (~10 us; 900 launches per step made it 8 ms of a host-bound 80 ms step); the two C
+    entry points behind it return the same handle in well under a microsecond."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_GET_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -86,6 +86,22 @@ def compute_dtype():
     return _COMPUTE[0]
 
 
+from ._lib import _GET_DEVICE  # noqa: E402
+
+_FAMILIES = {}
+_FAMILY_KEY = {"vcv_conv_bf16_run": "bf16", "vcv_conv_x3_run": "x3", "vcv_conv_pk_run": "pk"}
+_DEVS = {}
+
+
+def _cur_dev():
+    """torch.device of the current GPU (cached objects; the index through the C entry point when torch has it)."""
+    i = _GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device()
+    d = _DEVS.get(i)
+    if d is None:
+        d = _DEVS[i] = torch.device("cuda", i)
+    return d
+
+
 def _launch_conv(a, flip_w=None):
     """Forward-type launches go to the packed-weight kernels when one is eligible -- the bf16-operand kernel
     (vcv_conv_bf16_*) under set_compute_dtype("bf16"), else the fp32 LDS-DMA kernel (vcv_conv_dma_*) -- everything else to
@@ -99,16 +115,20 @@ def _launch_conv(a, flip_w=None):
             a.w = ptr(flip_w)
         flip = 1 if flip_w is not None else 0
         plan = (ctypes.c_int64 * 3)()
-        families = ((L.vcv_conv_bf16_plan, L.vcv_conv_bf16_run, "vcv_conv_bf16_run"),) if _COMPUTE[0] == "bf16" else ()
-        if _USE_X3[0] and _COMPUTE[0] == "f32":
-            families += ((L.vcv_conv_x3_plan, L.vcv_conv_x3_run, "vcv_conv_x3_run"),)
-        if _USE_PK[0]:
-            families += ((L.vcv_conv_pk_plan, L.vcv_conv_pk_run, "vcv_conv_pk_run"),)
-        families += ((L.vcv_conv_dma_plan, L.vcv_conv_dma_run, "vcv_conv_dma_run"),)
+        fkey = (_COMPUTE[0], _USE_X3[0], _USE_PK[0])
+        families = _FAMILIES.get(fkey)
+        if families is None:  # (built once per switch setting: this function runs ~450 times per step)
+            families = ((L.vcv_conv_bf16_plan, L.vcv_conv_bf16_run, "vcv_conv_bf16_run"),) if _COMPUTE[0] == "bf16" else ()
+            if _USE_X3[0] and _COMPUTE[0] == "f32":
+                families += ((L.vcv_conv_x3_plan, L.vcv_conv_x3_run, "vcv_conv_x3_run"),)
+            if _USE_PK[0]:
+                families += ((L.vcv_conv_pk_plan, L.vcv_conv_pk_run, "vcv_conv_pk_run"),)
+            families += ((L.vcv_conv_dma_plan, L.vcv_conv_dma_run, "vcv_conv_dma_run"),)
+            _FAMILIES[fkey] = families
         for plan_fn, run_fn, name in families:
             if plan_fn(ctypes.byref(a), flip, plan) != 0:
                 continue
-            dev = torch.device("cuda", torch.cuda.current_device())
+            dev = _cur_dev()
             ent = _stable_entry(a.w)
             packs = ent["packs"] if ent is not None else None
             key = (a.w, plan[0], plan[2])
@@ -126,7 +146,7 @@ def _launch_conv(a, flip_w=None):
                         (bytes(a), flip)
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
             check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
-            LAUNCH_COUNTS[{"vcv_conv_bf16_run": "bf16", "vcv_conv_x3_run": "x3", "vcv_conv_pk_run": "pk"}.get(name, "dma")] += 1
+            LAUNCH_COUNTS[_FAMILY_KEY.get(name, "dma")] += 1
             return
         if flip_w is not None:
             a.w = saved
@@ -154,14 +174,14 @@ def _launch_wgrad(a):
     if _DETERMINISTIC[0] and a.G == 1:
         nw = a.Mg * a.Cg * a.K
         n = min(nw * 512, max(nw * 4, 24 << 20))
-        slab = torch.empty((n,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+        slab = torch.empty((n,), device=_cur_dev(), dtype=torch.float32)
         a.slab, a.slab_floats = ptr(slab), n
     if _COMPUTE[0] == "bf16" or (_USE_X3[0] and _USE_X3_WGRAD[0]):
         L = lib()
         bf = _COMPUTE[0] == "bf16"
         n = (L.vcv_wgrad_bf16_scratch if bf else L.vcv_wgrad_x3_scratch)(ctypes.byref(a))
         if n > 0:
-            scratch = torch.empty((n,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+            scratch = torch.empty((n,), device=_cur_dev(), dtype=torch.float32)
             if bf:
                 check(L.vcv_wgrad_bf16(ctypes.byref(a), ptr(scratch), n, stream()), "vcv_wgrad_bf16")
             else:
