@@ -76,6 +76,86 @@ __device__ __forceinline__ void pack_pk(const VcvPackJob& J, size_t i) {
   }
 }
 
+// kind 0, coalesced: one workgroup per (phase, m-tile, 16-channel group, 32-row slice).  The slice's source weights are 32
+// (mode 0: [m][16*K]) or 16 (modes 1 / 2: [c][32*K]) contiguous runs -- read coalesced into a ~10 KB LDS tile (16 workgroups
+// per CU: the loads of one hide behind the gathers of the others), packed planes gathered from there.  The
+// thread-per-item body above reads its 8 channels K floats apart and rows C*K floats apart across lanes: every lane-load
+// its own cache line.  Same bits as pack_x3 (tests/test_pack_many_gpu.py).
+constexpr int PK_RT = 32;
+
+__global__ void __launch_bounds__(256) pack_x3_tile_kernel(const VcvPackJob* __restrict__ jobs, int n) {
+  extern __shared__ float src[];
+  int lo = 0, hi = n - 1;
+  const long long bx = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= bx) lo = mid; else hi = mid - 1;
+  }
+  const VcvPackJob J = jobs[lo];
+  const int nsl = J.BM / PK_RT;  // row slices per m-tile
+  int t = (int)(bx - J.block0);
+  const int sl = t % nsl; t /= nsl;
+  const int g = t % J.nch; t /= J.nch;
+  const int mt = t % J.nmt;
+  const int r = t / J.nmt;
+  const int tid = threadIdx.x;
+  const int ml0 = sl * PK_RT, m0 = mt * J.BM + ml0, c0 = g * 16;
+  const int K = J.K;
+  int rows, L;
+  if (J.mode == 0) rows = PK_RT, L = 16 * K; else rows = 16, L = PK_RT * K;
+  const int pitch = L | 1;
+  // valid rows / valid part of a row (the rest of the tile reads as zero)
+  int vrows = J.mode == 0 ? J.M - m0 : J.C - c0;
+  vrows = vrows < 0 ? 0 : (vrows < rows ? vrows : rows);
+  int vL = J.mode == 0 ? (J.C - c0) * K : (J.M - m0) * K;
+  vL = vL < 0 ? 0 : (vL < L ? vL : L);
+  const size_t rstride = J.mode == 0 ? (size_t)J.C * K : (size_t)J.M * K;
+  const float* base = J.mode == 0 ? J.w + ((size_t)m0 * J.C + c0) * K : J.w + ((size_t)c0 * J.M + m0) * K;
+  const int tot = rows * L;
+  for (int i0 = tid; i0 < tot; i0 += 256 * 6) {
+    float v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = i0 + u * 256;
+      const int row = i / L, col = i - row * L;
+      v[u] = (i < tot && row < vrows && col < vL) ? base[(size_t)row * rstride + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = i0 + u * 256;
+      if (i < tot) {
+        const int row = i / L, col = i - row * L;
+        src[row * pitch + col] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int items = J.JA * 2 * PK_RT;
+  const size_t slab0 = (((size_t)r * J.nmt + mt) * J.nch + g) * J.JA;
+  for (int it = tid; it < items; it += 256) {
+    const int mr = it % PK_RT;
+    const int hh = (it / PK_RT) & 1;
+    const int j = it / (2 * PK_RT);
+    const int kk = J.mode == 0 ? j : J.mode == 1 ? K - 1 - j : r + j * J.phases;
+    const bool kok = J.mode == 2 ? kk < K : j < K;
+    bf16x8 v0, v1, v2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = 0.f;
+      if (kok) f = J.mode == 0 ? src[mr * pitch + (hh * 8 + e) * K + kk] : src[(hh * 8 + e) * pitch + mr * K + kk];
+      const __bf16 a = (__bf16)f;
+      const float r1 = f - (float)a;
+      const __bf16 b = (__bf16)r1;
+      const __bf16 d = (__bf16)(r1 - (float)b);
+      v0[e] = a, v1[e] = b, v2[e] = d;
+    }
+    bf16x8* o = (bf16x8*)J.wp + (slab0 + j) * (size_t)(3 * 2 * J.BM) + (size_t)hh * J.BM + ml0 + mr;
+    o[0] = v0;
+    o[(size_t)2 * J.BM] = v1;
+    o[(size_t)4 * J.BM] = v2;
+  }
+}
+
 __global__ void __launch_bounds__(256) pack_many_kernel(const VcvPackJob* __restrict__ jobs, int n) {
   // the job of this block: the last one whose first block is <= blockIdx.x (binary search; jobs are sorted by block0)
   int lo = 0, hi = n - 1;
@@ -99,14 +179,44 @@ __global__ void __launch_bounds__(256) pack_many_kernel(const VcvPackJob* __rest
 extern "C" int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* stream) {
   if (!jobs || n <= 0 || !table_dev) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  long long blocks = 0;
+  static const bool no_tile = getenv("VCVITS_PACK_NO_TILE") != nullptr;
+  constexpr size_t TILE_LDS_MAX = 40 * 1024;
+  auto tile_lds = [](const VcvPackJob& j) {
+    return sizeof(float) * (size_t)(j.mode == 0 ? PK_RT * ((16 * j.K) | 1) : 16 * ((PK_RT * j.K) | 1));
+  };
+  // the split-operand jobs go first (coalesced tile kernel: one workgroup per 32-row slice of a 16-channel group), the
+  // thread-per-item jobs after them: two launches over the two parts of one table (the host array is re-ordered in place)
+  int nt = 0;
   for (int i = 0; i < n; ++i) {
-    if (!jobs[i].w || !jobs[i].wp || jobs[i].total <= 0 || jobs[i].kind < 0 || jobs[i].kind > 2) return VCV_EINVAL;
+    VcvPackJob& j = jobs[i];
+    if (!j.w || !j.wp || j.total <= 0 || j.kind < 0 || j.kind > 2) return VCV_EINVAL;
+    const bool tile = j.kind == 0 && !no_tile && j.BM % PK_RT == 0 && tile_lds(j) <= TILE_LDS_MAX &&
+                      j.total % ((int64_t)j.JA * 2 * j.BM) == 0;
+    j.reserved = tile ? 1 : 0;
+    if (tile) {
+      const VcvPackJob tmp = jobs[nt];
+      jobs[nt] = j;
+      jobs[i] = tmp;
+      ++nt;
+    }
+  }
+  long long blocks_t = 0, blocks = 0;
+  size_t lds_max = 0;
+  for (int i = 0; i < nt; ++i) {
+    const VcvPackJob& j = jobs[i];
+    jobs[i].block0 = blocks_t;
+    blocks_t += j.total / ((int64_t)j.JA * 2 * j.BM) * (j.BM / PK_RT);
+    if (tile_lds(j) > lds_max) lds_max = tile_lds(j);
+  }
+  for (int i = nt; i < n; ++i) {
     jobs[i].block0 = blocks;
     blocks += (jobs[i].total + 255) / 256;
   }
-  if (blocks >= (1ll << 31)) return VCV_EINVAL;
+  if (blocks >= (1ll << 31) || blocks_t >= (1ll << 31)) return VCV_EINVAL;
   if (hipMemcpyAsync(table_dev, jobs, sizeof(VcvPackJob) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) return VCV_EHIP;
-  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const VcvPackJob*)table_dev, n);
+  if (nt > 0)
+    hipLaunchKernelGGL(pack_x3_tile_kernel, dim3((unsigned)blocks_t), dim3(256), lds_max, st, (const VcvPackJob*)table_dev, nt);
+  if (n > nt)
+    hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const VcvPackJob*)table_dev + nt, n - nt);
   return vcv_check_launch();
 }
