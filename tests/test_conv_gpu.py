@@ -61,6 +61,11 @@ CONV_CASES = [
     (5, 256, 1, 111, 3, 1, 1, 1, 1),
     (2, 24, 1, 300, 5, 1, 0, 1, 1),
     (3, 1, 16, 3000, 15, 1, 7, 1, 1),  # one input channel: several row chunks per batch element
+    (3, 48, 1, 70, 5, 1, 4, 2, 1),     # one output channel: three channel sub-rows per workgroup, dilated halo
+    (2, 1, 17, 300, 15, 1, 7, 1, 1),   # one input channel: 255 of the 256 weight lanes
+    (2, 1, 18, 300, 15, 1, 7, 1, 1),   # ... 270 weights: the row-per-workgroup kernel
+    (2, 1, 40, 257, 5, 1, 2, 1, 1),
+    (5, 20, 1, 1, 3, 1, 1, 1, 1),      # a single position per row
 ]
 
 
@@ -97,6 +102,8 @@ PERIOD_CASES = [
     (3, 1024, 1, 3, 37, 3, 1, 1),
     (2, 1, 32, 700, 37, 5, 3, 2),
     (2, 1, 32, 1400, 3, 5, 3, 2),
+    (2, 64, 1, 9, 5, 3, 1, 1),
+    (2, 1, 16, 40, 7, 15, 1, 7),
     (2, 32, 128, 911, 2, 5, 3, 2),
 ]
 
