@@ -137,6 +137,8 @@ CONVT_CASES = [
     (2, 128, 64, 100, 4, 4, 0),
     (2, 64, 32, 300, 4, 2, 1),
     (2, 20, 12, 17, 3, 1, 1),
+    (16, 512, 256, 32, 16, 8, 4),  # the first generator stage at the bench's batch: folded forward and data gradient
+    (3, 40, 24, 17, 4, 4, 0),
 ]
 
 

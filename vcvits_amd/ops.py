@@ -267,12 +267,19 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
               "vcv_conv_c1_dgrad")
         return out
     if (M == 1 and groups == 1 and stride == 1 and C >= 16 and K <= 16 and kw.get("in_tf", TF_NONE) == TF_NONE
-            and set(kw) <= {"in_tf", "xaux", "slope"}):
-        # one OUTPUT channel (conv_post of the discriminators, 1024 -> 1): the data gradient is a one-input-channel
-        # convolution of dy with the flipped taps -- an HBM write stream, not a GEMM (was 35 us on the generic kernel)
+            and set(kw) <= {"in_tf", "xaux", "slope", "out_tf", "oaux"}
+            and kw.get("out_tf", TF_NONE) in (TF_NONE, TF_DLEAKY)):
+        # one OUTPUT channel (conv_post of the discriminators, 1024 -> 1; of the generator, 32 -> 1): the data gradient
+        # is a one-input-channel convolution of dy with the flipped taps -- an HBM write stream, not a GEMM (was 35 us
+        # on the generic kernel); the derivative of a leaky-ReLU on the conv's input is one more streaming pass in place
         wf = w.reshape(C, K).flip(-1).contiguous()
-        check(lib().vcv_conv_c1_fwd(ptr(dy), ptr(wf), None, ptr(out), B, C, Tout, Tin, P, K, 1, dil, (K - 1) * dil - pad,
+        masked = kw.get("out_tf", TF_NONE) == TF_DLEAKY
+        raw = torch.empty_like(out) if masked else out
+        check(lib().vcv_conv_c1_fwd(ptr(dy), ptr(wf), None, ptr(raw), B, C, Tout, Tin, P, K, 1, dil, (K - 1) * dil - pad,
                                     ACT_NONE, kw.get("slope", 0.1), stream()), "vcv_conv_c1_fwd")
+        if masked:
+            check(lib().vcv_act_grad(ptr(raw), ptr(kw["oaux"]), ptr(out), TF_DLEAKY, kw.get("slope", 0.1), out.numel(),
+                                     stream()), "vcv_act_grad")
         return out
     if stride == 1 and groups == 1 and M >= 32 and C >= 32:
         # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
@@ -391,7 +398,7 @@ def convT_forward(x, w, bias=None, stride=1, pad=0, out=None, **kw):
         raise RuntimeError("convT_forward: channel mismatch")
     Tout = convT_out_len(Tin, K, stride, pad)
     if out is None:
-        out = torch.empty((B, M, Tout), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, M, Tout) if x.dim() == 3 else (B, M, Tout, P), device=x.device, dtype=torch.float32)
     a = VcvConvArgs()
     a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, 1, C, M
@@ -590,7 +597,12 @@ class _ConvFn(torch.autograd.Function):
         # "image" [1,C,T,B] (P = B columns) and the tile's N runs over (t, b) pairs.
         ctx.bt = (not transposed and x.dim() == 3 and groups == 1 and res is None and x.shape[0] > 1
                   and x.shape[2] <= 64 and w.shape[0] >= 32 and w.shape[1] >= 32)
-        if transposed:
+        if transposed and x.dim() == 3 and x.shape[2] <= 64 and x.shape[0] > 1 and res is None and stride > 1:
+            # first generator stage (32 frames per utterance): a phase of the transposed conv has 32 columns per batch
+            # element, below what the packed-weight kernels tile (the launch fell to the generic kernel at 14 TFLOP/s);
+            # folded like the short convs, one phase has 32 x B columns
+            y = _from_bt(convT_forward(_to_bt(x), w, stride=stride, pad=pad, **kw))
+        elif transposed:
             y = convT_forward(x, w, stride=stride, pad=pad, **kw)
         elif ctx.bt:
             w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
