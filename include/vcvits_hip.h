@@ -84,7 +84,15 @@ typedef struct VcvConvArgs {
   int32_t Q;          /* number of q positions per phase */
   int32_t a_mode, in_tf, out_act, out_tf, accumulate;
   float alpha, slope;
+  int32_t io;         /* storage type of the activations in HBM: 0 = all fp32 (every entry point); VCV_IO_BF16 (3) = `x`,
+                         `y` and `res` are bf16 tensors (same [B, C, T(, P)] layout, 2-byte elements, rows of an even number
+                         of elements): vcv_conv_bf16io_* only -- every other entry point returns VCV_EINVAL for io != 0 */
+  float post_scale;   /* 0: none.  Else the epilogue becomes v = (act(alpha*acc + bias) * dact + res) * mask * post_scale
+                         (+ y if accumulate): the mean over the three ResBlocks of a generator stage is accumulated by the
+                         blocks' last convs (post_scale 1/3) instead of by a pass over three stored outputs
+                         (vcv_conv_bf16io_* only) */
 } VcvConvArgs;
+#define VCV_IO_BF16 3
 
 int vcv_conv_gemm(const VcvConvArgs* args, void* stream);
 
@@ -121,6 +129,22 @@ int vcv_conv_pk_plan(const VcvConvArgs* args, int flip, int64_t* out);
 int vcv_conv_pk_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream);
 int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
                       void* stream);
+/*
+ * The bf16 kernel with bf16 ACTIVATIONS in HBM (args->io == VCV_IO_BF16; conv_pk_io.hip): the conv <-> conv tensors of
+ * the HiFi-GAN decoder in inference (synthesizer_svc.py:108 under the reference's fp16 autocast, train.py:104-106: AMP
+ * stores conv activations in half precision) -- `x` is read with 16-byte loads of eight positions, `y` is rounded once
+ * (nearest even) after the fp32 epilogue, `res` / the accumulate target are bf16 like `y`; bias / mask stay fp32; out_tf
+ * must be NONE.  Packs are interchangeable with vcv_conv_bf16_* (same layout, same out[2]); out[1] is always 0 (no
+ * split reduction).  vcv_cast_f32_bf16 / vcv_cast_bf16_f32: the conversions at the two ends of such a chain.
+ * vcv_conv_m1_bf16in_fwd: vcv_conv_m1_fwd (one output channel, stride 1) over a bf16 `x`, fp32 `y`.
+ */
+int vcv_conv_bf16io_plan(const VcvConvArgs* args, int flip, int64_t* out);
+int vcv_conv_bf16io_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
+                        void* stream);
+int vcv_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+int vcv_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream);
+int vcv_conv_m1_bf16in_fwd(const void* x, const float* w, const float* bias, float* y, int B, int C, int Tin, int Tout,
+                           int K, int dil, int pad, int in_leaky, int out_act, float slope, void* stream);
 
 /*
  * fp32 convolutions on the bf16 matrix pipe by exact operand splitting (conv_x3.hip): every fp32 operand is the exact sum

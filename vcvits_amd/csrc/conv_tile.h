@@ -25,7 +25,21 @@ struct BfGeom {
 // columns (wn*TN + tn)*32 ..), `smem` the workgroup's LDS (free: the caller's main loop ended with a barrier), `part`
 // the partial-sum slabs of a split launch.  b: batch element, kz: split index, u0 / m0: first column / row of the tile,
 // oo: output row offset (phase residue included).
-template <int TM, int TN>
+// activation element i of a tensor stored as fp32 or (B16) bf16
+template <bool B16>
+__device__ __forceinline__ float ld_act(const float* p, size_t i) {
+  if constexpr (B16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+  else return p[i];
+}
+template <bool B16>
+__device__ __forceinline__ void st_act(float* p, size_t i, float v) {
+  if constexpr (B16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;  // round to nearest even (v_cvt_pk_bf16_f32)
+  else p[i] = v;
+}
+
+// IO bit 1: `y`, `res` and the accumulate target are bf16 tensors (conv_pk_io.hip); the split-reduction paths are fp32-only
+// (the planner never splits such a launch).
+template <int TM, int TN, int IO = 0>
 __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const BfGeom& tg, f32x16 (&acc)[TM][TN], char* smem,
                                                    float* __restrict__ part, int wave, int wm, int wn, int lane, int b, int kz,
                                                    int u0, int m0, int oo, int BM) {
@@ -33,7 +47,91 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
   const int P = p.P, U = p.Q * P, Mg = p.Mg;
   const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
   const bool mtail = m0 + BM > Mg;
-  if (TM * TN <= 4 && tg.vec) {  // (compile-time bound: the unrolled body of the 5- and 7-tile waves would not stay in registers)
+  constexpr bool YB = (IO & 2) != 0;
+  if constexpr (YB) {
+    if (TM * TN <= 4 && tg.vec) {
+      // ---- 16-byte epilogue, bf16 output: as below, each lane taking EIGHT consecutive columns of one row (two 16-byte
+      // LDS reads, one 16-byte store; `res` / the accumulate target are read the same way)
+      typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+      float* T = reinterpret_cast<float*>(smem) + wave * (32 * 40);
+      const unsigned rowstride = (unsigned)(p.Tout * P);
+      const size_t ybase = ((size_t)b * Mg + m0) * rowstride;
+      const float* bias = p.bias ? p.bias + m0 : nullptr;
+      unsigned short* y16 = reinterpret_cast<unsigned short*>(p.y);
+      const unsigned short* r16 = reinterpret_cast<const unsigned short*>(p.res);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = acc[tm][tn][e];
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const int r = ps * 16 + (lane >> 2), c8 = lane & 3;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + r * 40 + 8 * c8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + r * 40 + 8 * c8 + 4);
+            const int ml = (wm * TM + tm) * 32 + r;
+            const int u = u0 + (wn * TN + tn) * 32 + 8 * c8;
+            if ((mtail && ml >= rows_valid) || u >= U) continue;
+            const size_t idx = ybase + (size_t)((unsigned)ml * rowstride) + u;
+            const int nv = U - u < 8 ? U - u : 8;
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, yy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (p.mask) {  // (P == 1: the mask row of this batch element is indexed by u)
+              const float* mrow = p.mask + (size_t)b * p.Tout + u;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < nv) mk[j] = mrow[j];
+            }
+            if (nv == 8) {
+              if (p.res) {
+                const us8 t8 = *reinterpret_cast<const us8*>(r16 + idx);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = __uint_as_float((unsigned)t8[j] << 16);
+              }
+              if (p.accumulate) {
+                const us8 t8 = *reinterpret_cast<const us8*>(y16 + idx);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yy[j] = __uint_as_float((unsigned)t8[j] << 16);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                if (j < nv) {
+                  if (p.res) rr[j] = ld_act<true>(p.res, idx + j);
+                  if (p.accumulate) yy[j] = ld_act<true>(p.y, idx + j);
+                }
+              }
+            }
+            const float bv = bias ? bias[ml] : 0.f;
+            const float ps_ = p.post_scale != 0.f ? p.post_scale : 1.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float x = p.alpha * v[j] + bv;
+              x = vcv_act(x, p.out_act, p.slope);
+              x += rr[j];
+              x *= mk[j];
+              x = x * ps_ + yy[j];
+              v[j] = x;
+            }
+            if (nv == 8) {
+              us8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, (__bf16)v[j]);
+              *reinterpret_cast<us8*>(y16 + idx) = o;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < nv) st_act<true>(p.y, idx + j, v[j]);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+  if (!YB && TM * TN <= 4 && tg.vec) {  // (compile-time bound: the unrolled body of the 5- and 7-tile waves would not stay in registers)
     // ---- 16-byte epilogue: each 32 x 32 accumulator tile goes through a wave-private LDS tile (pitch 40 floats: the
     // two row halves of the MFMA layout land 32 banks apart), comes back as rows of four consecutive columns per lane,
     // and the epilogue operands (residual, activation-derivative mask, accumulate) are read the same way: a quarter
@@ -161,10 +259,11 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
         if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
         else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
         else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
-        if (p.res) v += p.res[idx];
+        if (p.res) v += ld_act<YB>(p.res, idx);
         v *= mk;
-        if (p.accumulate) v += p.y[idx];
-        p.y[idx] = v;
+        if (YB && p.post_scale != 0.f) v *= p.post_scale;
+        if (p.accumulate) v += ld_act<YB>(p.y, idx);
+        st_act<YB>(p.y, idx, v);
       }
     }
   }

@@ -3,6 +3,7 @@
 canonical VITS/HiFi-GAN definition with the in-tree ResBlock1
 (modules.py:186-222), ctor signature of synthesizer_tts.py:71-78, hyper-parameters of
 configs/base.json:55-63.  Parity with the hub weights is unpinned."""
+import torch
 from torch import nn
 
 from .. import ops
@@ -37,8 +38,33 @@ class Generator(nn.Module):
         for m in self.ups:
             m.weight_v.data.normal_(0.0, 0.01)
 
+    def _forward_bf16_activations(self, x, g):
+        """Inference in bf16 mode: every conv <-> conv tensor between conv_pre and conv_post lives in bf16 in HBM (the
+        reference's autocast does the same to every conv output: train.py:104-106), the mean over a stage's three
+        ResBlocks is accumulated by their last convs (post_scale 1/3) and conv_post reads bf16.  Arithmetic: operands
+        rounded to bf16 as in the fp32-activation path, fp32 accumulate and epilogue, one rounding per stored tensor."""
+        x = self.conv_pre(x)
+        if g is not None:
+            x = x + self.cond(g)
+        x = ops.cast_bf16(x)
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            up = self.ups[i]
+            x = ops.convT_forward_bf16io(x, up.effective_weight(), up.bias, stride=up.stride, pad=up.padding, in_leaky=True,
+                                         slope=LRELU_SLOPE)
+            acc = None
+            for j in range(nk):
+                acc = self.resblocks[i * nk + j].forward_bf16_activations(x, acc, 1.0 / nk)
+            x = acc
+        cp = self.conv_post
+        return ops.conv_m1_bf16in(x, cp.effective_weight(), cp.bias, pad=cp.padding, in_leaky=True, slope=0.01, out_act=ACT_TANH)
+
     def forward(self, x, g=None):
         modules.prepare_weight_norm(self)
+        if (ops.bf16_activations() and not torch.is_grad_enabled() and x.is_cuda and x.shape[-1] % 2 == 0
+                and x.shape[-1] >= 96 and isinstance(self.resblocks[0], modules.ResBlock1)
+                and self.conv_post.weight.shape[2] in (3, 5, 7)):
+            return self._forward_bf16_activations(x, g)
         x = self.conv_pre(x)
         if g is not None:
             x = x + self.cond(g)

@@ -73,7 +73,22 @@ _COMPUTE = ["f32"]
 
 
 # which kernel family each GEMM-shaped launch went to (tests assert that the bf16 path really ran)
-LAUNCH_COUNTS = {"bf16": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad_x3": 0, "wgrad": 0, "attn_fused": 0}
+LAUNCH_COUNTS = {"bf16": 0, "bf16io": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, "wgrad_bf16": 0, "wgrad_x3": 0, "wgrad": 0,
+                 "attn_fused": 0}
+
+# bf16 mode stores the conv <-> conv activations of the decoder's inference pass in bf16 in HBM (vcv_conv_bf16io_*: what the
+# reference's fp16 autocast does to every conv output, train.py:104-106); VCVITS_BF16_ACT=0 / set_bf16_activations(False)
+# keeps them fp32 (operands still rounded on their way into the matrix cores)
+_BF16_ACT = [__import__("os").environ.get("VCVITS_BF16_ACT", "1") == "1"]
+
+
+def set_bf16_activations(on):
+    _BF16_ACT[0] = bool(on)
+
+
+def bf16_activations():
+    """True when no-grad decoder passes keep their intermediate activations in bf16."""
+    return _BF16_ACT[0] and _COMPUTE[0] == "bf16"
 
 
 def set_compute_dtype(name):
@@ -89,7 +104,7 @@ def compute_dtype():
 from ._lib import _GET_DEVICE  # noqa: E402
 
 _FAMILIES = {}
-_FAMILY_KEY = {"vcv_conv_bf16_run": "bf16", "vcv_conv_x3_run": "x3", "vcv_conv_pk_run": "pk"}
+_FAMILY_KEY = {"vcv_conv_bf16_run": "bf16", "vcv_conv_x3_run": "x3", "vcv_conv_pk_run": "pk", "vcv_conv_bf16io_run": "bf16io"}
 _DEVS = {}
 
 
@@ -115,8 +130,10 @@ def _launch_conv(a, flip_w=None):
             a.w = ptr(flip_w)
         flip = 1 if flip_w is not None else 0
         plan = (ctypes.c_int64 * 3)()
-        fkey = (_COMPUTE[0], _USE_X3[0], _USE_PK[0])
+        fkey = (_COMPUTE[0], _USE_X3[0], _USE_PK[0], a.io)
         families = _FAMILIES.get(fkey)
+        if families is None and a.io != 0:  # bf16 activations: one family reads / writes them
+            families = _FAMILIES[fkey] = ((L.vcv_conv_bf16io_plan, L.vcv_conv_bf16io_run, "vcv_conv_bf16io_run"),)
         if families is None:  # (built once per switch setting: this function runs ~450 times per step)
             families = ((L.vcv_conv_bf16_plan, L.vcv_conv_bf16_run, "vcv_conv_bf16_run"),) if _COMPUTE[0] == "bf16" else ()
             if _USE_X3[0] and _COMPUTE[0] == "f32":
@@ -150,6 +167,8 @@ def _launch_conv(a, flip_w=None):
             return
         if flip_w is not None:
             a.w = saved
+    if a.io != 0:
+        raise RuntimeError("vcvits_amd: no kernel takes this launch with bf16 activations (shape outside vcv_conv_bf16io_*)")
     LAUNCH_COUNTS["gemm"] += 1
     check(lib().vcv_conv_gemm(ctypes.byref(a), stream()), "vcv_conv_gemm")
 
@@ -412,6 +431,91 @@ def convT_forward(x, w, bias=None, stride=1, pad=0, out=None, **kw):
     _common(a, bias=bias, **kw)
     _launch_conv(a)
     return out
+
+
+# ---- bf16 activations in HBM (inference decoder; no autograd) -----------------------------------------------------------
+def _bf16t(t, what):
+    if t is None:
+        return None
+    if t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise RuntimeError("vcvits_amd: %s must be a contiguous bf16 tensor" % what)
+    return t
+
+
+def cast_bf16(x):
+    """fp32 -> bf16 (round to nearest even), same shape."""
+    x = _f32c(x)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib().vcv_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()), "vcv_cast_f32_bf16")
+    return y
+
+
+def cast_f32(x):
+    x = _bf16t(x, "x")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib().vcv_cast_bf16_f32(ptr(x), ptr(y), x.numel(), stream()), "vcv_cast_bf16_f32")
+    return y
+
+
+def conv_forward_bf16io(x, w, bias=None, stride=1, pad=0, dil=1, in_leaky=False, out_act=ACT_NONE, slope=0.1, res=None,
+                        out=None, accumulate=False, post_scale=0.0):
+    """conv_forward over bf16 activations: x / res / out are bf16 [B, C, T]; w / bias fp32.  With `out` given and
+    accumulate=True the result is added onto it; post_scale multiplies (conv + bias + res) first (0 = none)."""
+    x, res, out = _bf16t(x, "x"), _bf16t(res, "res"), _bf16t(out, "out")
+    B, C, Tin, P = _rows(x)
+    M, Cg, K = w.shape[0], w.shape[1], w.shape[2]
+    if Cg != C:
+        raise RuntimeError("conv_forward_bf16io: channel mismatch")
+    Tout = conv_out_len(Tin, K, stride, pad, dil)
+    if out is None:
+        out = torch.empty((B, M, Tout) if x.dim() == 3 else (B, M, Tout, P), device=x.device, dtype=torch.bfloat16)
+    a = VcvConvArgs()
+    a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
+    a.B, a.G, a.Cg, a.Mg = B, 1, Cg, M
+    a.Tin, a.Tout, a.P, a.K = Tin, Tout, P, K
+    a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = stride, dil, -pad, 1, 0, 1, Tout, 0
+    _common(a, bias=_f32c(bias), res=res, in_tf=TF_LEAKY if in_leaky else TF_NONE, out_act=out_act, slope=slope,
+            accumulate=accumulate)
+    a.io, a.post_scale = 3, float(post_scale)
+    _launch_conv(a)
+    return out
+
+
+def convT_forward_bf16io(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.1):
+    """convT_forward over bf16 activations (x, result: bf16; w [Cin, Cout, K] / bias fp32)."""
+    x = _bf16t(x, "x")
+    B, C, Tin, P = _rows(x)
+    Cin, M, K = w.shape
+    if Cin != C:
+        raise RuntimeError("convT_forward_bf16io: channel mismatch")
+    Tout = convT_out_len(Tin, K, stride, pad)
+    out = torch.empty((B, M, Tout), device=x.device, dtype=torch.bfloat16)
+    a = VcvConvArgs()
+    a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
+    a.B, a.G, a.Cg, a.Mg = B, 1, C, M
+    a.Tin, a.Tout, a.P, a.K = Tin, Tout, P, K
+    a.a_mode = 1
+    if stride == 1:
+        a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q = 1, -1, pad, 1, 0, 1, Tout
+    else:
+        a.s, a.dj, a.off, a.os, a.oo, a.phases = 1, -1, 0, stride, -pad, stride
+        a.Q = (Tout - 1 + pad) // stride + 1
+    _common(a, bias=_f32c(bias), in_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope)
+    a.io = 3
+    _launch_conv(a)
+    return out
+
+
+def conv_m1_bf16in(x, w, bias=None, pad=0, in_leaky=False, out_act=ACT_NONE, slope=0.1):
+    """One-output-channel conv (stride 1, dilation 1) over a bf16 [B, C, T] input -> fp32 [B, 1, Tout]."""
+    x = _bf16t(x, "x")
+    B, C, Tin = x.shape
+    K = w.shape[2]
+    Tout = conv_out_len(Tin, K, 1, pad, 1)
+    y = torch.empty((B, 1, Tout), device=x.device, dtype=torch.float32)
+    check(lib().vcv_conv_m1_bf16in_fwd(ptr(x), ptr(_f32c(w)), ptr(_f32c(bias)), ptr(y), B, C, Tin, Tout, K, 1, pad,
+                                       1 if in_leaky else 0, out_act, slope, stream()), "vcv_conv_m1_bf16in_fwd")
+    return y
 
 
 def convT_dgrad(dy, w, x_shape, stride=1, pad=0, out=None, **kw):
