@@ -142,13 +142,41 @@ def launch_ranks(a, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the optimizers' gloo side channel needs no hostname lookup
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    import tempfile
     procs = []
+    out0_file = tempfile.TemporaryFile(mode="w+")  # (a file, not a pipe: the supervisor below polls instead of reading)
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
+    # supervise: a rank that dies early (OOM, device fault) would leave its siblings in RCCL init / an all-reduce until
+    # the watchdog fires minutes later -- when any child exits non-zero the others are terminated; overall limit
+    # VCVITS_BENCH_TIMEOUT seconds (default 3600)
+    deadline = time.time() + float(os.environ.get("VCVITS_BENCH_TIMEOUT", "3600"))
+    failed = False
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes) or time.time() > deadline:
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
     codes = [p.wait() for p in procs]
+    out0_file.seek(0)
+    out0 = out0_file.read()
+    out0_file.close()
+    if failed and not any(codes):
+        codes = [1] * n  # (timeout: every child was still healthy when it was stopped)
     lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
     if any(codes) or not lines:
         sys.stderr.write("bench.py: rank exit codes %s, %d JSON line(s) from rank 0\n" % (codes, len(lines)))
@@ -473,6 +501,25 @@ def dry_run(a, world, rank):
     dist.destroy_process_group()
 
 
+def pin_rank_cpus(local_rank, local_world):
+    """Give each local rank its own contiguous slice of the CPUs this process may run on (one NUMA-local block per GPU on
+    the usual 2-socket / 8-GPU node, where GPUs 0-3 hang off socket 0) and size the OpenMP / torch intra-op pools to it.
+    Called BEFORE anything initialises the GPU.  VCVITS_BENCH_NO_PIN=1 leaves the scheduler alone."""
+    if local_world <= 1 or os.environ.get("VCVITS_BENCH_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per < 1:
+            return None
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, 16)))
+        return mine
+    except OSError:
+        return None
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
@@ -485,6 +532,7 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and (a.gpus > 1 or world > 1):
         raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (a.gpus, world))
+    pinned = pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if a.dry_run:
         return dry_run(a, world, rank)
     if a.backend != "nccl":

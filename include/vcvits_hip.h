@@ -84,9 +84,9 @@ typedef struct VcvConvArgs {
   int32_t Q;          /* number of q positions per phase */
   int32_t a_mode, in_tf, out_act, out_tf, accumulate;
   float alpha, slope;
-  int32_t io;         /* storage type of the activations in HBM: 0 = all fp32 (every entry point); VCV_IO_BF16 (3) = `x`,
-                         `y` and `res` are bf16 tensors (same [B, C, T(, P)] layout, 2-byte elements, rows of an even number
-                         of elements): vcv_conv_bf16io_* only -- every other entry point returns VCV_EINVAL for io != 0 */
+  int32_t io;         /* storage type of the activations in HBM: 0 = all fp32 (every entry point); else VCV_IO_* bits: `x`,
+                         `y` and `res` are 16-bit tensors (same [B, C, T(, P)] layout, rows of an even number of elements):
+                         vcv_conv_bf16io_* only -- every other entry point returns VCV_EINVAL for io != 0 */
   float post_scale;   /* 0: none.  Else the epilogue becomes v = (act(alpha*acc + bias) * dact + res) * mask * post_scale
                          (+ y if accumulate): the mean over the three ResBlocks of a generator stage is accumulated by the
                          blocks' last convs (post_scale 1/3) instead of by a pass over three stored outputs
@@ -130,22 +130,29 @@ int vcv_conv_pk_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, 
 int vcv_conv_bf16_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
                       void* stream);
 /*
- * The bf16 kernel with bf16 ACTIVATIONS in HBM (args->io == VCV_IO_BF16; conv_pk_io.hip): the conv <-> conv tensors of
- * the HiFi-GAN decoder in inference (synthesizer_svc.py:108 under the reference's fp16 autocast, train.py:104-106: AMP
- * stores conv activations in half precision) -- `x` is read with 16-byte loads of eight positions, `y` is rounded once
- * (nearest even) after the fp32 epilogue, `res` / the accumulate target are bf16 like `y`; bias / mask stay fp32; out_tf
- * must be NONE.  Packs are interchangeable with vcv_conv_bf16_* (same layout, same out[2]); out[1] is always 0 (no
- * split reduction).  vcv_cast_f32_bf16 / vcv_cast_bf16_f32: the conversions at the two ends of such a chain.
- * vcv_conv_m1_bf16in_fwd: vcv_conv_m1_fwd (one output channel, stride 1) over a bf16 `x`, fp32 `y`.
+ * The bf16 kernel with 16-bit ACTIVATIONS in HBM (args->io != 0; conv_pk_io*.hip): the conv <-> conv tensors of the
+ * HiFi-GAN decoder in inference (synthesizer_svc.py:108 under the reference's fp16 autocast, train.py:104-106: AMP stores
+ * conv activations in half precision).  io = VCV_IO_X16 | VCV_IO_Y16 [| VCV_IO_XF16] [| VCV_IO_YF16]: `x`, and `y` with
+ * `res` and the accumulate target, are 16-bit tensors -- bf16, or IEEE fp16 with the *F16 bit (values clamped to the
+ * finite fp16 range).  `x` is read with 16-byte loads of eight positions (rows of an even number of elements) and reaches
+ * the matrix cores as bf16 (a bf16 `x` without input transform: as stored); the epilogue runs in fp32 and rounds once
+ * (nearest even); bias / mask stay fp32; out_tf must be NONE.  Combinations built: 3 (all bf16), 7 (fp16 x -> bf16 y), 11
+ * (bf16 x -> fp16 y / res), 15 (all fp16).  Packs are interchangeable with vcv_conv_bf16_* wherever the plans agree
+ * (out[2]); out[1] is always 0 (no split reduction).
+ * vcv_cast_f32_x16 / vcv_cast_x16_f32: the conversions at the two ends of such a chain (kind 1 = bf16, 2 = fp16).
+ * vcv_conv_m1_x16_fwd: vcv_conv_m1_fwd (one output channel, stride 1, dilation 1, K in {3, 5, 7}) over a 16-bit `x`.
  */
+#define VCV_IO_X16 1
+#define VCV_IO_Y16 2
+#define VCV_IO_XF16 4
+#define VCV_IO_YF16 8
 int vcv_conv_bf16io_plan(const VcvConvArgs* args, int flip, int64_t* out);
 int vcv_conv_bf16io_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
                         void* stream);
-int vcv_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
-int vcv_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream);
-int vcv_conv_m1_bf16in_fwd(const void* x, const float* w, const float* bias, float* y, int B, int C, int Tin, int Tout,
-                           int K, int dil, int pad, int in_leaky, int out_act, float slope, void* stream);
-
+int vcv_cast_f32_x16(const float* x, void* y, int64_t n, int kind, void* stream);
+int vcv_cast_x16_f32(const void* x, float* y, int64_t n, int kind, void* stream);
+int vcv_conv_m1_x16_fwd(const void* x, int kind, const float* w, const float* bias, float* y, int B, int C, int Tin,
+                        int Tout, int K, int dil, int pad, int in_leaky, int out_act, float slope, void* stream);
 /*
  * fp32 convolutions on the bf16 matrix pipe by exact operand splitting (conv_x3.hip): every fp32 operand is the exact sum
  * of three bf16 terms, so an fp32 product is the sum of nine exact bf16 products accumulated in fp32 -- the arithmetic
@@ -252,7 +259,8 @@ int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const fl
 /* Grouped k=41, stride 4, padding 20 convolutions with 4 input channels per group (DiscriminatorS
  * layers 2-5, discriminator.py:55-58): direct fp32 FMA kernels (an MFMA tile would be mostly padding).
  * x [B, G*4, Tin], w [G*Mg, 4, 41], y/dy [B, G*Mg, Tout], Mg in {4, 16}.  dtf / yaux: activation
- * derivative applied to dy while staging (VCV_TF_DLEAKY with yaux = y).  wgrad accumulates into dw. */
+ * derivative applied to dy while staging: VCV_TF_NONE or VCV_TF_DLEAKY with yaux = y (any other dtf: VCV_EINVAL).
+ * wgrad accumulates into dw. */
 int vcv_grouped41_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg, int Tin,
                       int Tout, int out_act, float slope, void* stream);
 int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg, int Tin,

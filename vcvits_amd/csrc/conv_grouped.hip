@@ -421,6 +421,7 @@ grouped_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
 extern "C" int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg,
                                    int Tin, int Tout, int dtf, float slope, void* stream) {
   if (!dy || !w || !dx || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
+  if (dtf != VCV_TF_NONE && dtf != VCV_TF_DLEAKY) return VCV_EINVAL;  // (the staging applies the leaky-ReLU derivative only)
   if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
   dim3 grid(vcv_cdiv(vcv_cdiv(Tin, 4), 256), G, B);
   if (Mg == 16) hipLaunchKernelGGL(grouped_dgrad_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, w, dx, G, Tin, Tout, dtf, slope);
@@ -529,6 +530,7 @@ grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
 extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
                                    int Tin, int Tout, int dtf, float slope, void* stream) {
   if (!dy || !x || !dw || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
+  if (dtf != VCV_TF_NONE && dtf != VCV_TF_DLEAKY) return VCV_EINVAL;  // (the staging applies the leaky-ReLU derivative only)
   if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
   // time chunks so that the grid has >= ~1000 workgroups
   int nchunk = 1;

@@ -15,11 +15,12 @@
 //     FMAs, fp32 output);  vcv_cast_*: the conversions at the two ends of a bf16 chain.
 // Numerics (tests/test_bf16_io_gpu.py): a launch equals the fp32 CPU convolution of the same bf16 inputs to 1e-5 before
 // the output rounding; the decoder's waveform stays within the north_star's 1e-3 RMS of the fp32 oracle.
-#include "conv_pk_kernel.h"
+#include "conv_pk_io_inst.h"
 
 namespace {
 
-__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n) {
+template <int KIND>
+__global__ void __launch_bounds__(256) cast_f32_16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n) {
   typedef unsigned short us8 __attribute__((ext_vector_type(8)));
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i + 8 <= n) {
@@ -27,16 +28,16 @@ __global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restr
     us8 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o[j] = __builtin_bit_cast(unsigned short, (__bf16)a[j]);
-      o[j + 4] = __builtin_bit_cast(unsigned short, (__bf16)b[j]);
+      o[j] = f32_to_us<KIND>(a[j]);
+      o[j + 4] = f32_to_us<KIND>(b[j]);
     }
     *reinterpret_cast<us8*>(y + i) = o;
   } else {
-    for (size_t j = i; j < n; ++j) y[j] = __builtin_bit_cast(unsigned short, (__bf16)x[j]);
+    for (size_t j = i; j < n; ++j) y[j] = f32_to_us<KIND>(x[j]);
   }
 }
 
-__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, size_t n) {
+__global__ void __launch_bounds__(256) cast_16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, size_t n, int kind) {
   typedef unsigned short us8 __attribute__((ext_vector_type(8)));
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i + 8 <= n) {
@@ -44,13 +45,13 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const unsigned short
     f32x4 o0, o1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o0[j] = __uint_as_float((unsigned)a[j] << 16);
-      o1[j] = __uint_as_float((unsigned)a[j + 4] << 16);
+      o0[j] = us_to_f32(a[j], kind);
+      o1[j] = us_to_f32(a[j + 4], kind);
     }
     *reinterpret_cast<f32x4*>(y + i) = o0;
     *reinterpret_cast<f32x4*>(y + i + 4) = o1;
   } else {
-    for (size_t j = i; j < n; ++j) y[j] = __uint_as_float((unsigned)x[j] << 16);
+    for (size_t j = i; j < n; ++j) y[j] = us_to_f32(x[j], kind);
   }
 }
 
@@ -61,8 +62,8 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const unsigned short
 // grid: (ceil(T / 2048), B)
 template <int K>
 __global__ void __launch_bounds__(256)
-conv_m1_bf16in_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                      float* __restrict__ y, int C, int Tin, int Tout, int dil, int pad, int in_leaky, int out_act, float slope) {
+conv_m1_x16_kernel(const unsigned short* __restrict__ x, int kind, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int C, int Tin, int Tout, int pad, int in_leaky, int out_act, float slope) {
   const int b = blockIdx.y;
   const int u = (blockIdx.x * 256 + threadIdx.x) * 8;
   const int lo = u - pad, start = lo & ~1, sh = lo - start;  // (arithmetic: -3 & ~1 = -4)
@@ -99,7 +100,7 @@ conv_m1_bf16in_kernel(const unsigned short* __restrict__ x, const float* __restr
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const unsigned d = __builtin_amdgcn_alignbit(i < 7 ? r[i + 1] : 0u, r[i], shbits);
-      const float t0 = __uint_as_float(d << 16), t1 = __uint_as_float(d & 0xffff0000u);
+      const float t0 = us_to_f32((unsigned short)(d & 0xffffu), kind), t1 = us_to_f32((unsigned short)(d >> 16), kind);
       g[2 * i] = fmaxf(t0, t0 * sl);  // (sl = 1 without the input leaky-ReLU)
       g[2 * i + 1] = fmaxf(t1, t1 * sl);
     }
@@ -129,38 +130,59 @@ conv_m1_bf16in_kernel(const unsigned short* __restrict__ x, const float* __restr
 
 }  // namespace
 
-extern "C" int vcv_conv_bf16io_plan(const VcvConvArgs* args, int flip, int64_t* out) { return plan_t<Bf16El, VCV_IO_BF16>(args, flip, out); }
+// storage combinations instantiated (conv_pk_io{3,7,11,15}.hip): all-bf16 (3), fp16 x -> bf16 y (7: the first conv of a
+// ResBlock pair, which stores leaky(xt) as the bf16 operand its only consumer feeds the matrix cores), bf16 x -> fp16 y
+// and res (11: the second conv), fp16 -> fp16 (15: the transposed convs)
+extern "C" int vcv_conv_bf16io_plan(const VcvConvArgs* args, int flip, int64_t* out) {
+  if (!args) return VCV_EINVAL;
+  switch (args->io) {
+    case 3: return vcv_conv_io_plan_3(args, flip, out);
+    case 7: return vcv_conv_io_plan_7(args, flip, out);
+    case 11: return vcv_conv_io_plan_11(args, flip, out);
+    case 15: return vcv_conv_io_plan_15(args, flip, out);
+    default: return VCV_EINVAL;
+  }
+}
 extern "C" int vcv_conv_bf16io_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid,
                                    void* stream) {
-  return run_t<Bf16El, VCV_IO_BF16>(args, pack_ws, scratch_ws, flip, pack_valid, stream);
+  if (!args) return VCV_EINVAL;
+  switch (args->io) {
+    case 3: return vcv_conv_io_run_3(args, pack_ws, scratch_ws, flip, pack_valid, stream);
+    case 7: return vcv_conv_io_run_7(args, pack_ws, scratch_ws, flip, pack_valid, stream);
+    case 11: return vcv_conv_io_run_11(args, pack_ws, scratch_ws, flip, pack_valid, stream);
+    case 15: return vcv_conv_io_run_15(args, pack_ws, scratch_ws, flip, pack_valid, stream);
+    default: return VCV_EINVAL;
+  }
 }
 
-extern "C" int vcv_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
-  if (!x || !y || n <= 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return VCV_EINVAL;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, x,
-                     (unsigned short*)y, (size_t)n);
+// kind: 1 = bf16, 2 = fp16 (the storage kinds of conv_tile.h)
+extern "C" int vcv_cast_f32_x16(const float* x, void* y, int64_t n, int kind, void* stream) {
+  if (!x || !y || n <= 0 || (kind != 1 && kind != 2) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VCV_EINVAL;
+  const dim3 grid((unsigned)((n + 2047) / 2048)), block(256);
+  if (kind == 2) hipLaunchKernelGGL(cast_f32_16_kernel<2>, grid, block, 0, (hipStream_t)stream, x, (unsigned short*)y, (size_t)n);
+  else hipLaunchKernelGGL(cast_f32_16_kernel<1>, grid, block, 0, (hipStream_t)stream, x, (unsigned short*)y, (size_t)n);
   return vcv_check_launch();
 }
 
-extern "C" int vcv_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream) {
-  if (!x || !y || n <= 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return VCV_EINVAL;
-  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)x, y, (size_t)n);
+extern "C" int vcv_cast_x16_f32(const void* x, float* y, int64_t n, int kind, void* stream) {
+  if (!x || !y || n <= 0 || (kind != 1 && kind != 2) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VCV_EINVAL;
+  hipLaunchKernelGGL(cast_16_f32_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, y, (size_t)n, kind);
   return vcv_check_launch();
 }
 
-extern "C" int vcv_conv_m1_bf16in_fwd(const void* x, const float* w, const float* bias, float* y, int B, int C, int Tin,
-                                      int Tout, int K, int dil, int pad, int in_leaky, int out_act, float slope, void* stream) {
-  if (!x || !w || !y || B <= 0 || C <= 0 || Tin <= 0 || Tout <= 0) return VCV_EINVAL;
+extern "C" int vcv_conv_m1_x16_fwd(const void* x, int kind, const float* w, const float* bias, float* y, int B, int C, int Tin,
+                                   int Tout, int K, int dil, int pad, int in_leaky, int out_act, float slope, void* stream) {
+  if (!x || !w || !y || B <= 0 || C <= 0 || Tin <= 0 || Tout <= 0 || (kind != 1 && kind != 2)) return VCV_EINVAL;
   // rows of an even number of elements (4-byte aligned), window of 8 + (K - 1) * dil + 1 <= 16 elements, dilation 1
   if ((Tin & 1) || dil != 1 || pad < 0 || Tout != Tin + 2 * pad - dil * (K - 1) || (long long)Tin * 2 >= (1ll << 31)) return VCV_EINVAL;
   dim3 grid((unsigned)vcv_cdiv(Tout, 2048), (unsigned)B), block(256);
   hipStream_t st = (hipStream_t)stream;
   const unsigned short* xs = (const unsigned short*)x;
   switch (K) {
-    case 3: hipLaunchKernelGGL(conv_m1_bf16in_kernel<3>, grid, block, 0, st, xs, w, bias, y, C, Tin, Tout, dil, pad, in_leaky, out_act, slope); break;
-    case 5: hipLaunchKernelGGL(conv_m1_bf16in_kernel<5>, grid, block, 0, st, xs, w, bias, y, C, Tin, Tout, dil, pad, in_leaky, out_act, slope); break;
-    case 7: hipLaunchKernelGGL(conv_m1_bf16in_kernel<7>, grid, block, 0, st, xs, w, bias, y, C, Tin, Tout, dil, pad, in_leaky, out_act, slope); break;
+    case 3: hipLaunchKernelGGL(conv_m1_x16_kernel<3>, grid, block, 0, st, xs, kind, w, bias, y, C, Tin, Tout, pad, in_leaky, out_act, slope); break;
+    case 5: hipLaunchKernelGGL(conv_m1_x16_kernel<5>, grid, block, 0, st, xs, kind, w, bias, y, C, Tin, Tout, pad, in_leaky, out_act, slope); break;
+    case 7: hipLaunchKernelGGL(conv_m1_x16_kernel<7>, grid, block, 0, st, xs, kind, w, bias, y, C, Tin, Tout, pad, in_leaky, out_act, slope); break;
     default: return VCV_EINVAL;
   }
   return vcv_check_launch();

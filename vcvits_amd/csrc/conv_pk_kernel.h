@@ -80,8 +80,8 @@ pack_pk_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, 
 // X4: a staging task is a 16-byte channel group x 256 positions, each lane loading FOUR consecutive positions of every
 // channel with one 16-byte buffer load (a 4x4 block that is transposed by register naming: a quarter of the load
 // instructions); otherwise x 64 positions with one dword load per channel.
-// IO (bit 0: `x` is bf16 in HBM; bit 1: `y`, `res` and the accumulate target are; only 0 and 3 = VCV_IO_BF16 are
-// instantiated): a bf16 `x` is staged in tasks of a 16-byte channel group x 512 positions, each lane loading EIGHT consecutive
+// IO (bit 0: `x` is a 16-bit tensor in HBM; bit 1: `y`, `res` and the accumulate target are; bit 2 / bit 3: that `x` / `y` is
+// fp16, else bf16; 0 in conv_pk.hip, the 16-bit combinations in conv_pk_io*.hip): a 16-bit `x` is staged in tasks of a 16-byte channel group x 512 positions, each lane loading EIGHT consecutive
 // positions of every channel with one 16-byte buffer load (rows of an even number of elements: 4-byte aligned); the 8 x 8
 // block is transposed by register naming and goes out as eight 16-byte LDS writes -- no conversion unless the input
 // leaky-ReLU is fused (then through fp32 and back, the rounding the fp32-activation path applies).
@@ -92,6 +92,7 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   constexpr int NS = NP ? NP : NW;  // staging waves
   constexpr int CPG = EL::CPG;
   constexpr bool XB = (IO & 1) != 0;
+  constexpr bool XF16 = (IO & 4) != 0;  // the 16-bit `x` is fp16 (else bf16)
   static_assert(!XB || (X4 && EL::ESZ == 2), "bf16 activations: the bf16 element type, 16-byte loads");
   constexpr int PPL = XB ? 8 : (X4 ? 4 : 1);  // consecutive positions a lane loads per channel
   typedef typename EL::frag frag;
@@ -208,11 +209,19 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
               for (int e2 = 0; e2 < 4; ++e2) {
                 const unsigned lo = __float_as_uint(xr[t][4 * (2 * e2) + (jj >> 1)]);
                 const unsigned hi = __float_as_uint(xr[t][4 * (2 * e2 + 1) + (jj >> 1)]);
-                if (LEAKY) {
-                  float f0 = __uint_as_float((jj & 1) ? (lo & 0xffff0000u) : (lo << 16));
-                  float f1 = __uint_as_float((jj & 1) ? (hi & 0xffff0000u) : (hi << 16));
-                  f0 = fmaxf(f0, f0 * p.slope);
-                  f1 = fmaxf(f1, f1 * p.slope);
+                if (LEAKY || XF16) {
+                  float f0, f1;
+                  if constexpr (XF16) {  // fp16 storage: through fp32 to the bf16 MFMA operand
+                    f0 = (float)__builtin_bit_cast(_Float16, (unsigned short)((jj & 1) ? (lo >> 16) : (lo & 0xffffu)));
+                    f1 = (float)__builtin_bit_cast(_Float16, (unsigned short)((jj & 1) ? (hi >> 16) : (hi & 0xffffu)));
+                  } else {
+                    f0 = __uint_as_float((jj & 1) ? (lo & 0xffff0000u) : (lo << 16));
+                    f1 = __uint_as_float((jj & 1) ? (hi & 0xffff0000u) : (hi << 16));
+                  }
+                  if (LEAKY) {
+                    f0 = fmaxf(f0, f0 * p.slope);
+                    f1 = fmaxf(f1, f1 * p.slope);
+                  }
                   const bf16x2 pk = {(__bf16)f0, (__bf16)f1};
                   d[e2] = __builtin_bit_cast(unsigned, pk);
                 } else {
@@ -503,7 +512,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const typename EL::frag*, float*);
   if constexpr (IO != 0) {
-    static_assert(IO == VCV_IO_BF16 && NP == 0, "bf16 activations: x, y and res together; no producer-wave variants");
+    static_assert((IO & 3) == 3 && NP == 0, "16-bit activations: x, y and res together; no producer-wave variants");
     if (pl.ppl != 8) return VCV_EINVAL;
     kern = a.in_tf == VCV_TF_LEAKY ? conv_pk_kernel<EL, TM, TN, WM, WN, true, MAXT_X4, 0, true, IO>
                                    : conv_pk_kernel<EL, TM, TN, WM, WN, false, MAXT_X4, 0, true, IO>;

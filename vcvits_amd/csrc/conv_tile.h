@@ -25,20 +25,30 @@ struct BfGeom {
 // columns (wn*TN + tn)*32 ..), `smem` the workgroup's LDS (free: the caller's main loop ended with a barrier), `part`
 // the partial-sum slabs of a split launch.  b: batch element, kz: split index, u0 / m0: first column / row of the tile,
 // oo: output row offset (phase residue included).
-// activation element i of a tensor stored as fp32 or (B16) bf16
-template <bool B16>
+// Storage kinds of an activation tensor in HBM: 0 = fp32, 1 = bf16, 2 = fp16 (IEEE half: the residual stream of the decoder
+// in bf16-activation mode -- 11 significand bits, so re-rounding the stream at every residual add costs 1/64 of the error
+// energy a bf16 stream would; values are clamped to the finite fp16 range before the conversion)
+__device__ __forceinline__ float us_to_f32(unsigned short u, int kind) {
+  return kind == 2 ? (float)__builtin_bit_cast(_Float16, u) : __uint_as_float((unsigned)u << 16);
+}
+template <int KIND>
+__device__ __forceinline__ unsigned short f32_to_us(float v) {
+  if constexpr (KIND == 2) return __builtin_bit_cast(unsigned short, (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f));
+  else return __builtin_bit_cast(unsigned short, (__bf16)v);  // round to nearest even (v_cvt_pk_bf16_f32)
+}
+template <int KIND>
 __device__ __forceinline__ float ld_act(const float* p, size_t i) {
-  if constexpr (B16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+  if constexpr (KIND != 0) return us_to_f32(reinterpret_cast<const unsigned short*>(p)[i], KIND);
   else return p[i];
 }
-template <bool B16>
+template <int KIND>
 __device__ __forceinline__ void st_act(float* p, size_t i, float v) {
-  if constexpr (B16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;  // round to nearest even (v_cvt_pk_bf16_f32)
+  if constexpr (KIND != 0) reinterpret_cast<unsigned short*>(p)[i] = f32_to_us<KIND>(v);
   else p[i] = v;
 }
 
-// IO bit 1: `y`, `res` and the accumulate target are bf16 tensors (conv_pk_io.hip); the split-reduction paths are fp32-only
-// (the planner never splits such a launch).
+// IO bit 1 (value 2): `y`, `res` and the accumulate target are 16-bit tensors (conv_pk_io*.hip) -- bf16, or fp16 with bit 3
+// (value 8); the split-reduction paths are fp32-only (the planner never splits such a launch).
 template <int TM, int TN, int IO = 0>
 __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const BfGeom& tg, f32x16 (&acc)[TM][TN], char* smem,
                                                    float* __restrict__ part, int wave, int wm, int wn, int lane, int b, int kz,
@@ -48,6 +58,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
   const int rows_valid = Mg - m0 < BM ? Mg - m0 : BM;
   const bool mtail = m0 + BM > Mg;
   constexpr bool YB = (IO & 2) != 0;
+  constexpr int YK = YB ? ((IO & 8) ? 2 : 1) : 0;  // storage kind of y / res
   if constexpr (YB) {
     if (TM * TN <= 4 && tg.vec) {
       // ---- 16-byte epilogue, bf16 output: as below, each lane taking EIGHT consecutive columns of one row (two 16-byte
@@ -88,19 +99,19 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
               if (p.res) {
                 const us8 t8 = *reinterpret_cast<const us8*>(r16 + idx);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rr[j] = __uint_as_float((unsigned)t8[j] << 16);
+                for (int j = 0; j < 8; ++j) rr[j] = us_to_f32(t8[j], YK);
               }
               if (p.accumulate) {
                 const us8 t8 = *reinterpret_cast<const us8*>(y16 + idx);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) yy[j] = __uint_as_float((unsigned)t8[j] << 16);
+                for (int j = 0; j < 8; ++j) yy[j] = us_to_f32(t8[j], YK);
               }
             } else {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 if (j < nv) {
-                  if (p.res) rr[j] = ld_act<true>(p.res, idx + j);
-                  if (p.accumulate) yy[j] = ld_act<true>(p.y, idx + j);
+                  if (p.res) rr[j] = ld_act<YK>(p.res, idx + j);
+                  if (p.accumulate) yy[j] = ld_act<YK>(p.y, idx + j);
                 }
               }
             }
@@ -118,12 +129,12 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
             if (nv == 8) {
               us8 o;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, (__bf16)v[j]);
+              for (int j = 0; j < 8; ++j) o[j] = f32_to_us<YK>(v[j]);
               *reinterpret_cast<us8*>(y16 + idx) = o;
             } else {
 #pragma unroll
               for (int j = 0; j < 8; ++j)
-                if (j < nv) st_act<true>(p.y, idx + j, v[j]);
+                if (j < nv) st_act<YK>(p.y, idx + j, v[j]);
             }
           }
         }
@@ -259,11 +270,11 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
         if (p.out_tf == VCV_TF_DLEAKY) v *= vcv_dleaky(p.oaux[idx], p.slope);
         else if (p.out_tf == VCV_TF_DRELU) v = p.oaux[idx] > 0.f ? v : 0.f;
         else if (p.out_tf == VCV_TF_DTANH) v *= 1.f - p.oaux[idx] * p.oaux[idx];
-        if (p.res) v += ld_act<YB>(p.res, idx);
+        if (p.res) v += ld_act<YK>(p.res, idx);
         v *= mk;
         if (YB && p.post_scale != 0.f) v *= p.post_scale;
-        if (p.accumulate) v += ld_act<YB>(p.y, idx);
-        st_act<YB>(p.y, idx, v);
+        if (p.accumulate) v += ld_act<YK>(p.y, idx);
+        st_act<YK>(p.y, idx, v);
       }
     }
   }

@@ -8,10 +8,34 @@ and the gradient all-reduce is a handful of large RCCL collectives over contiguo
 -- launched from post-accumulate-grad hooks as soon as a bucket is complete, i.e. overlapped
 with the rest of the backward pass.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .. import ops
+
+# gloo side channels for the host-side "received a gradient" flag exchange, one per set of ranks, shared by every optimizer
+# over that set (optim_g and optim_d of one model; a rebuilt optimizer) and destroyed by shutdown_flag_groups()
+_FLAG_GROUPS = {}
+
+
+def _flag_group(process_group):
+    ranks = tuple(dist.get_process_group_ranks(process_group if process_group is not None else dist.group.WORLD))
+    g = _FLAG_GROUPS.get(ranks)
+    if g is None:
+        g = _FLAG_GROUPS[ranks] = dist.new_group(ranks=list(ranks), backend="gloo")
+    return g
+
+
+def shutdown_flag_groups():
+    """Destroy the cached gloo side channels (before dist.destroy_process_group())."""
+    for g in _FLAG_GROUPS.values():
+        try:
+            dist.destroy_process_group(g)
+        except Exception:
+            pass
+    _FLAG_GROUPS.clear()
 
 
 class FlatAdamW:
@@ -57,15 +81,23 @@ class FlatAdamW:
         self._synced = False
         # VCVITS_FORCE_DDP=1 keeps the bucket hooks / collectives active in a 1-rank group (used to exercise
         # the RCCL path on a single-GPU box)
-        import os
         self._ddp = self.world > 1 or (os.environ.get("VCVITS_FORCE_DDP") == "1" and dist.is_initialized())
         self._flag_pg = None
+        # Static-graph mode (default; torch DDP's `static_graph` contract): once STATIC_AFTER consecutive steps had every
+        # rank report the SAME set of parameters with a gradient, the set is frozen and the per-step flag exchange -- a
+        # blocking host collective, i.e. a cross-rank host barrier twice per batch -- is skipped; a later step whose local
+        # set differs raises (the other ranks no longer take part in an exchange).  VCVITS_DDP_STATIC=0 exchanges every step.
+        self._static_ok = os.environ.get("VCVITS_DDP_STATIC", "1") == "1"
+        self._static_set = None
+        self._agree_steps = 0
+        self.flag_exchanges = 0  # (observable: tests / bench)
         if self._ddp:
             self._make_buckets(int(bucket_mb * 1024 * 1024 / 4))
             # the per-parameter "received a gradient" flags are OR-ed across ranks on the HOST (finish_grad_sync): over
             # RCCL that would be a device round trip -- a host sync in the middle of the step (measured: -5 % on one rank)
-            # -- so GPU groups get a gloo side channel for this 400-byte reduction; CPU (gloo) groups use their own
-            self._flag_pg = dist.new_group(backend="gloo") if dist.get_backend(process_group) == "nccl" else process_group
+            # -- so GPU groups get a gloo side channel (over the SAME ranks, shared between optimizers) for this small
+            # reduction; CPU (gloo) groups use their own
+            self._flag_pg = _flag_group(process_group) if dist.get_backend(process_group) == "nccl" else process_group
         # One post-accumulate hook per parameter: marks the parameter as "received a gradient in this pass"
         # (torch.optim.AdamW skips parameters whose .grad is None -- no decay, no moment update, no step count)
         # and, under data parallelism, counts its bucket down.  The handles are kept so a rebuilt optimizer can
@@ -149,9 +181,27 @@ class FlatAdamW:
         # averaged gradient everywhere: every rank must apply the same update, so the "received a gradient" flags are
         # OR-ed across the group (torch DDP reduces its used-parameter bitmap for the same reason).
         if self._ddp:  # (also in a forced 1-rank group, so that the single-GPU tests run this collective)
-            flags = torch.tensor(list(self._touched), dtype=torch.uint8)  # host tensor, gloo: no device sync
+            if self._static_set is not None:
+                if bytes(self._touched) != self._static_set:
+                    raise RuntimeError("FlatAdamW: the set of parameters that received a gradient changed after it was "
+                                       "frozen (static-graph mode); set VCVITS_DDP_STATIC=0 for models whose used-parameter "
+                                       "set varies from step to step")
+                return
+            n = len(self._touched)
+            # one MAX all-reduce of [flags, 1 - flags]: the first half is the OR over ranks, the second half NOT(AND) --
+            # OR == AND means every rank saw the same set
+            local = list(self._touched)
+            flags = torch.tensor(local + [1 - f for f in local], dtype=torch.uint8)  # host tensor, gloo: no device sync
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._flag_pg)
-            self._touched[:] = bytes(flags.tolist())
+            self.flag_exchanges += 1
+            out = flags.tolist()
+            self._touched[:] = bytes(out[:n])
+            same = all(o == 1 - a for o, a in zip(out[:n], out[n:]))
+            self._agree_steps = self._agree_steps + 1 if same else 0
+            if self._static_ok and self._agree_steps >= self.STATIC_AFTER:
+                self._static_set = bytes(self._touched)
+
+    STATIC_AFTER = 2  # steps of cross-rank agreement before the used-parameter set is frozen
 
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -195,9 +245,13 @@ class FlatAdamW:
         self.lr = float(lr)
         self.param_groups[0]["lr"] = self.lr
 
-    def set_epoch(self, epoch, gamma):
-        """Closed form of ExponentialLR after `epoch` epoch-end steps from the base rate."""
-        self.set_lr(self.base_lr * (gamma ** epoch))
+    def set_epoch(self, epoch, gamma, reference_stack=None):
+        """Closed form of ExponentialLR after `epoch` epoch-end steps from the base rate, in the same mode as the
+        ExponentialLR class below (reference_stack: the first epoch-end step of a fresh run does not decay)."""
+        if reference_stack is None:
+            reference_stack = ExponentialLR.DEFAULT_REFERENCE_STACK
+        e = max(epoch - 1, 0) if reference_stack else epoch
+        self.set_lr(self.base_lr * (gamma ** e))
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
@@ -231,12 +285,20 @@ class ExponentialLR:
     gamma, so after a resume the rate continues from whatever the restored optimizer state holds (and from the
     base rate when that state was dropped -- exactly what the reference does)."""
 
-    def __init__(self, optimizer, gamma, last_epoch=-1, reference_stack=True):
-        """reference_stack=True follows the scheduler of the reference's PINNED stack (requirements.txt: lightning 2.0.x on
-        torch 2.0.x), whose `get_lr` returns the rate unchanged when `last_epoch == 0`: after the reference re-seats
-        `last_epoch = current_epoch - 1 = -1` on a fresh run, the first epoch-end step therefore does NOT decay, and the
-        rate after e >= 1 epochs is base * gamma^(e - 1).  False: torch >= 2.2 (`_is_initial`), every step decays."""
+    # VCVITS_LR_REFERENCE_STACK=0 / hparams train.lr_reference_stack=False select the torch >= 2.2 behaviour
+    DEFAULT_REFERENCE_STACK = os.environ.get("VCVITS_LR_REFERENCE_STACK", "1") == "1"
+
+    def __init__(self, optimizer, gamma, last_epoch=-1, reference_stack=None):
+        """reference_stack=True (default) follows the scheduler of the stack the reference was written for: its
+        requirements pin lightning==2.0.0 (requirements.txt) and torch==2.0.0 (requirements_torch.txt:1),
+        whose `ExponentialLR.get_lr` returns the rate unchanged when `last_epoch == 0`: after the reference re-seats
+        `last_epoch = current_epoch - 1 = -1` on a fresh run (vcvits.py:258-261), the first epoch-end step therefore does
+        NOT decay, and the rate after e >= 1 epochs is base * gamma^(e - 1).  False: torch >= 2.2 (`_is_initial`; the torch
+        installed HERE is 2.10): every step decays, base * gamma^e.  None: the process default (environment
+        VCVITS_LR_REFERENCE_STACK, or `train.lr_reference_stack` in the hparams via VCVITS.configure_optimizers)."""
         self.optimizer, self.gamma = optimizer, float(gamma)
+        if reference_stack is None:
+            reference_stack = ExponentialLR.DEFAULT_REFERENCE_STACK
         self.reference_stack = bool(reference_stack)
         self.last_epoch = last_epoch + 1  # torch's constructor performs the initial step: rate unchanged
         self._last_lr = [optimizer.lr]

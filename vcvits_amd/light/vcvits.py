@@ -198,9 +198,11 @@ class VCVITS(nn.Module):
                                  t.learning_rate, betas=t.betas, eps=t.eps, process_group=process_group)
         # vcvits.py:258-261: ExponentialLR per optimizer with last_epoch re-seated to current_epoch - 1 (the rate
         # itself starts at learning_rate; a resume restores it with the optimizer state)
-        self.scheduler_g = ExponentialLR(self.optim_g, gamma=t.lr_decay)
+        # (`train.lr_reference_stack` in the hparams selects the scheduler semantics: see ExponentialLR)
+        ref_stack = t.get("lr_reference_stack", None) if hasattr(t, "get") else getattr(t, "lr_reference_stack", None)
+        self.scheduler_g = ExponentialLR(self.optim_g, gamma=t.lr_decay, reference_stack=ref_stack)
         self.scheduler_g.last_epoch = self.current_epoch - 1
-        self.scheduler_d = ExponentialLR(self.optim_d, gamma=t.lr_decay)
+        self.scheduler_d = ExponentialLR(self.optim_d, gamma=t.lr_decay, reference_stack=ref_stack)
         self.scheduler_d.last_epoch = self.current_epoch - 1
         return [self.optim_g, self.optim_d], [self.scheduler_g, self.scheduler_d]
 

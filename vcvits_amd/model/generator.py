@@ -39,25 +39,29 @@ class Generator(nn.Module):
             m.weight_v.data.normal_(0.0, 0.01)
 
     def _forward_bf16_activations(self, x, g):
-        """Inference in bf16 mode: every conv <-> conv tensor between conv_pre and conv_post lives in bf16 in HBM (the
-        reference's autocast does the same to every conv output: train.py:104-106), the mean over a stage's three
-        ResBlocks is accumulated by their last convs (post_scale 1/3) and conv_post reads bf16.  Arithmetic: operands
-        rounded to bf16 as in the fp32-activation path, fp32 accumulate and epilogue, one rounding per stored tensor."""
+        """Inference in bf16 mode: every conv <-> conv tensor between conv_pre and conv_post lives in 16 bits in HBM (the
+        reference's autocast does the same to every conv output: train.py:104-106).  The residual stream (stage inputs,
+        ResBlock inputs / outputs, the accumulated stage mean) is stored as fp16 -- re-rounded at every residual add, it
+        needs the 11 significand bits to stay below the operand rounding; the tensor between the two convs of a pair is
+        stored as the bf16 matrix-core operand itself (after the leaky-ReLU its only consumer applies).  The mean over a
+        stage's three ResBlocks is accumulated by their last convs (post_scale 1/3) and conv_post reads the stream.
+        Arithmetic: bf16 MFMA operands, fp32 accumulate and epilogue, as in the fp32-activation path."""
+        stream = torch.float16
         x = self.conv_pre(x)
         if g is not None:
             x = x + self.cond(g)
-        x = ops.cast_bf16(x)
+        x = ops.cast_x16(x, stream)
         nk = self.num_kernels
         for i in range(self.num_upsamples):
             up = self.ups[i]
-            x = ops.convT_forward_bf16io(x, up.effective_weight(), up.bias, stride=up.stride, pad=up.padding, in_leaky=True,
-                                         slope=LRELU_SLOPE)
+            x = ops.convT_forward_x16(x, up.effective_weight(), up.bias, stride=up.stride, pad=up.padding, in_leaky=True,
+                                      slope=LRELU_SLOPE, out_dtype=stream)
             acc = None
             for j in range(nk):
-                acc = self.resblocks[i * nk + j].forward_bf16_activations(x, acc, 1.0 / nk)
+                acc = self.resblocks[i * nk + j].forward_x16(x, acc, 1.0 / nk)
             x = acc
         cp = self.conv_post
-        return ops.conv_m1_bf16in(x, cp.effective_weight(), cp.bias, pad=cp.padding, in_leaky=True, slope=0.01, out_act=ACT_TANH)
+        return ops.conv_m1_x16(x, cp.effective_weight(), cp.bias, pad=cp.padding, in_leaky=True, slope=0.01, out_act=ACT_TANH)
 
     def forward(self, x, g=None):
         modules.prepare_weight_norm(self)

@@ -227,20 +227,22 @@ class ResBlock1(nn.Module):
             x = c2(xt, in_leaky=True, slope=LRELU_SLOPE, res=x, link=(link, "src") if link else None)
         return x
 
-    def forward_bf16_activations(self, x, acc, scale):
-        """Inference over bf16 activations (ops.conv_forward_bf16io): x bf16 [B, C, T]; the block's output times `scale`
-        is ADDED onto `acc` (created when None) by the last conv's epilogue -- the stage mean of the generator without a
-        pass over three stored outputs.  c1 stores leaky(xt) (its only consumer is c2's fused input leaky-ReLU), so c2
-        stages its operand without any conversion."""
+    def forward_x16(self, x, acc, scale):
+        """Inference over 16-bit activations (ops.conv_forward_x16): x is the residual stream (fp16 [B, C, T]); the block's
+        output times `scale` is ADDED onto `acc` (created when None) by the last conv's epilogue -- the stage mean of the
+        generator without a pass over three stored outputs.  c1 stores leaky(xt) in bf16 (its only consumer is c2's fused
+        input leaky-ReLU followed by the rounding to the bf16 operand), so c2 stages its operand without any conversion
+        and the result is the fp32-activation path's, rounding for rounding."""
         n = len(self.convs1)
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
-            xt = ops.conv_forward_bf16io(x, c1.effective_weight(), c1.bias, pad=c1.padding, dil=c1.dilation, in_leaky=True,
-                                         out_act=ACT_LEAKY, slope=LRELU_SLOPE)
+            xt = ops.conv_forward_x16(x, c1.effective_weight(), c1.bias, pad=c1.padding, dil=c1.dilation, in_leaky=True,
+                                      out_act=ACT_LEAKY, slope=LRELU_SLOPE, out_dtype=torch.bfloat16)
             if i < n - 1:
-                x = ops.conv_forward_bf16io(xt, c2.effective_weight(), c2.bias, pad=c2.padding, dil=c2.dilation, res=x)
+                x = ops.conv_forward_x16(xt, c2.effective_weight(), c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
+                                         out_dtype=x.dtype)
             else:
-                acc = ops.conv_forward_bf16io(xt, c2.effective_weight(), c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
-                                              out=acc, accumulate=acc is not None, post_scale=scale)
+                acc = ops.conv_forward_x16(xt, c2.effective_weight(), c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
+                                           out=acc, accumulate=acc is not None, post_scale=scale, out_dtype=x.dtype)
         return acc
 
 

@@ -159,8 +159,10 @@ def _launch_conv(a, flip_w=None):
                     # in one launch (_replay_packs)
                     if len(_PACK_JOBS) > 64:
                         _PACK_JOBS.clear()
-                    _PACK_JOBS.setdefault(ent["key"], {})[(a.w - ent["lo"], int(plan[0]), int(plan[2]), name)] = \
-                        (bytes(a), flip)
+                    jobs = _PACK_JOBS.get(ent["key"])
+                    if jobs is None or jobs["shapes"] != ent["shapes"]:  # (a recycled address set is another module's)
+                        jobs = _PACK_JOBS[ent["key"]] = {"shapes": ent["shapes"], "jobs": {}}
+                    jobs["jobs"][(a.w - ent["lo"], int(plan[0]), int(plan[2]), name)] = (bytes(a), flip)
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
             check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
             LAUNCH_COUNTS[_FAMILY_KEY.get(name, "dma")] += 1
@@ -433,42 +435,55 @@ def convT_forward(x, w, bias=None, stride=1, pad=0, out=None, **kw):
     return out
 
 
-# ---- bf16 activations in HBM (inference decoder; no autograd) -----------------------------------------------------------
-def _bf16t(t, what):
+# ---- 16-bit activations in HBM (inference decoder; no autograd) ---------------------------------------------------------
+# Storage kinds: torch.bfloat16 (an MFMA operand as it is: the tensor between the two convs of a ResBlock pair, stored
+# after the leaky-ReLU its consumer would apply) and torch.float16 (the residual stream: 11 significand bits, so the
+# re-rounding at every residual add stays far below the operand rounding; the reference's autocast stores fp16 too).
+_KIND = {torch.bfloat16: 1, torch.float16: 2}
+
+
+def _x16(t, what):
     if t is None:
         return None
-    if t.dtype != torch.bfloat16 or not t.is_contiguous():
-        raise RuntimeError("vcvits_amd: %s must be a contiguous bf16 tensor" % what)
+    if t.dtype not in _KIND or not t.is_contiguous():
+        raise RuntimeError("vcvits_amd: %s must be a contiguous bf16 / fp16 tensor" % what)
     return t
 
 
-def cast_bf16(x):
-    """fp32 -> bf16 (round to nearest even), same shape."""
+def _io_bits(x, y):
+    return 3 | (4 if x.dtype == torch.float16 else 0) | (8 if y.dtype == torch.float16 else 0)
+
+
+def cast_x16(x, dtype=torch.bfloat16):
+    """fp32 -> bf16 / fp16 (round to nearest even; fp16 clamps to its finite range), same shape."""
     x = _f32c(x)
-    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
-    check(lib().vcv_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()), "vcv_cast_f32_bf16")
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib().vcv_cast_f32_x16(ptr(x), ptr(y), x.numel(), _KIND[dtype], stream()), "vcv_cast_f32_x16")
     return y
 
 
 def cast_f32(x):
-    x = _bf16t(x, "x")
+    x = _x16(x, "x")
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    check(lib().vcv_cast_bf16_f32(ptr(x), ptr(y), x.numel(), stream()), "vcv_cast_bf16_f32")
+    check(lib().vcv_cast_x16_f32(ptr(x), ptr(y), x.numel(), _KIND[x.dtype], stream()), "vcv_cast_x16_f32")
     return y
 
 
-def conv_forward_bf16io(x, w, bias=None, stride=1, pad=0, dil=1, in_leaky=False, out_act=ACT_NONE, slope=0.1, res=None,
-                        out=None, accumulate=False, post_scale=0.0):
-    """conv_forward over bf16 activations: x / res / out are bf16 [B, C, T]; w / bias fp32.  With `out` given and
-    accumulate=True the result is added onto it; post_scale multiplies (conv + bias + res) first (0 = none)."""
-    x, res, out = _bf16t(x, "x"), _bf16t(res, "res"), _bf16t(out, "out")
+def conv_forward_x16(x, w, bias=None, stride=1, pad=0, dil=1, in_leaky=False, out_act=ACT_NONE, slope=0.1, res=None,
+                     out=None, accumulate=False, post_scale=0.0, out_dtype=torch.bfloat16):
+    """conv_forward over 16-bit activations: x is bf16 / fp16 [B, C, T]; res / out share one 16-bit dtype (out_dtype when
+    `out` is created here); w / bias fp32.  With `out` given and accumulate=True the result is added onto it; post_scale
+    multiplies (conv + bias + res) first (0 = none)."""
+    x, res, out = _x16(x, "x"), _x16(res, "res"), _x16(out, "out")
     B, C, Tin, P = _rows(x)
     M, Cg, K = w.shape[0], w.shape[1], w.shape[2]
     if Cg != C:
-        raise RuntimeError("conv_forward_bf16io: channel mismatch")
+        raise RuntimeError("conv_forward_x16: channel mismatch")
     Tout = conv_out_len(Tin, K, stride, pad, dil)
     if out is None:
-        out = torch.empty((B, M, Tout) if x.dim() == 3 else (B, M, Tout, P), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty((B, M, Tout) if x.dim() == 3 else (B, M, Tout, P), device=x.device, dtype=out_dtype)
+    if res is not None and res.dtype != out.dtype:
+        raise RuntimeError("conv_forward_x16: res and out must share their storage type")
     a = VcvConvArgs()
     a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, 1, Cg, M
@@ -476,20 +491,20 @@ def conv_forward_bf16io(x, w, bias=None, stride=1, pad=0, dil=1, in_leaky=False,
     a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = stride, dil, -pad, 1, 0, 1, Tout, 0
     _common(a, bias=_f32c(bias), res=res, in_tf=TF_LEAKY if in_leaky else TF_NONE, out_act=out_act, slope=slope,
             accumulate=accumulate)
-    a.io, a.post_scale = 3, float(post_scale)
+    a.io, a.post_scale = _io_bits(x, out), float(post_scale)
     _launch_conv(a)
     return out
 
 
-def convT_forward_bf16io(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.1):
-    """convT_forward over bf16 activations (x, result: bf16; w [Cin, Cout, K] / bias fp32)."""
-    x = _bf16t(x, "x")
+def convT_forward_x16(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.1, out_dtype=torch.bfloat16):
+    """convT_forward over 16-bit activations (x, result: bf16 / fp16; w [Cin, Cout, K] / bias fp32)."""
+    x = _x16(x, "x")
     B, C, Tin, P = _rows(x)
     Cin, M, K = w.shape
     if Cin != C:
-        raise RuntimeError("convT_forward_bf16io: channel mismatch")
+        raise RuntimeError("convT_forward_x16: channel mismatch")
     Tout = convT_out_len(Tin, K, stride, pad)
-    out = torch.empty((B, M, Tout), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((B, M, Tout), device=x.device, dtype=out_dtype)
     a = VcvConvArgs()
     a.x, a.w, a.y = ptr(x), ptr(w), ptr(out)
     a.B, a.G, a.Cg, a.Mg = B, 1, C, M
@@ -501,20 +516,20 @@ def convT_forward_bf16io(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope
         a.s, a.dj, a.off, a.os, a.oo, a.phases = 1, -1, 0, stride, -pad, stride
         a.Q = (Tout - 1 + pad) // stride + 1
     _common(a, bias=_f32c(bias), in_tf=TF_LEAKY if in_leaky else TF_NONE, slope=slope)
-    a.io = 3
+    a.io = _io_bits(x, out)
     _launch_conv(a)
     return out
 
 
-def conv_m1_bf16in(x, w, bias=None, pad=0, in_leaky=False, out_act=ACT_NONE, slope=0.1):
-    """One-output-channel conv (stride 1, dilation 1) over a bf16 [B, C, T] input -> fp32 [B, 1, Tout]."""
-    x = _bf16t(x, "x")
+def conv_m1_x16(x, w, bias=None, pad=0, in_leaky=False, out_act=ACT_NONE, slope=0.1):
+    """One-output-channel conv (stride 1, dilation 1) over a 16-bit [B, C, T] input -> fp32 [B, 1, Tout]."""
+    x = _x16(x, "x")
     B, C, Tin = x.shape
     K = w.shape[2]
     Tout = conv_out_len(Tin, K, 1, pad, 1)
     y = torch.empty((B, 1, Tout), device=x.device, dtype=torch.float32)
-    check(lib().vcv_conv_m1_bf16in_fwd(ptr(x), ptr(_f32c(w)), ptr(_f32c(bias)), ptr(y), B, C, Tin, Tout, K, 1, pad,
-                                       1 if in_leaky else 0, out_act, slope, stream()), "vcv_conv_m1_bf16in_fwd")
+    check(lib().vcv_conv_m1_x16_fwd(ptr(x), _KIND[x.dtype], ptr(_f32c(w)), ptr(_f32c(bias)), ptr(y), B, C, Tin, Tout, K, 1, pad,
+                                    1 if in_leaky else 0, out_act, slope, stream()), "vcv_conv_m1_x16_fwd")
     return y
 
 
@@ -978,12 +993,23 @@ _PACK_FILL = {"vcv_conv_x3_run": "vcv_conv_x3_pack_job", "vcv_conv_pk_run": "vcv
 
 def _replay_packs(key, ent):
     """Make every recorded pack of parameter set `key` for its freshly normalised weights `ent` (one launch)."""
-    jobs = _PACK_JOBS.get(key)
-    if not jobs or not _PACK_BATCH[0]:
+    rec = _PACK_JOBS.get(key)
+    if not rec or not _PACK_BATCH[0]:
+        return
+    if rec["shapes"] != ent["shapes"]:
+        # the same addresses now hold another module's parameters: its jobs would read outside the new buffer
+        del _PACK_JOBS[key]
         return
     from ._lib import VcvPackJob
     L = lib()
-    todo = [(k, v) for k, v in jobs.items() if k[3] in _PACK_FILL]
+    # only the families the current switches can launch (a job of another arithmetic would be packed for nothing)
+    live = {"vcv_conv_pk_run"} if _USE_PK[0] else set()
+    if _COMPUTE[0] == "bf16":
+        live.add("vcv_conv_bf16_run")
+    elif _USE_X3[0]:
+        live.add("vcv_conv_x3_run")
+    span = ent["hi"] - ent["lo"]
+    todo = [(k, v) for k, v in rec["jobs"].items() if k[3] in _PACK_FILL and k[3] in live]
     if not todo:
         return
     arr = (VcvPackJob * len(todo))()
@@ -994,6 +1020,8 @@ def _replay_packs(key, ent):
     reg = []
     for (woff, words, sig, fam), (abytes, flip) in todo:
         a = VcvConvArgs.from_buffer_copy(abytes)
+        if woff < 0 or woff + 4 * a.Mg * a.Cg * a.K > span:
+            continue
         a.w = ent["lo"] + woff
         if getattr(L, _PACK_FILL[fam])(ctypes.byref(a), flip, ctypes.byref(arr[n])) != 0:
             continue  # (the plan no longer takes this launch, e.g. a mode switch: it will pack lazily)
@@ -1056,7 +1084,8 @@ def _wn_forward_all(vg, n):
                 _WN_CACHE.clear()
             import weakref
             ent = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
-                       lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={}, key=key)
+                       lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={}, key=key,
+                       shapes=tuple(tuple(t.shape) for t in vg))
             _WN_CACHE[key] = ent
             _replay_packs(key, ent)
     h = _WnHolder()
