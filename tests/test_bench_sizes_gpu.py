@@ -1,0 +1,257 @@
+"""GPU: parity AT THE BENCHMARKED SIZES.  Tile choice, split reductions and batch folding depend on B x positions, so the
+shapes bench.py times must be the shapes a test has checked:
+  * BASELINE configs[2] -- configs/base.json full SynthesizerSVC + MPD + MSD at B = 32 x 384 frames: (a) in the fp32
+    arithmetic, one whole G step + D step against the CPU oracle AT B = 32 (losses and every parameter gradient); (b) in
+    bf16 mode (the timed arithmetic), batch row b of the B = 32 pass against the B = 1 pass of row b -- forward outputs and
+    the parameter gradients of a probe loss on that row -- plus the bf16 step's losses against the fp32 oracle's;
+  * BASELINE configs[4] -- 48 kHz inference at B = 64 x 938 frames in bf16 mode: rows of the batch against their B = 1 runs
+    and against the fp32 oracle (waveform RMS <= 1e-3, north_star).
+Reference: vits/light/vcvits.py:54-183 (training_step), vits/model/synthesizers/synthesizer_svc.py:70-109."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import close_kinked, fill_state_dict, keys_shapes_of, record_stats
+
+pytestmark = pytest.mark.gpu
+
+ROWS = (3, 29)
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _sub(batch, b):
+    return {k: v[b:b + 1].contiguous() for k, v in batch.items()}
+
+
+def _full_batch(cfg, B, seed, dev="cpu"):
+    from vcvits_amd import synthetic
+    m = cfg["model"]
+    batch = synthetic.full_batch(B, m["hubert_channels"], seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    batch["noise"] = torch.randn(B, m["inter_channels"], 384, generator=g)
+    lens = (batch["y_wav_lengths"] // cfg["data"]["hop_length"]).long()
+    seg = cfg["train"]["segment_size"] // cfg["data"]["hop_length"]
+    batch["ids_slice"] = (torch.rand(B, generator=g) * (lens - seg + 1).float()).long()
+    return {k: v.to(dev) for k, v in batch.items()}
+
+
+def test_config2_full_step_B32_vs_oracle_f32(gpu):
+    """configs[2]'s shapes in the fp32 arithmetic: one G step + D step at B = 32 against the CPU oracle at B = 32."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import configs
+    from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS
+    torch.manual_seed(2)
+    cfg = configs.base()
+    cfg["model"]["p_dropout"] = 0.0  # (the dropout draws are compared with regenerated masks in tests/test_dropout_step_gpu.py)
+    module = VCVITS(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, DEFAULT_PERIODS, vocoder_only=False)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    batch = _full_batch(cfg, 32, seed=77)
+    torch.set_num_threads(16)  # (bench.py's thread sweep: the oracle is fastest at 16 threads on the GPU box's host)
+    lg, ld = trainer.batch(batch)
+    names = {id(p): n for n, p in module.named_parameters()}
+    grads = {}
+
+    def probe(idx, opt):
+        for p in opt.params:
+            grads[names[id(p)]] = p.grad.detach().cpu().clone()
+
+    out = module.fit_batch({k: v.to(gpu) for k, v in batch.items()}, after_backward=probe)
+    for a, b, n in zip((out["g"], out["d"]), (lg, ld), ("loss_g", "loss_d")):
+        assert abs(float(a) - float(b)) <= 2e-4 * abs(float(b)) + 1e-5, (n, float(a), float(b))
+    ref = dict(trainer.grads_g)
+    ref.update(trainer.grads_d)
+    tops = {}
+    for kk, v in ref.items():
+        tops[kk.split(".")[0]] = max(tops.get(kk.split(".")[0], 0.0), float(v.abs().max()))
+    for k, b in ref.items():
+        close_kinked("B32/" + k, grads[k], b, tol=5e-4, floor=2e-6 * tops[k.split(".")[0]])
+
+
+def _generator_probe(module, batch, row, R):
+    """net_g forward on `batch`; probe loss on batch row `row`; returns (outputs of that row, parameter gradients)."""
+    for p in module.net_g.parameters():
+        p.grad = None
+    y_hat, y, y_mel_slice, (z_p, logs_q, m_p, logs_p, z_mask) = module._generator_pass(batch)
+    outs = {"y_hat": y_hat[row], "z_p": z_p[row], "logs_q": logs_q[row], "m_p": m_p[row], "logs_p": logs_p[row]}
+    loss = sum((outs[k] * R[k]).sum() for k in outs)
+    loss.backward()
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in module.net_g.named_parameters()}
+    return {k: v.detach().clone() for k, v in outs.items()}, grads, y.detach(), y_hat.detach()
+
+
+def _disc_probe(module, y, y_hat, row, seed):
+    for net in (module.net_period_d, module.net_scale_d):
+        for p in net.parameters():
+            p.grad = None
+    outs = []
+    for net in (module.net_period_d, module.net_scale_d):
+        rs, gs, frs, fgs = net(y, y_hat)
+        for lst in (rs, gs):
+            outs += [t[row] for t in lst]
+        for fl in (frs, fgs):
+            for fm in fl:
+                outs += [t[row] for t in fm]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    loss = 0.0
+    for t in outs:
+        r = torch.randn(t.shape, generator=g).to(t.device)
+        loss = loss + (t * r).sum() / max(1, t.numel()) ** 0.5
+    loss.backward()
+    grads = {}
+    for prefix, net in (("p.", module.net_period_d), ("s.", module.net_scale_d)):
+        for n, p in net.named_parameters():
+            grads[prefix + n] = p.grad.detach().clone() if p.grad is not None else None
+    return [t.detach().clone() for t in outs], grads
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config2_batch_rows_equal_single_runs(gpu, dtype):
+    """configs[2] (B = 32 x 384 frames): row b of the batched pass == the B = 1 pass of row b, forward and backward; in the
+    bf16 arithmetic bench.py times (differences: fp32 summation order, then 2^-9 wherever a rounding flips) and in fp32."""
+    from vcvits_amd import configs, ops
+    from vcvits_amd.light.vcvits import VCVITS
+    torch.manual_seed(3)
+    cfg = configs.base()
+    cfg["model"]["p_dropout"] = 0.0
+    module = VCVITS(**cfg).to(gpu)
+    # plain autograd accumulation (no optimizer: no gradient sinks, parameters keep their own .grad)
+    batch = _full_batch(cfg, 32, seed=78, dev=gpu)
+    tol_out, tol_grad = (2e-5, 5e-4) if dtype == "f32" else (1e-2, 4e-2)
+    ops.set_compute_dtype(dtype)
+    try:
+        before = dict(ops.LAUNCH_COUNTS)
+        rng = torch.Generator().manual_seed(5)
+        m = cfg["model"]
+        seg = cfg["train"]["segment_size"]
+        R = {"y_hat": torch.randn(1, seg, generator=rng), "z_p": torch.randn(m["inter_channels"], 384, generator=rng),
+             "logs_q": torch.randn(m["inter_channels"], 384, generator=rng), "m_p": torch.randn(m["inter_channels"], 384, generator=rng),
+             "logs_p": torch.randn(m["inter_channels"], 384, generator=rng)}
+        R = {k: v.to(gpu) for k, v in R.items()}
+        for row in ROWS:
+            o32, g32, y32, yh32 = _generator_probe(module, batch, row, R)
+            o1, g1, y1, yh1 = _generator_probe(module, _sub(batch, row), 0, R)
+            for k in o32:
+                e = _rel_l2(o32[k], o1[k])
+                record_stats("rows", "cfg2/%s/gen/%s" % (dtype, k), rel_l2=e)
+                assert e <= tol_out, (dtype, row, k, e)
+            num = den = 0.0
+            for n in g32:
+                if g32[n] is None or g1[n] is None:
+                    assert g32[n] is None and g1[n] is None, n
+                    continue
+                num += (g32[n].double() - g1[n].double()).pow(2).sum().item()
+                den += g1[n].double().pow(2).sum().item()
+            e = (num / den) ** 0.5
+            record_stats("rows", "cfg2/%s/gen/grads" % dtype, rel_l2=e)
+            assert e <= tol_grad, (dtype, row, "net_g gradients", e)
+            # discriminators: stacked (y, y_hat) of the B = 32 pass, probe on row b
+            d32, gd32 = _disc_probe(module, y32, yh32, row, seed=9)
+            d1, gd1 = _disc_probe(module, y32[row:row + 1].contiguous(), yh32[row:row + 1].contiguous(), 0, seed=9)
+            for i, (a, b) in enumerate(zip(d32, d1)):
+                e = _rel_l2(a, b)
+                assert e <= tol_out * (5 if dtype == "bf16" else 1), (dtype, row, "disc output %d" % i, e)
+            num = den = 0.0
+            for n in gd32:
+                if gd32[n] is None:
+                    continue
+                num += (gd32[n].double() - gd1[n].double()).pow(2).sum().item()
+                den += gd1[n].double().pow(2).sum().item()
+            e = (num / den) ** 0.5
+            record_stats("rows", "cfg2/%s/disc/grads" % dtype, rel_l2=e)
+            # (fp32: the two passes sum in different orders, so a few of the ~1e7 leaky-ReLU pre-activations of a row land
+            # on different sides of zero -- golden_util.close_kinked; observed 5.4e-4)
+            assert e <= (2e-3 if dtype == "f32" else tol_grad), (dtype, row, "discriminator gradients", e)
+        if dtype == "bf16":
+            assert ops.LAUNCH_COUNTS["bf16"] - before["bf16"] > 500 and ops.LAUNCH_COUNTS["wgrad_bf16"] - before["wgrad_bf16"] > 100
+    finally:
+        ops.set_compute_dtype("f32")
+
+
+def test_config2_bf16_step_losses_B32(gpu):
+    """The timed configs[2] step itself (bf16 mode, B = 32): losses within the bf16 bound (2e-3) of the fp32 CPU oracle
+    run on the same 32 utterances."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import configs, ops
+    from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VCVITS
+    torch.manual_seed(4)
+    cfg = configs.base()
+    cfg["model"]["p_dropout"] = 0.0
+    module = VCVITS(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, DEFAULT_PERIODS, vocoder_only=False)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    batch = _full_batch(cfg, 32, seed=79)
+    torch.set_num_threads(16)
+    lg, ld = trainer.batch(batch)
+    ops.set_compute_dtype("bf16")
+    try:
+        out = module.fit_batch({k: v.to(gpu) for k, v in batch.items()})
+    finally:
+        ops.set_compute_dtype("f32")
+    for a, b, n in zip((out["g"], out["d"]), (lg, ld), ("loss_g", "loss_d")):
+        assert abs(float(a) - float(b)) <= 2e-3 * abs(float(b)) + 1e-5, (n, float(a), float(b))
+
+
+def test_config4_inference_B64_rows(gpu):
+    """configs[4] (48 kHz, B = 64 x 938 frames, bf16 mode with 16-bit activations): rows of the batched decode against their
+    B = 1 runs and against the fp32 oracle (waveform RMS <= 1e-3; weights with content: signal RMS >= 0.1)."""
+    from oracle import vits_oracle as O
+    from vcvits_amd import configs, ops
+    from vcvits_amd.model.synthesizers.synthesizer_svc import SynthesizerSVC
+    cfg = configs.base_48k()
+    d, m = cfg["data"], cfg["model"]
+    net = SynthesizerSVC(d["filter_length"] // 2 + 1, 32, n_speakers=d["n_speakers"], **m).eval()
+    sd0 = fill_state_dict(keys_shapes_of(net), seed=6)
+    net.load_state_dict(sd0)
+    sd = {"n." + k: v for k, v in sd0.items()}
+    net = net.to(gpu)
+    C, H, T, B = m["inter_channels"], m["hidden_channels"], 938, 64
+    g = torch.Generator().manual_seed(1234)
+    m_p = torch.randn(B, C, T, generator=g)
+    logs_p = torch.randn(B, C, T, generator=g) * 0.1 - 1.0
+    noise = torch.randn(B, C, T, generator=g)
+    sid = torch.randint(0, d["n_speakers"], (B,), generator=g)
+    mask = torch.ones(B, 1, T)
+    rms = lambda a, b: ((a.detach().cpu().double() - b.double()) ** 2).mean().sqrt().item()
+    ops.set_compute_dtype("bf16")
+    try:
+        with torch.no_grad():
+            def run(sl):
+                spk = net.emb_g(sid[sl].to(gpu)).unsqueeze(-1)
+                z_p = ops.prior_sample(m_p[sl].to(gpu), logs_p[sl].to(gpu), noise[sl].to(gpu), 1.0)
+                z = net.flow(z_p, mask[sl].to(gpu), g=spk, reverse=True)
+                return net.dec(ops.mask_mul(z, mask[sl].to(gpu).reshape(z.shape[0], -1)))
+            before = ops.LAUNCH_COUNTS["bf16io"]
+            o64 = run(slice(0, B))
+            assert ops.LAUNCH_COUNTS["bf16io"] - before == 76
+            assert tuple(o64.shape) == (B, 1, T * d["hop_length"])
+            for row in (5, 41):
+                o1 = run(slice(row, row + 1))
+                # B = 64 and B = 1 choose different tiles, i.e. other fp32 summation orders: where a sum lands on the other
+                # side of a 16-bit rounding boundary the stored element moves by one ulp, and these flips decorrelate the
+                # two passes' rounding noise layer by layer (scratch diag: 0.08 % of the elements differ after conv_pre,
+                # 20 % after the first stage) -- the difference between two VALID bf16 passes approaches the size of the
+                # bf16 error itself (observed 5.4e-4 against 8e-4 to the oracle); with equal plans it is < 2e-5
+                # (tests/test_bf16_gpu.py, B = 2 against B = 1)
+                e = rms(o1[0], o64[row].cpu())
+                record_stats("rows", "cfg4/bf16/row_vs_single", rms=e)
+                assert e <= 8e-4, (row, e)
+                gg = F.embedding(sid[row:row + 1], sd["n.emb_g.weight"]).unsqueeze(-1)
+                z_o = O.flow_forward(sd, "n.flow", m_p[row:row + 1] + noise[row:row + 1] * torch.exp(logs_p[row:row + 1]),
+                                     mask[row:row + 1], gg, True, C, H, 5, 1, 4)
+                o_o = O.generator_forward(sd, "n.dec", z_o * mask[row:row + 1])
+                sig = o_o.pow(2).mean().sqrt().item()
+                r = rms(o64[row:row + 1], o_o)
+                record_stats("bf16wave", "cfg4/B64/row%d" % row, rms_err=r, signal_rms=sig)
+                assert sig >= 0.1 and r <= 1e-3, (row, r, sig)
+    finally:
+        ops.set_compute_dtype("f32")
