@@ -221,6 +221,12 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# launcher calls that went through check() since import (bench.py reports the per-step count: one call = one kernel launch,
+# two for the launchers that add a finishing / fill pass)
+CALLS = [0]
+
+
 def check(status, what):
+    CALLS[0] += 1
     if status != VCV_OK:
         raise RuntimeError("vcvits_hip: %s failed with status %d" % (what, status))
