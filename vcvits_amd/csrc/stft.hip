@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int N = 2048, HALF = 1024, NBIN = 1025, NF = 8, NT = 256;
+constexpr int TWS = HALF + HALF / 32;  // twiddle table in LDS, skewed by one entry per 32 (see fft2048_ws)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -34,20 +35,22 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 // position of register r of this thread after the LDS re-deal:  n = wave*512 + (r>>2)*256 + lane*4 + (r&3)
-__device__ __forceinline__ int pos2(int r) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ int pos2(int r, int t) {
   return ((t >> 6) << 9) | ((r >> 2) << 8) | ((t & 63) << 2) | (r & 3);
 }
 // frequency index held at position n after the transform
 __device__ __forceinline__ int rev11(int n) { return (int)(__brev((unsigned)n) >> 21); }
 
-// In: x[r] = element n = t + 256 r (natural order).  Out: x[r] = X[rev11(pos2(r))].  `xch` = 2048 float2 of LDS scratch
+// In: x[r] = element n = t + 256 r (natural order).  Out: x[r] = X[rev11(pos2(r, tid))].  `xch` = 2048 float2 of LDS scratch
 // (the caller guarantees nobody still reads it), `tw` = LDS table exp(-2 pi i k / 2048), k < 1024.
+// t = index of the thread within the 256 threads that share the frame (a workgroup may hold several such groups, each with
+// its own `xch`; the barrier inside is the workgroup's, so all groups call this together)
 template <bool INV>
-__device__ __forceinline__ void fft2048_ws(float2 (&x)[8], float2* xch, const float2* tw) {
-  const int t = threadIdx.x, lane = t & 63;
+__device__ __forceinline__ void fft2048_ws(float2 (&x)[8], float2* xch, const float2* tw, int t) {
+  const int lane = t & 63;
   auto W = [&](int idx) {
-    float2 w = tw[idx];
+    // (skewed table: the shuffle stages read twiddles 2^s entries apart -- 32 lanes on one bank of a dense table)
+    float2 w = tw[idx + (idx >> 5)];
     if (INV) w.y = -w.y;
     return w;
   };
@@ -80,7 +83,7 @@ __device__ __forceinline__ void fft2048_ws(float2 (&x)[8], float2* xch, const fl
   for (int r = 0; r < 8; ++r) xch[t + 256 * r] = x[r];
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 8; ++r) x[r] = xch[pos2(r)];
+  for (int r = 0; r < 8; ++r) x[r] = xch[pos2(r, t)];
   // ---- bits 7..2: wavefront shuffles.  Stage of bit b = lane bit b - 2: the lane with that bit clear keeps a + b, its
   // partner (bit set) keeps (a - b) * W[(n mod 2^b) << (10 - b)] ----
 #pragma unroll
@@ -142,55 +145,180 @@ __device__ __forceinline__ void load_frame(float2 (&x)[8], const float* yb, cons
   }
 }
 
-__global__ void __launch_bounds__(NT)
+// Forward.  A workgroup holds GROUPS groups of 256 threads; each group transforms FPG consecutive frames one after the other,
+// so a workgroup covers NFW = GROUPS * FPG consecutive frames of one utterance and writes them as rows of NFW contiguous
+// floats.  The window lives in registers (a thread always multiplies positions tid + 256 r), and the samples of the next
+// frame are loaded before the current frame's transform starts, so their latency hides under it.  Round 3's kernel ran
+// one group and eight frames per workgroup with a dependent global load in front of every transform: 64 workgroups for
+// the training step's 16 x 32-frame launch, each a chain of eight load -> transform latencies (49 us, 75 GB/s).  Small
+// launches now take one frame per group and workgroup (512 workgroups for that launch), large ones 4 groups x 4 frames.
+template <int GROUPS, int FPG>
+__global__ void __launch_bounds__(NT * GROUPS)
 stft_mag_fwd_kernel(const float* __restrict__ y, const float* __restrict__ window,
                     const float2* __restrict__ twg, float* __restrict__ mag, int T, int F, int hop,
                     int pad, int reflect, float eps) {
-  __shared__ float2 xch[N];
-  __shared__ float2 tw[HALF];
-  __shared__ float tile[NBIN * NF];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y, f0 = blockIdx.x * NF;
+  constexpr int NFW = GROUPS * FPG;
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  float2* tw = reinterpret_cast<float2*>(smem_);          // [HALF]
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  float2* xch = tw + TWS + grp * N;                       // [GROUPS][N]
+  float* tile = reinterpret_cast<float*>(tw + TWS + GROUPS * N);  // [NBIN][NFW]
+  const int b = blockIdx.y, f0 = blockIdx.x * NFW;
   const float* yb = y + (size_t)b * T;
-  for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
-  int nf = F - f0;
-  if (nf > NF) nf = NF;
-  for (int fi = 0; fi < nf; ++fi) {
-    float2 x[8];
-    load_frame(x, yb, window, (f0 + fi) * hop, pad, T, reflect);
-    __syncthreads();  // the previous frame's re-deal reads are done (and, first time round, tw is staged)
-    fft2048_ws<false>(x, xch, tw);
+  for (int i = threadIdx.x; i < HALF; i += NT * GROUPS) tw[i + (i >> 5)] = twg[i];
+  float win[8], raw[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) win[r] = window[tid + 256 * r];
+  auto load_raw = [&](int f) {
+    const int start = f * hop;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int k = rev11(pos2(r));
-      if (k < NBIN) tile[k * NF + fi] = sqrtf(x[r].x * x[r].x + x[r].y * x[r].y + eps);
+      const int o = f < F ? src_index(start + tid + 256 * r, pad, T, reflect) : -1;
+      raw[r] = o >= 0 ? yb[o] : 0.f;
+    }
+  };
+  load_raw(f0 + grp * FPG);
+#pragma unroll
+  for (int i = 0; i < FPG; ++i) {
+    const int fi = grp * FPG + i;
+    float2 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = make_float2(raw[r] * win[r], 0.f);
+    if (i + 1 < FPG) load_raw(f0 + fi + 1);  // in flight under this frame's transform
+    __syncthreads();  // the previous frame's re-deal reads are done (and, first time round, tw is staged)
+    fft2048_ws<false>(x, xch, tw, tid);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = rev11(pos2(r, tid));
+      if (k < NBIN) tile[k * NFW + fi] = sqrtf(x[r].x * x[r].x + x[r].y * x[r].y + eps);
     }
   }
   __syncthreads();
   float* mb = mag + (size_t)b * NBIN * F;
-  for (int i = tid; i < NBIN * NF; i += NT) {
-    const int k = i / NF, fi = i - k * NF;
-    if (fi < nf) mb[(size_t)k * F + f0 + fi] = tile[i];
+  int nf = F - f0;
+  if (nf > NFW) nf = NFW;
+  if (NFW % 4 == 0 && (F & 3) == 0) {
+    // rows of NFW floats, four frames per thread: 16-byte stores (f0 and F are multiples of four)
+    for (int i = threadIdx.x; i < NBIN * (NFW / 4); i += NT * GROUPS) {
+      const int k = i / (NFW / 4), q = i - k * (NFW / 4);
+      if (4 * q < nf) *reinterpret_cast<f32x4*>(mb + (size_t)k * F + f0 + 4 * q) = *reinterpret_cast<const f32x4*>(tile + k * NFW + 4 * q);
+    }
+  } else {
+    for (int i = threadIdx.x; i < NBIN * NFW; i += NT * GROUPS) {
+      const int k = i / NFW, fi = i - k * NFW;
+      if (fi < nf) mb[(size_t)k * F + f0 + fi] = tile[i];
+    }
   }
 }
 
-// Backward.  OWN = true (zero pad): the block owns the padded positions [f0*hop, (f0+NF)*hop) (the last block also the
-// tail), gathers every frame that overlaps them into an LDS accumulator and writes dy with plain stores.
-// OWN = false (reflect pad): each block scatters its NF frames with atomics.
+// Backward, zero pad (the only mode the training step differentiates).  The workgroup OWNS the padded positions
+// [f0 * hop, (f0 + NFO) * hop) (the last one also the tail) and gathers every frame that overlaps them (3 halo frames are
+// recomputed); its GROUPS groups of 256 threads take those frames round robin, each accumulating into its OWN copy of the
+// owned span in LDS (within a group the frames come one after the other: one thread per position and frame, no conflict);
+// at the end the copies are added in group order and written with plain stores -- no atomics, no memset, bit-reproducible.
+template <int GROUPS, int NFO>
+__global__ void __launch_bounds__(NT * GROUPS)
+stft_mag_bwd_own_kernel(const float* __restrict__ y, const float* __restrict__ window,
+                        const float2* __restrict__ twg, const float* __restrict__ dmag,
+                        float* __restrict__ dy, int T, int F, int hop, int pad, float eps) {
+  constexpr int SPAN = NFO * 512 + N;  // hop <= 512 (checked by the launcher)
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  float2* tw = reinterpret_cast<float2*>(smem_);
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  float2* xch = tw + TWS + grp * N;
+  float* accs_all = reinterpret_cast<float*>(tw + TWS + GROUPS * N);  // [GROUPS][SPAN]
+  float* accs = accs_all + grp * SPAN;
+  const int b = blockIdx.y, f0 = blockIdx.x * NFO;
+  const float* yb = y + (size_t)b * T;
+  float* dyb = dy + (size_t)b * T;
+  const float* db = dmag + (size_t)b * NBIN * F;
+  for (int i = threadIdx.x; i < HALF; i += NT * GROUPS) tw[i + (i >> 5)] = twg[i];
+  for (int i = threadIdx.x; i < GROUPS * SPAN; i += NT * GROUPS) accs_all[i] = 0.f;
+  const bool last = (int)blockIdx.x == (int)gridDim.x - 1;
+  const int own_lo = f0 * hop;
+  const int own_hi = last ? T + 2 * pad : (f0 + NFO) * hop;  // padded positions [own_lo, own_hi)
+  const int halo = (N + hop - 1) / hop - 1;  // frames starting up to N - 1 positions earlier still reach own_lo
+  const int fa = f0 - halo < 0 ? 0 : f0 - halo;
+  const int fb = f0 + NFO > F ? F : f0 + NFO;
+  float win[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) win[r] = window[tid + 256 * r];
+  for (int fr = fa; fr < fb; fr += GROUPS) {  // (every group runs every round: the transforms contain workgroup barriers)
+    const int f = fr + grp;
+    const bool live = f < fb;
+    const int start = f * hop;
+    float2 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int o = live ? src_index(start + tid + 256 * r, pad, T, 0) : -1;
+      x[r] = make_float2(o >= 0 ? yb[o] * win[r] : 0.f, 0.f);
+    }
+    float dv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // the dmag column of this frame, loaded under the first transform
+      const int k = rev11(pos2(r, tid));
+      dv[r] = (live && k < NBIN) ? db[(size_t)k * F + f] : 0.f;
+    }
+    __syncthreads();
+    fft2048_ws<false>(x, xch, tw, tid);  // spectrum, bit-reversed
+    float2 G[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float m = sqrtf(x[r].x * x[r].x + x[r].y * x[r].y + eps);
+      const float sc = dv[r] / m;
+      G[r] = make_float2(sc * x[r].x, sc * x[r].y);
+    }
+    __syncthreads();  // every thread is past its re-deal reads of xch
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r, tid))] = G[r];  // natural order for the second transform
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = xch[tid + 256 * r];
+    __syncthreads();
+    fft2048_ws<true>(x, xch, tw, tid);  // g, bit-reversed
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r, tid))].x = x[r].x;  // natural order for the overlap-add
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = tid + 256 * r;
+        const int pi = start + n;
+        if (pi >= own_lo && pi < own_hi && pi - own_lo < SPAN) accs[pi - own_lo] += xch[n].x * win[r];
+      }
+    }
+  }
+  __syncthreads();
+  for (int pi = own_lo + (int)threadIdx.x; pi < own_hi; pi += NT * GROUPS) {
+    const int o = pi - pad;
+    if (o >= 0 && o < T) {
+      float v = 0.f;
+      if (pi - own_lo < SPAN) {
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) v += accs_all[g * SPAN + pi - own_lo];  // fixed order
+      }
+      dyb[o] = v;
+    }
+  }
+}
+
+// Backward, general form (reflect pad: validation only; zero pad when the owning form above does not apply).  OWN = true:
+// one group per workgroup, as above; OWN = false: each block scatters its NF frames with atomics.
 template <bool OWN>
 __global__ void __launch_bounds__(NT)
 stft_mag_bwd_kernel(const float* __restrict__ y, const float* __restrict__ window,
                     const float2* __restrict__ twg, const float* __restrict__ dmag,
                     float* __restrict__ dy, int T, int F, int hop, int pad, int reflect, float eps) {
   __shared__ float2 xch[N];
-  __shared__ float2 tw[HALF];
+  __shared__ float2 tw[TWS];
   __shared__ float accs[OWN ? NF * 512 + N : 1];  // hop <= 512 (checked by the launcher)
   const int tid = threadIdx.x;
   const int b = blockIdx.y, f0 = blockIdx.x * NF;
   const float* yb = y + (size_t)b * T;
   float* dyb = dy + (size_t)b * T;
   const float* db = dmag + (size_t)b * NBIN * F;
-  for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
+  for (int i = tid; i < HALF; i += NT) tw[i + (i >> 5)] = twg[i];
   const bool last = (int)blockIdx.x == (int)gridDim.x - 1;
   const int own_lo = f0 * hop;
   const int own_hi = last ? T + 2 * pad : (f0 + NF) * hop;  // padded positions [own_lo, own_hi)
@@ -206,11 +334,11 @@ stft_mag_bwd_kernel(const float* __restrict__ y, const float* __restrict__ windo
     float2 x[8];
     load_frame(x, yb, window, start, pad, T, reflect);
     __syncthreads();
-    fft2048_ws<false>(x, xch, tw);  // spectrum, bit-reversed
+    fft2048_ws<false>(x, xch, tw, tid);  // spectrum, bit-reversed
     float2 G[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int k = rev11(pos2(r));
+      const int k = rev11(pos2(r, tid));
       G[r] = make_float2(0.f, 0.f);
       if (k < NBIN) {
         const float m = sqrtf(x[r].x * x[r].x + x[r].y * x[r].y + eps);
@@ -220,15 +348,15 @@ stft_mag_bwd_kernel(const float* __restrict__ y, const float* __restrict__ windo
     }
     __syncthreads();  // every thread is past its re-deal reads of xch
 #pragma unroll
-    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r))] = G[r];  // natural order for the second transform
+    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r, tid))] = G[r];  // natural order for the second transform
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = xch[tid + 256 * r];
     __syncthreads();
-    fft2048_ws<true>(x, xch, tw);  // g, bit-reversed
+    fft2048_ws<true>(x, xch, tw, tid);  // g, bit-reversed
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r))].x = x[r].x;  // natural order for the coalesced overlap-add
+    for (int r = 0; r < 8; ++r) xch[rev11(pos2(r, tid))].x = x[r].x;  // natural order for the coalesced overlap-add
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -258,19 +386,19 @@ stft_complex_fwd_kernel(const float* __restrict__ y, const float* __restrict__ w
                         const float2* __restrict__ twg, float2* __restrict__ out, int T, int F, int hop, int pad,
                         int reflect) {
   __shared__ float2 xch[N];
-  __shared__ float2 tw[HALF];
+  __shared__ float2 tw[TWS];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, f = blockIdx.x;
   const float* yb = y + (size_t)b * T;
-  for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
+  for (int i = tid; i < HALF; i += NT) tw[i + (i >> 5)] = twg[i];
   float2 x[8];
   load_frame(x, yb, window, f * hop, pad, T, reflect);
   __syncthreads();
-  fft2048_ws<false>(x, xch, tw);
+  fft2048_ws<false>(x, xch, tw, tid);
   float2* ob = out + (size_t)b * NBIN * F;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int k = rev11(pos2(r));
+    const int k = rev11(pos2(r, tid));
     if (k < NBIN) ob[(size_t)k * F + f] = x[r];
   }
 }
@@ -282,11 +410,11 @@ __global__ void __launch_bounds__(NT)
 istft_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ window, const float2* __restrict__ twg,
                  float* __restrict__ ola, int F, int hop, int L) {
   __shared__ float2 xch[N];
-  __shared__ float2 tw[HALF];
+  __shared__ float2 tw[TWS];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, f = blockIdx.x;
   const float2* sb = spec + (size_t)b * NBIN * F;
-  for (int i = tid; i < HALF; i += NT) tw[i] = twg[i];
+  for (int i = tid; i < HALF; i += NT) tw[i + (i >> 5)] = twg[i];
   float2 x[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -302,10 +430,10 @@ istft_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ wind
     x[r] = v;
   }
   __syncthreads();
-  fft2048_ws<true>(x, xch, tw);
+  fft2048_ws<true>(x, xch, tw, tid);
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 8; ++r) xch[rev11(pos2(r))].x = x[r].x;
+  for (int r = 0; r < 8; ++r) xch[rev11(pos2(r, tid))].x = x[r].x;
   __syncthreads();
   float* ob = ola + (size_t)b * L;
   const float inv = 1.f / N;
@@ -366,6 +494,19 @@ extern "C" int vcv_istft(const float* spec, const float* window, const float* tw
   return vcv_check_launch();
 }
 
+template <int GROUPS, int FPG>
+static int launch_fwd(const float* y, const float* window, const float* twiddle, float* mag, int B, int T, int F, int hop, int pad,
+                      int reflect, float eps, hipStream_t st) {
+  constexpr int NFW = GROUPS * FPG;
+  const size_t lds = sizeof(float2) * (TWS + (size_t)GROUPS * N) + sizeof(float) * (size_t)NBIN * NFW;
+  auto kern = stft_mag_fwd_kernel<GROUPS, FPG>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  hipLaunchKernelGGL(kern, dim3(vcv_cdiv(F, NFW), B), dim3(NT * GROUPS), lds, st, y, window, (const float2*)twiddle, mag, T, F, hop,
+                     pad, reflect, eps);
+  return vcv_check_launch();
+}
+
 extern "C" int vcv_stft_mag_fwd(const float* y, const float* window, const float* twiddle, float* mag,
                                 int B, int T, int n_fft, int hop, int pad, int reflect, float eps,
                                 void* stream) {
@@ -374,8 +515,23 @@ extern "C" int vcv_stft_mag_fwd(const float* y, const float* window, const float
   if (reflect && pad > T - 1) return VCV_EINVAL;
   const int F = (T + 2 * pad - n_fft) / hop + 1;
   if (F <= 0) return VCV_EINVAL;
-  hipLaunchKernelGGL(stft_mag_fwd_kernel, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, (hipStream_t)stream, y,
-                     window, (const float2*)twiddle, mag, T, F, hop, pad, reflect, eps);
+  hipStream_t st = (hipStream_t)stream;
+  const long long frames = (long long)B * F;
+  // few frames: one per workgroup (the chip has 256 CUs); more: wider rows per store, the next frame's loads in flight
+  if (frames <= 1024) return launch_fwd<1, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
+  if (frames <= 4096) return launch_fwd<4, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
+  return launch_fwd<4, 4>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
+}
+
+template <int GROUPS, int NFO>
+static int launch_bwd_own(const float* y, const float* window, const float* twiddle, const float* dmag, float* dy, int B, int T,
+                          int F, int hop, int pad, float eps, hipStream_t st) {
+  const size_t lds = sizeof(float2) * (TWS + (size_t)GROUPS * N) + sizeof(float) * (size_t)GROUPS * (NFO * 512 + N);
+  auto kern = stft_mag_bwd_own_kernel<GROUPS, NFO>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  hipLaunchKernelGGL(kern, dim3(vcv_cdiv(F, NFO), B), dim3(NT * GROUPS), lds, st, y, window, (const float2*)twiddle, dmag, dy, T, F,
+                     hop, pad, eps);
   return vcv_check_launch();
 }
 
@@ -387,14 +543,16 @@ extern "C" int vcv_stft_mag_bwd(const float* y, const float* window, const float
   if (reflect && pad > T - 1) return VCV_EINVAL;
   const int F = (T + 2 * pad - n_fft) / hop + 1;
   if (F <= 0) return VCV_EINVAL;
-  if (!reflect && hop <= 512 && T + 2 * pad - ((vcv_cdiv(F, NF) - 1) * NF) * hop <= NF * 512 + N) {
-    // zero pad: every sample is owned by one workgroup -> plain stores, no memset, bit-reproducible
-    hipLaunchKernelGGL(stft_mag_bwd_kernel<true>, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, (hipStream_t)stream, y,
-                       window, (const float2*)twiddle, dmag, dy, T, F, hop, pad, reflect, eps);
-    return vcv_check_launch();
+  hipStream_t st = (hipStream_t)stream;
+  // zero pad: every sample is owned by one workgroup -> plain stores, no memset, bit-reproducible.  Few frames (the training
+  // step's 16 x 32-frame segment batch): two hops per workgroup, four frame groups; more: eight hops, two groups.
+  auto tail_fits = [&](int nfo) { return T + 2 * pad - ((vcv_cdiv(F, nfo) - 1) * nfo) * hop <= nfo * 512 + N; };
+  if (!reflect && hop <= 512) {
+    if ((long long)B * F <= 2048 && tail_fits(2)) return launch_bwd_own<4, 2>(y, window, twiddle, dmag, dy, B, T, F, hop, pad, eps, st);
+    if (tail_fits(8)) return launch_bwd_own<2, 8>(y, window, twiddle, dmag, dy, B, T, F, hop, pad, eps, st);
   }
-  if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * T, (hipStream_t)stream) != hipSuccess) return VCV_EHIP;
-  hipLaunchKernelGGL(stft_mag_bwd_kernel<false>, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, (hipStream_t)stream, y,
+  if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * T, st) != hipSuccess) return VCV_EHIP;
+  hipLaunchKernelGGL(stft_mag_bwd_kernel<false>, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, st, y,
                      window, (const float2*)twiddle, dmag, dy, T, F, hop, pad, reflect, eps);
   return vcv_check_launch();
 }
