@@ -445,6 +445,7 @@ int vcv_prof_bytes(double* out, int ncls);
 int vcv_prof_roof(double* out, int ncls);
 /* sampling inside an open window: while paused != 0 launches carry no events (they run as plain launches) */
 int vcv_prof_pause(int paused);
+int vcv_prof_active(void); /* 1 while launches get events attached (window open, not paused) */
 /* per-launch CSV of the last profiling window: cls, ms, gflop, 12 shape tags */
 int vcv_prof_dump(const char* path);
 
@@ -462,6 +463,10 @@ const char* vcv_version(void);
 /* Deterministic mode (also VCVITS_DETERMINISTIC=1): every launcher that splits a reduction over workgroups and combines
  * with fp32 atomics runs it unsplit, one writer per output element (slower; bit-reproducible run to run).  The MFMA
  * weight-gradient kernels combine through VcvWgradArgs.slab instead; the caller passes it (and no dbias). */
+int vcv_set_seed_offset_ptr(const void* dev_u64); /* non-NULL: the FORWARD dropout / attention launchers make their kernels add
+                                                      *dev_u64 to the host seed -- a launch sequence replayed from a HIP
+                                                      graph (vcvits_amd/light/graphed.py) gets fresh masks per replay */
+const void* vcv_get_seed_offset_ptr(void);
 int vcv_set_deterministic(int on);
 int vcv_get_deterministic(void);
 

@@ -50,6 +50,7 @@ struct AttnArgs {
   int B, H, dk, T, w, TP;
   float qscale, pdrop;
   unsigned long long seed;
+  const unsigned long long* seed_off;  // forward launches only: *seed_off is added to seed (graph replays: version.hip)
 };
 
 // One MFMA step: F32: 2 reduction elements (lane half h supplies element 2s + h); BF16: 16 (lane half h supplies
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(NTH) rel_attn_fwd_kernel(const AttnArgs p) {
       if (j < T) {
         const float pv = Sr[j] * inv;
         if (p.P) p.P[rowoff + j] = pv;
-        pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, rowoff + j, p.pdrop, inv_keep) : pv;
+        pd = p.pdrop > 0.f ? pv * drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), rowoff + j, p.pdrop, inv_keep) : pv;
         if (p.Pd) p.Pd[rowoff + j] = pd;
       }
       Sr[j] = pd;
@@ -479,6 +480,7 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
   AttnArgs a = {};
   a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.out = out, a.P = P, a.Pd = Pd;
   a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
+  a.seed_off = (const unsigned long long*)vcv_get_seed_offset_ptr();
   const size_t lds = lds_bytes(a.TP);
   auto kern = bf16 ? rel_attn_fwd_kernel<true> : rel_attn_fwd_kernel<false>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -487,7 +489,7 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
   const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 100, 32 * 1000 + 32, 0};
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
-  hipExtLaunchKernelGGL(kern, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds, (hipStream_t)stream, ev0, ev1, 0, a);
+  VCV_LAUNCH_EV(kern, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds, (hipStream_t)stream, ev0, ev1, a);
   return vcv_check_launch();
 }
 
@@ -516,12 +518,12 @@ extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, 
   const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 101, 32 * 1000 + 32, 0};
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
-  hipExtLaunchKernelGGL(rows, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds, st, ev0, ev1, 0, a);
+  VCV_LAUNCH_EV(rows, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds, st, ev0, ev1, a);
   const int tag2[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 102, 32 * 1000 + 32, 0};
   vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
   const size_t lds2 = sizeof(float) * 2 * BSF;
   if (lds2 > 64 * 1024 && hipFuncSetAttribute((const void*)cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
     return VCV_EHIP;
-  hipExtLaunchKernelGGL(cols, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds2, st, ev0, ev1, 0, a);
+  VCV_LAUNCH_EV(cols, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds2, st, ev0, ev1, a);
   return vcv_check_launch();
 }

@@ -40,3 +40,4 @@ static inline int vcv_check_launch() {
 static inline int vcv_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 extern "C" int vcv_get_deterministic(void);  // version.hip
+extern "C" const void* vcv_get_seed_offset_ptr(void);  // version.hip

@@ -425,7 +425,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, float* ws, float* part, bool pa
   const double abytes = 4.0 * ((double)a.B * a.Cg * a.Tin * a.P + (double)a.Mg * a.Cg * a.K +
                                (double)a.B * a.Mg * a.Tout * a.P * (1 + (a.res ? 1 : 0) + (a.oaux ? 1 : 0)));
   vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, 0, aa, g, (const float*)ws, part);
+  VCV_LAUNCH_EV(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, aa, g, (const float*)ws, part);
   if (g.ks > 1) {
     const size_t n = (size_t)a.B * a.Mg * a.Q * a.P;
     hipLaunchKernelGGL(conv_dma_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, (const float*)part, g.ks);

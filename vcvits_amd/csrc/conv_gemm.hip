@@ -395,7 +395,7 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
   const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, phases, a.a_mode, BM * 1000 + BN, tg.BKC};
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_CONV, flops, tag, 12, &ev0, &ev1);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, tg);
+  VCV_LAUNCH_EV(kern, grid, block, (unsigned)lds, st, ev0, ev1, a, tg);
   return vcv_check_launch();
 }
 

@@ -290,7 +290,7 @@ int launch_wgrad_bu(const VcvWgradArgs& a, hipStream_t st, bool allow_sync) {
   const int tag[12] = {a.B, a.G, a.Cg, a.Mg, a.K, a.Ta, a.P, a.s, tg.Z, 0, BM * 1000 + BN, tg.NCH};
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD, flops, tag, 12, &ev0, &ev1);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, tg);
+  VCV_LAUNCH_EV(kern, grid, block, (unsigned)lds, st, ev0, ev1, a, tg);
   return vcv_check_launch();
 }
 

@@ -26,3 +26,11 @@ void vcv_prof_events(int cls, double flops, const int* tag, int ntag, hipEvent_t
                      double roof_s = 0.0);
 #define VCV_PEAK_F32_MFMA 157.3e12
 #define VCV_PEAK_BF16_MFMA 2.5e15
+
+// Launch with dispatch-attached events when the profiler handed some out, as a plain launch otherwise (plain launches are
+// what HIP-graph stream capture records; the profiler is off while a sequence is captured or replayed).
+#define VCV_LAUNCH_EV(kern, grid, block, lds, st, ev0, ev1, ...)                                  \
+  do {                                                                                           \
+    if (ev0) hipExtLaunchKernelGGL(kern, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__);        \
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                            \
+  } while (0)

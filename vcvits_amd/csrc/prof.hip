@@ -75,6 +75,12 @@ extern "C" int vcv_prof_begin(int max_launches) {
 // Sampling: while paused, launches get no events (plain launches); the window stays open.  bench.py times every other
 // step of its timed region this way: dispatch-attached events cost ~4 % of the step (they keep consecutive kernels from
 // overlapping their launch latencies).
+// 1 while launches get events attached (window open and not paused)
+extern "C" int vcv_prof_active(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_on && !g_paused ? 1 : 0;
+}
+
 extern "C" int vcv_prof_pause(int paused) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_paused = paused != 0;

@@ -40,7 +40,8 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned lo
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p,
-                               float inv_keep, unsigned long long seed) {
+                               float inv_keep, unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] = x[i] * drop_scale(seed, i, p, inv_keep);
 }
@@ -265,7 +266,8 @@ __global__ void __launch_bounds__(64)
 rel_softmax_fwd_kernel(const float* __restrict__ S, const float* __restrict__ q, const float* __restrict__ embk,
                        const float* __restrict__ mask, float* __restrict__ P, float* __restrict__ Pd,
                        float* __restrict__ Pt, int H, int dk, int T, int w, float qscale, float pdrop,
-                       unsigned long long seed) {
+                       unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off;
   const int i = blockIdx.x, g = blockIdx.y;
   const int b = g / H;
   const int lane = threadIdx.x;
@@ -615,14 +617,14 @@ extern "C" int vcv_rel_softmax_fwd(const float* S, const float* q, const float* 
     return VCV_EINVAL;
   if (pdrop < 0.f || pdrop >= 1.f || (pdrop > 0.f && !Pd)) return VCV_EINVAL;
   hipLaunchKernelGGL(rel_softmax_fwd_kernel, dim3(T, B * H), dim3(64), 0, ST, S, q, embk, mask, P, Pd, Pt, H, dk,
-                     T, w, qscale, pdrop, (unsigned long long)seed);
+                     T, w, qscale, pdrop, (unsigned long long)seed, (const unsigned long long*)vcv_get_seed_offset_ptr());
   return vcv_check_launch();
 }
 
 extern "C" int vcv_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
   if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return VCV_EINVAL;
   hipLaunchKernelGGL(dropout_kernel, g1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n, p, 1.f / (1.f - p),
-                     (unsigned long long)seed);
+                     (unsigned long long)seed, (const unsigned long long*)vcv_get_seed_offset_ptr());
   return vcv_check_launch();
 }
 

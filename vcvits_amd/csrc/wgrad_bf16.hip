@@ -462,7 +462,7 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes, NT * flops / VCV_PEAK_BF16_MFMA);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, ev0, ev1, 0, a, g, scratch);
+  VCV_LAUNCH_EV(kern, grid, block, (unsigned)lds, st, ev0, ev1, a, g, scratch);
   if (g.Z <= 12)
     hipLaunchKernelGGL(wgrad_bf16_finish_kernel<true>, dim3((unsigned)vcv_cdiv(a.Cg, 32), (unsigned)vcv_cdiv(a.Mg, 8)), dim3(256), 0,
                        st, (const float*)scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha);

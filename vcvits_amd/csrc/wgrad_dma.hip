@@ -475,7 +475,7 @@ int run(const VcvWgradArgs& a, const WgPlan& pl, hipStream_t st) {
   hipEvent_t ev0, ev1;
   const double abytes = 4.0 * ((double)a.B * a.Mg * a.Ta * a.P + (double)a.B * a.Cg * a.Tb * a.P + (double)a.Mg * a.Cg * a.K);
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes);
-  hipExtLaunchKernelGGL(kern, grid, block, (unsigned)pl.lds, st, ev0, ev1, 0, a, g);
+  VCV_LAUNCH_EV(kern, grid, block, (unsigned)pl.lds, st, ev0, ev1, a, g);
   if (a.slab)
     hipLaunchKernelGGL(wgrad_slab_finish_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)a.slab, a.dw,
                        nw, g.Z, a.alpha);

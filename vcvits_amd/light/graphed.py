@@ -1,0 +1,90 @@
+"""HIP-graph replay of a no-grad pass.
+
+The discriminator step of the reference re-runs the whole generator forward under `torch.no_grad()` and keeps only
+`y_hat.detach()` (vits/light/vcvits.py:119,153).  That pass is ~300 launcher calls whose shapes, addresses and order do
+not change from step to step, and at bf16 speeds the step is bound by the host issuing them (bench.py:
+`host_issue_ms_per_step`), so it is captured once into a HIP graph (torch.cuda.CUDAGraph: the library's launches go to the
+capturing stream like torch's own) and replayed: one host call instead of ~300.
+
+What makes the captured sequence valid on replay:
+  * inputs are copied into static buffers, outputs are the capture's own tensors (valid until the next replay);
+  * every buffer the sequence allocates comes from the graph's private pool, so the addresses baked into device tables
+    (weight-norm records, packed-weight jobs) stay the same; host arrays a captured copy reads from are kept alive;
+  * derived-weight caches are bypassed while capturing (ops.CAPTURING): the graph always re-normalises and re-packs the
+    weights it uses, whatever the cache state was at capture time;
+  * dropout: the host seed is baked into the kernel arguments, so the kernels add a device-side counter that is bumped
+    before each replay (vcv_set_seed_offset_ptr) -- fresh masks every step; torch's own generators are graph-safe;
+  * the per-launch profiler must be idle (its events are not capturable): while it records, the pass runs eagerly.
+Any failure while capturing disables the graph for that callable (eager from then on)."""
+import os
+
+import torch
+
+from .. import ops
+from .._lib import lib
+
+ENABLED = [os.environ.get("VCVITS_GRAPHS", "1") == "1"]
+
+
+def set_enabled(on):
+    ENABLED[0] = bool(on)
+
+
+class GraphedNoGrad:
+    def __init__(self, fn, warmup=3):
+        self.fn, self.warmup = fn, int(warmup)
+        self.entries, self.counts = {}, {}
+        self.failed = False
+        self.replays = 0
+
+    def _key(self, batch, extra):
+        return tuple((k, tuple(v.shape), str(v.dtype), str(v.device)) for k, v in sorted(batch.items())) + tuple(extra)
+
+    def __call__(self, batch, extra=()):
+        if (not ENABLED[0] or self.failed or not torch.cuda.is_available() or torch.is_grad_enabled()
+                or lib().vcv_prof_active() or ops.DROPOUT_TRACE[0] is not None):
+            return self.fn(batch)
+        key = self._key(batch, extra)
+        ent = self.entries.get(key)
+        if ent is None:
+            n = self.counts[key] = self.counts.get(key, 0) + 1
+            if n <= self.warmup:
+                return self.fn(batch)  # eager warm-up: plans, device tables and allocator pools exist before the capture
+            ent = self._capture(key, batch)
+            if ent is None:
+                return self.fn(batch)
+        for k, v in batch.items():
+            ent["inputs"][k].copy_(v)
+        ent["seed"].add_(1)
+        ent["graph"].replay()
+        self.replays += 1
+        return ent["outputs"]
+
+    def _capture(self, key, batch):
+        L = lib()
+        dev = next(iter(batch.values())).device
+        static = {k: v.clone() for k, v in batch.items()}
+        seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        keep = []
+        graph = torch.cuda.CUDAGraph()
+        ops.CAPTURING[0] = keep
+        L.vcv_set_seed_offset_ptr(seed.data_ptr())
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                out = self.fn(static)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- whatever the capture tripped over: stay eager
+            self.failed = True
+            import sys
+            sys.stderr.write("vcvits_amd: HIP-graph capture of the no-grad generator pass failed (%s: %s); running eagerly\n"
+                             % (type(e).__name__, str(e)[:200]))
+            ops.invalidate_weights()
+            return None
+        finally:
+            L.vcv_set_seed_offset_ptr(None)
+            ops.CAPTURING[0] = None
+        # derived weights created while capturing hold no data yet (a capture records, it does not run)
+        ops.invalidate_weights()
+        ent = self.entries[key] = {"graph": graph, "inputs": static, "outputs": out, "seed": seed, "keep": keep}
+        return ent

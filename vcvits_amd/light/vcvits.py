@@ -89,24 +89,41 @@ class VCVITS(nn.Module):
                                 d.mel_fmax)
         return spec, mel
 
-    def _generator_pass(self, batch):
+    def _generator_pass(self, batch, decoder_only=False):
         """vcvits.py:55-82: targets (no grad), net_g forward, waveform slice.  Returns
-        (y_hat, y, y_mel_slice, kl_args or None)."""
+        (y_hat, y, y_mel_slice, kl_args or None).  decoder_only (the discriminator step's no-grad pass, which keeps y_hat
+        alone): the generator computes only what y_hat depends on (SynthesizerSVC.forward)."""
         d, t = self.hparams.data, self.hparams.train
         speakers = batch.get("sid", None)
         x_feat, x_lengths = self._source(batch)
         x_pitch, x_pitch_lengths = batch["x_pitch_values"], batch["x_pitch_lengths"]
         y_wav, y_wav_lengths = batch["y_wav_values"], batch["y_wav_lengths"]
         with torch.no_grad():
-            y_spec, y_mel = self._spec_mel(y_wav.squeeze(1))
+            if decoder_only:  # (the target mel is a loss operand of the generator step only)
+                y_mel = None
+                y_spec = spectrogram_torch_audio(y_wav.squeeze(1), d.filter_length, d.target_sampling_rate, d.hop_length,
+                                                 d.win_length, center=False)
+            else:
+                y_spec, y_mel = self._spec_mel(y_wav.squeeze(1))
             y_spec_lengths = (y_wav_lengths / d.hop_length).long()
         y_hat, ids_slice, z_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \
             self.net_g(x_feat, x_lengths, x_pitch, x_pitch_lengths, y_spec, y_spec_lengths, sid=speakers,
-                       noise=batch.get("noise", None), ids_slice=batch.get("ids_slice", None))
+                       noise=batch.get("noise", None), ids_slice=batch.get("ids_slice", None), decoder_only=decoder_only)
         with torch.no_grad():
             y = ops.slice_segments(y_wav, ids_slice, t.segment_size, d.hop_length)
-            y_mel_slice = commons.slice_segments(y_mel, ids_slice, t.segment_size // d.hop_length)
+            y_mel_slice = None if decoder_only else commons.slice_segments(y_mel, ids_slice, t.segment_size // d.hop_length)
         return y_hat, y, y_mel_slice, (z_p, logs_q, m_p, logs_p, z_mask)
+
+    def _nograd_generator_pass(self, batch):
+        """(y_hat, y) of the discriminator step's generator pass: a HIP-graph replay once the batch shapes repeat
+        (light/graphed.py), the eager pass otherwise."""
+        g = self.__dict__.get("_g_graph")
+        if g is None:
+            from .graphed import GraphedNoGrad
+            # (with the dropout trace of tests/test_dropout_step_gpu.py on, the pass stays whole: the trace lists its draws)
+            g = self.__dict__["_g_graph"] = GraphedNoGrad(
+                lambda b: self._generator_pass(b, decoder_only=ops.DROPOUT_TRACE[0] is None)[:2])
+        return g(batch, extra=(self.training, ops.compute_dtype(), ops._USE_X3[0], ops.bf16_activations()))
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int, optimizer_idx: int):
         t = self.hparams.train
@@ -132,7 +149,7 @@ class VCVITS(nn.Module):
             return loss_gen_all
         if optimizer_idx == 1:
             with torch.no_grad():  # only y_hat.detach() is consumed (vcvits.py:153,157)
-                y_hat, y, _, _ = self._generator_pass(batch)
+                y_hat, y = self._nograd_generator_pass(batch)
             y_dp_hat_r, y_dp_hat_g, _, _ = self.net_period_d(y, y_hat.detach())
             loss_disc_p, r_p, g_p = discriminator_loss(y_dp_hat_r, y_dp_hat_g)
             y_ds_hat_r, y_ds_hat_g, _, _ = self.net_scale_d(y, y_hat.detach())
@@ -271,9 +288,11 @@ class VocoderGAN(VCVITS):
         return Generator(m.inter_channels, m.resblock, m.resblock_kernel_sizes, m.resblock_dilation_sizes,
                          m.upsample_rates, m.upsample_initial_channel, m.upsample_kernel_sizes)
 
-    def _generator_pass(self, batch):
+    def _generator_pass(self, batch, decoder_only=False):
         y = batch["y_wav_values"]
         y_hat = self.net_g(batch["z_slice"])
-        with torch.no_grad():
-            _, y_mel = self._spec_mel(y.squeeze(1))
+        y_mel = None
+        if not decoder_only:
+            with torch.no_grad():
+                _, y_mel = self._spec_mel(y.squeeze(1))
         return y_hat, y, y_mel, None

@@ -86,6 +86,12 @@ def set_bf16_activations(on):
     _BF16_ACT[0] = bool(on)
 
 
+# a list while a launch sequence is being captured into a HIP graph (vcvits_amd/light/graphed.py): derived-weight caches
+# are bypassed (the graph must contain the launches that make its weights) and host arrays that captured copies read
+# from are appended to it (kept alive with the graph)
+CAPTURING = [None]
+
+
 def bf16_activations():
     """True when no-grad decoder passes keep their intermediate activations in bf16."""
     return _BF16_ACT[0] and _COMPUTE[0] == "bf16"
@@ -1035,6 +1041,8 @@ def _replay_packs(key, ent):
     table = torch.empty((n * ctypes.sizeof(VcvPackJob) // 4 + 8,), device=dev, dtype=torch.float32)
     check(L.vcv_pack_many(arr, n, ptr(table), stream()), "vcv_pack_many")
     ent["pack_table"] = table  # (kept alive with the entry)
+    if CAPTURING[0] is not None:
+        CAPTURING[0].extend((arr, table, arena))  # the captured upload reads `arr` at every replay
     for k, view in reg:
         ent["packs"][k] = view
     LAUNCH_COUNTS["pack_many"] = LAUNCH_COUNTS.get("pack_many", 0) + 1
@@ -1071,7 +1079,7 @@ def _wn_forward_all(vg, n):
         _WN_TABLES[key] = ent
     tab, tab_dev, total, rows = ent
     versions = tuple(t._version for t in vg)
-    hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
+    hit = _WN_CACHE.get(key) if (_WN_CACHE_ON[0] and CAPTURING[0] is None) else None
     if hit is not None and hit["versions"] == versions and all(r() is t for r, t in zip(hit["refs"], vg)):
         wbuf, norm = hit["wbuf"], hit["norm"]  # (identity: a recycled address is not the same parameter)
     else:
