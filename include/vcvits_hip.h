@@ -87,6 +87,12 @@ typedef struct VcvConvArgs {
   int32_t io;         /* storage type of the activations in HBM: 0 = all fp32 (every entry point); else VCV_IO_* bits: `x`,
                          `y` and `res` are 16-bit tensors (same [B, C, T(, P)] layout, rows of an even number of elements):
                          vcv_conv_bf16io_* only -- every other entry point returns VCV_EINVAL for io != 0 */
+  int32_t ms;         /* 0 / 1: none.  ms > 1 (vcv_conv_bf16io_* only): a ConvTranspose1d of stride ms with ALL its output phases as
+                         rows of ONE launch -- Mg = Cout * ms rows ordered (cout, phase), K = taps per phase (kernel / ms),
+                         a_mode 1, phases 1, s 1, dj -1; output row (cout, r), column q goes to y[b, cout, q * ms + r + oo]
+                         (oo = -padding): one staged input span feeds every phase, and a lane's four accumulator rows of
+                         one channel are four consecutive samples -- 8-byte stores, contiguous per wave -- instead of the
+                         phased launch's 2-byte stores `ms` elements apart.  `w` is the ConvTranspose weight [Cin, Cout, ms*K] */
   float post_scale;   /* 0: none.  Else the epilogue becomes v = (act(alpha*acc + bias) * dact + res) * mask * post_scale
                          (+ y if accumulate): the mean over the three ResBlocks of a generator stage is accumulated by the
                          blocks' last convs (post_scale 1/3) instead of by a pass over three stored outputs

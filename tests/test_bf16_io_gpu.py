@@ -101,12 +101,16 @@ def test_conv_x16_matches_rounded_reference(gpu, bf16_mode, case, storage):
     check_rounded("y", y, ref)
 
 
-@pytest.mark.parametrize("case", [(256, 128, 944, 16, 8, 4), (128, 64, 2048, 16, 8, 4), (64, 32, 4096, 4, 4, 0), (32, 16, 4096, 4, 2, 1),
+@pytest.mark.parametrize("case", [(256, 128, 944, 16, 8, 4), (128, 64, 2048, 16, 8, 4), (64, 32, 4096, 4, 4, 0), (32, 16, 4096, 4, 2, 1), (64, 32, 4096, 4, 2, 1), (128, 64, 1000, 4, 4, 0),
                                   (512, 256, 938, 16, 8, 4)],
                          ids=lambda c: "C%d-M%d-T%d-K%d-s%d" % c[:5])
+@pytest.mark.parametrize("merged", [True, False], ids=["merged", "phased"])
 @pytest.mark.parametrize("storage", ["bb", "hh"])
-def test_convT_x16_matches_rounded_reference(gpu, bf16_mode, case, storage):
+def test_convT_x16_matches_rounded_reference(gpu, bf16_mode, case, storage, merged):
+    """merged: all output phases as rows of one launch (VcvConvArgs.ms, interleaving epilogue); phased: one launch phase per
+    output residue."""
     ops = bf16_mode
+    ops._CONVT_MERGED[0] = merged
     xdt, ydt = STORAGE[storage]
     C, M, T, K, s, pad = case
     if M < 32:
@@ -117,6 +121,7 @@ def test_convT_x16_matches_rounded_reference(gpu, bf16_mode, case, storage):
     ref = F.conv_transpose1d(rb(F.leaky_relu(x, 0.1)), rb(w), b, stride=s, padding=pad)
     before = ops.LAUNCH_COUNTS["bf16io"]
     y = ops.convT_forward_x16(x.to(xdt).to(gpu), w.to(gpu), b.to(gpu), stride=s, pad=pad, in_leaky=True, slope=0.1, out_dtype=ydt)
+    ops._CONVT_MERGED[0] = True
     assert y.dtype == ydt
     assert ops.LAUNCH_COUNTS["bf16io"] == before + 1
     check_rounded("y", y, ref)

@@ -32,7 +32,7 @@ class VcvConvArgs(ctypes.Structure):
         ("Q", _i32),
         ("a_mode", _i32), ("in_tf", _i32), ("out_act", _i32), ("out_tf", _i32), ("accumulate", _i32),
         ("alpha", ctypes.c_float), ("slope", ctypes.c_float),
-        ("io", _i32), ("post_scale", ctypes.c_float),
+        ("io", _i32), ("ms", _i32), ("post_scale", ctypes.c_float),
     ]
 
 

@@ -404,7 +404,7 @@ int launch_conv(const VcvConvArgs& a, hipStream_t st, bool allow_sync = false) {
 extern "C" int vcv_conv_gemm(const VcvConvArgs* args, void* stream) {
   if (!args) return VCV_EINVAL;
   const VcvConvArgs& a = *args;
-  if (a.io != 0 || a.post_scale != 0.f) return VCV_EINVAL;  // (bf16 activations / post-scale: vcv_conv_bf16io_* only)
+  if (a.io != 0 || a.post_scale != 0.f || a.ms > 1) return VCV_EINVAL;  // (bf16 activations / post-scale: vcv_conv_bf16io_* only)
   if (a.B <= 0 || a.G <= 0 || a.Cg <= 0 || a.Mg <= 0 || a.Tin <= 0 || a.Tout <= 0 || a.P <= 0 ||
       a.K <= 0 || a.Q <= 0 || a.s <= 0)
     return VCV_EINVAL;

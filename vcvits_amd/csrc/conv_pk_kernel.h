@@ -67,7 +67,10 @@ pack_pk_kernel(const float* __restrict__ w, typename EL::frag* __restrict__ wp, 
     if (m < M && c < C) {
       if (mode == 0) { if (j < K) f = w[((size_t)m * C + c) * K + j]; }
       else if (mode == 1) { if (j < K) f = w[((size_t)c * M + m) * K + (K - 1 - j)]; }
-      else { const int k = r + j * phases; if (k < K) f = w[((size_t)c * M + m) * K + k]; }
+      else if (mode == 2) { const int k = r + j * phases; if (k < K) f = w[((size_t)c * M + m) * K + k]; }
+      // mode 3 (merged phases): row m = (cout, phase) with the phase fastest; M / K here are the launch's (Cout * phases rows,
+      // taps per phase); w is [C, Cout, K * phases]
+      else { const int co = m / phases, ph = m - co * phases; if (j < K) f = w[((size_t)c * (M / phases) + co) * (K * phases) + ph + j * phases]; }
     }
     EL::set(v, e, f);
   }
@@ -341,9 +344,12 @@ bool eligible(const VcvConvArgs& a, int io = 0) {
   if (a.io != io || (io == 0 && a.post_scale != 0.f)) return false;
   if (io != 0 && (a.out_tf != VCV_TF_NONE || (((long long)a.Tin * a.P) & 1) || (((long long)a.Tout * a.P) & 1) || a.xaux || a.oaux))
     return false;  // bf16 tensors: rows of an even number of elements (4-byte aligned), no derivative masks
-  const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
-  const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1;
-  return (fwd_type || phased) && a.G == 1 &&
+  const bool fwd_type = a.a_mode == 0 && a.phases <= 1 && a.ms <= 1;
+  const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1 && a.ms <= 1;
+  // all output phases of a transposed conv as rows of one launch (16-bit activations only: the epilogue that interleaves them)
+  const bool merged = io != 0 && a.ms > 1 && a.a_mode == 1 && a.phases <= 1 && a.s == 1 && a.dj == -1 && a.os == a.ms && a.P == 1 &&
+                      a.Mg % a.ms == 0 && !a.res && !a.mask && !a.accumulate;
+  return (fwd_type || phased || merged) && a.G == 1 &&
          (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) && a.Mg >= 32 &&
          a.Cg >= 16 && a.K <= 16 && a.s >= 1 && a.s <= 3 && (long long)a.Tin * a.P * 4 < (1ll << 31) &&
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);
@@ -497,6 +503,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
               (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
   // bf16 `y`: the 16-byte stores carry eight columns: rows of a multiple of eight elements, 16-byte aligned tensors
   if ((IO & 2) && ((a.Tout * a.P) % 8 != 0 || (((uintptr_t)a.y | (uintptr_t)a.res) & 15))) pl.g.vec = 0;
+  if (a.ms > 1) pl.g.vec = 0;  // (merged phases: the interleaving epilogue)
   return true;
 }
 
@@ -506,9 +513,9 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   const BfGeom& g = pl.g;
   if (!pack_valid) {
     const size_t total = pl.pack_bytes / 16;
-    const int mode = g.phases > 1 ? 2 : (flip ? 1 : 0);
+    const int mode = a.ms > 1 ? 3 : (g.phases > 1 ? 2 : (flip ? 1 : 0));
     hipLaunchKernelGGL(pack_pk_kernel<EL>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Mg, a.Cg, a.K,
-                       BM, g.BKC, g.JA, g.nch, g.nmt, g.phases, mode, total);
+                       BM, g.BKC, g.JA, g.nch, g.nmt, a.ms > 1 ? a.ms : g.phases, mode, total);
   }
   void (*kern)(const VcvConvArgs, const BfGeom, const typename EL::frag*, float*);
   if constexpr (IO != 0) {
@@ -530,7 +537,7 @@ int launch(const VcvConvArgs& a, const Plan& pl, typename EL::frag* wp, float* p
   const int tag[12] = {a.B, EL::ESZ == 2 ? 2 : 4, a.Cg, a.Mg, a.K, a.Q, a.P, a.s, g.phases, a.a_mode + 10 * g.ks, BM * 1000 + pl.BN, g.BKC};
   const double esz = IO ? 2.0 : 4.0;  // bytes per activation element in HBM
   const double abytes = esz * (double)a.B * a.Cg * a.Tin * a.P + 4.0 * (double)a.Mg * a.Cg * a.K +
-                        esz * (double)a.B * a.Mg * a.Tout * a.P * (1 + (a.res ? 1 : 0) + (a.oaux ? 1 : 0) + (a.accumulate ? 1 : 0));
+                        esz * (double)a.B * (a.ms > 1 ? a.Mg / a.ms : a.Mg) * a.Tout * a.P * (1 + (a.res ? 1 : 0) + (a.oaux ? 1 : 0) + (a.accumulate ? 1 : 0));
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes, EL::ESZ == 2 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
   VCV_LAUNCH_EV(kern, grid, block, (unsigned)pl.lds_bytes, st, ev0, ev1, a, g, (const typename EL::frag*)wp, part);
@@ -561,7 +568,7 @@ int plan_t(const VcvConvArgs* args, int flip, int64_t* out) {
   out[1] = (int64_t)pl.scratch_floats;
   const BfGeom& g = pl.g;
   out[2] = ((int64_t)(EL::ESZ == 2 ? 2 : 1) << 61) | ((int64_t)pl.BM << 40) | ((int64_t)g.BKC << 28) | ((int64_t)g.JA << 20) |
-           ((int64_t)g.phases << 8) | (flip ? 1 : 0);
+           ((int64_t)g.phases << 8) | ((int64_t)(args->ms > 1 ? args->ms : 0) << 1) | (flip ? 1 : 0);
   return 0;
 }
 

@@ -244,6 +244,50 @@ __device__ __forceinline__ void conv_tile_epilogue(const VcvConvArgs& p, const B
     }
     return;
   }
+  if constexpr (YB) {
+    if (p.ms > 1) {
+      // ---- merged phases of a transposed conv: row = (cout, phase), column = q; element -> y[b, cout, q * ms + phase + oo].
+      // The four accumulator registers e & 3 = 0..3 of a lane are four consecutive rows: with ms a multiple of four they are
+      // four consecutive phases of one channel, i.e. four consecutive output samples -- one 8-byte store when aligned, and the
+      // 32 columns of a half-wave then cover 32 * ms contiguous samples.
+      const int ms = p.ms, M = Mg / ms;
+      unsigned short* y16 = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int q = u0 + (wn * TN + tn) * 32 + l31;
+        if (q >= U) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int row0 = m0 + (wm * TM + tm) * 32 + 8 * e4 + 4 * h;  // rows row0 .. row0 + 3 (registers 4 e4 .. 4 e4 + 3)
+            float v[4];
+            int trow[4], co[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int row = row0 + j;
+              co[j] = row / ms;
+              trow[j] = q * ms + (row - co[j] * ms) + oo;
+              float x = p.alpha * acc[tm][tn][4 * e4 + j];
+              if (p.bias && row < Mg) x += p.bias[co[j]];
+              v[j] = vcv_act(x, p.out_act, p.slope);
+            }
+            const size_t idx0 = ((size_t)b * M + co[0]) * (size_t)p.Tout + trow[0];
+            if ((ms & 3) == 0 && row0 + 3 < Mg && trow[0] >= 0 && trow[3] < p.Tout && (idx0 & 3) == 0) {
+              typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+              *reinterpret_cast<us4*>(y16 + idx0) = us4{f32_to_us<YK>(v[0]), f32_to_us<YK>(v[1]), f32_to_us<YK>(v[2]), f32_to_us<YK>(v[3])};
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (row0 + j < Mg && trow[j] >= 0 && trow[j] < p.Tout)
+                  st_act<YK>(p.y, ((size_t)b * M + co[j]) * (size_t)p.Tout + trow[j], v[j]);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   // ---- epilogue (as conv_gemm_kernel / conv_dma_kernel) ----
   const unsigned rowstride = (unsigned)(p.Tout * P);
   const size_t ybase = ((size_t)b * Mg + m0) * rowstride;

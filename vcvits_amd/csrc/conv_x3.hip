@@ -358,7 +358,7 @@ struct Plan {
 bool eligible(const VcvConvArgs& a) {
   const bool fwd_type = a.a_mode == 0 && a.phases <= 1;
   const bool phased = a.a_mode == 1 && a.phases > 1 && a.s == 1 && a.dj == -1;
-  return (fwd_type || phased) && a.G == 1 && a.io == 0 && a.post_scale == 0.f &&
+  return (fwd_type || phased) && a.G == 1 && a.io == 0 && a.post_scale == 0.f && a.ms <= 1 &&
          (a.in_tf == VCV_TF_NONE || (a.in_tf == VCV_TF_LEAKY && a.slope < 1.f && a.slope >= 0.f)) && a.Mg >= 32 &&
          a.Cg >= 16 && a.K <= 16 && a.s >= 1 && a.s <= 3 && (long long)a.Tin * a.P * 4 < (1ll << 31) &&
          (long long)a.Mg * a.Tout * a.P < (1ll << 31);

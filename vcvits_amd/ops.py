@@ -129,7 +129,7 @@ def _launch_conv(a, flip_w=None):
     the register-staged fp32 kernel.  flip_w: original [C, M, K] weight of a stride-1 data gradient (the pack flips it;
     the register path needs the explicit flipped copy in a.w).  Packed weights of tensors inside a cached weight-norm
     buffer (see _WeightNormManyFn) are kept with that buffer and reused until its parameters change."""
-    if _USE_DMA[0] and (a.a_mode == 0 or (a.a_mode == 1 and a.phases > 1)):
+    if _USE_DMA[0] and (a.a_mode == 0 or (a.a_mode == 1 and (a.phases > 1 or a.ms > 1))):
         L = lib()
         if flip_w is not None:
             saved = a.w
@@ -502,6 +502,9 @@ def conv_forward_x16(x, w, bias=None, stride=1, pad=0, dil=1, in_leaky=False, ou
     return out
 
 
+_CONVT_MERGED = [__import__("os").environ.get("VCVITS_CONVT_MERGED", "1") == "1"]  # (0: one launch phase per output residue)
+
+
 def convT_forward_x16(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.1, out_dtype=torch.bfloat16):
     """convT_forward over 16-bit activations (x, result: bf16 / fp16; w [Cin, Cout, K] / bias fp32)."""
     x = _x16(x, "x")
@@ -518,6 +521,12 @@ def convT_forward_x16(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.
     a.a_mode = 1
     if stride == 1:
         a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q = 1, -1, pad, 1, 0, 1, Tout
+    elif K % stride == 0 and _CONVT_MERGED[0]:
+        # all `stride` output phases as rows (cout, phase) of ONE launch: one staged input span feeds every phase and the
+        # epilogue writes runs of consecutive samples (VcvConvArgs.ms)
+        a.Mg, a.K, a.ms = M * stride, K // stride, stride
+        a.s, a.dj, a.off, a.os, a.oo, a.phases = 1, -1, 0, stride, -pad, 1
+        a.Q = (Tout - 1 + pad) // stride + 1
     else:
         a.s, a.dj, a.off, a.os, a.oo, a.phases = 1, -1, 0, stride, -pad, stride
         a.Q = (Tout - 1 + pad) // stride + 1
