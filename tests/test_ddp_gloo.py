@@ -213,3 +213,49 @@ def test_parameter_used_on_one_rank_is_updated_on_all():
     assert t0 == t1 and all(t0)          # every parameter counts as touched on BOTH ranks
     assert torch.equal(g0, g1)           # the same averaged gradient ...
     assert r0 == r1 and len(r0) == 1     # ... and the same single update range on both ranks
+
+
+# ---- static-graph mode: the host-side used-parameter exchange stops once the ranks agreed for STATIC_AFTER steps ---------
+def _static_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcvits_amd.light.optim import FlatAdamW
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+    extra = torch.nn.Linear(8, 1)  # used from step 5 on by rank 1 only: a change of the frozen set
+    opt = FlatAdamW(list(net.parameters()) + list(extra.parameters()), 1e-2, bucket_mb=0.0003)
+    opt.broadcast_parameters()
+    g = torch.Generator().manual_seed(7 + rank)
+    counts, err = [], None
+    for step in range(6):
+        x = torch.randn(4, 8, generator=g)
+        opt.zero_grad()
+        y = net(x)
+        if step >= 5 and rank == 1:
+            y = y + extra(x)
+        y.pow(2).mean().backward()
+        try:
+            opt.finish_grad_sync()
+        except RuntimeError as e:
+            err = str(e)
+            break
+        counts.append(opt.flag_exchanges)
+    out[rank] = (counts, err, opt._static_set is not None)
+    dist.destroy_process_group()  # (no barrier: the rank that raised has left the lock step)
+
+
+def test_flag_exchange_stops_after_agreement_and_a_later_change_raises():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_static_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    from vcvits_amd.light.optim import FlatAdamW
+    n = FlatAdamW.STATIC_AFTER
+    c0, e0, f0 = out[0]
+    c1, e1, f1 = out[1]
+    # the exchange ran in the first STATIC_AFTER steps only; rank 0 (whose set never changes) runs all six steps without
+    # another collective, rank 1 is told that its set changed instead of silently diverging
+    assert c0[:n + 2] == list(range(1, n + 1)) + [n, n] and f0 and f1, (c0, c1)
+    assert e0 is None and c0[-1] == n
+    assert e1 is not None and "static-graph" in e1, e1
