@@ -22,6 +22,16 @@ __device__ __forceinline__ float vcv_tf(float v, int tf, const float* aux, size_
   return v;
 }
 
+// the same with the aux element already in a register
+__device__ __forceinline__ float vcv_tf_val(float v, int tf, float a, float slope) {
+  if (tf == VCV_TF_LEAKY) return vcv_leaky(v, slope);
+  if (tf == VCV_TF_DLEAKY) return v * vcv_dleaky(a, slope);
+  if (tf == VCV_TF_DRELU) return a > 0.f ? v : 0.f;
+  if (tf == VCV_TF_DTANH) return v * (1.f - a * a);
+  if (tf == VCV_TF_DLOGCLAMP) return a > logf(slope) ? v * expf(-a) : 0.f;
+  return v;
+}
+
 __device__ __forceinline__ float vcv_act(float v, int act, float slope) {
   switch (act) {
     case VCV_ACT_LEAKY: return vcv_leaky(v, slope);

@@ -142,18 +142,35 @@ act_grad_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, 
   const int lo = seg * per;
   const int hi = lo + per < units ? lo + per : units;
   float s = 0.f;
-  for (int unit = lo; unit < hi; ++unit) {
-    const int b = unit / nchunk, ch = unit - b * nchunk;
-    const size_t row = ((size_t)b * C + c) * (size_t)T;
+  // four units per round, all their loads issued before the first store: one unit per iteration was a chain of
+  // load -> store latencies (32 units per block on the 1024-channel period layers)
+  for (int unit0 = lo; unit0 < hi; unit0 += 4) {
+    float dv[4][4], yv[4][4];
+    size_t idx[4][4];
+    bool in[4][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int t = (ch << 10) + k * 256 + threadIdx.x;
-      if (t < T) {
-        const float v = vcv_tf(dy[row + t], tf, y, row + t, slope);
-        out[row + t] = v;
-        s += v;
+    for (int q = 0; q < 4; ++q) {
+      const int unit = unit0 + q;
+      const int b = unit / nchunk, ch = unit - b * nchunk;
+      const size_t row = ((size_t)b * C + c) * (size_t)T;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = (ch << 10) + k * 256 + threadIdx.x;
+        in[q][k] = unit < hi && t < T;
+        idx[q][k] = row + t;
+        dv[q][k] = in[q][k] ? dy[row + t] : 0.f;
+        yv[q][k] = (in[q][k] && tf != VCV_TF_NONE) ? y[row + t] : 0.f;
       }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (in[q][k]) {
+          const float v = vcv_tf_val(dv[q][k], tf, yv[q][k], slope);
+          out[idx[q][k]] = v;
+          s += v;
+        }
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   __shared__ float red[4];

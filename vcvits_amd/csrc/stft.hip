@@ -4,8 +4,13 @@
 // vits/mel_processing.py:54-96 of the reference (zero-pad variant :76-96 used in training,
 // reflect-pad variant :54-74 / :115-142 used in validation).
 //
-// One workgroup (4 wavefronts) transforms NF consecutive frames of one utterance.  The 2048-point FFT is a radix-2
-// decimation-in-frequency transform over 11 index bits held as  [wave : 2][lane : 6][register : 3]:
+// Two transforms live here.
+// (1) Forward magnitude (stft_mag_fwd_wave_kernel, round 4): ONE WAVEFRONT per frame, the 2048 real samples as a 1024-point
+//     complex transform (16 values per lane: register-local 4- and 16-point DFTs, three exchanges through a wave-private
+//     LDS region, no workgroup barrier and no cross-lane shuffle inside a transform) -- see the comment at the kernel.
+// (2) fft2048_ws, the 2048-point complex transform on 256 threads (4 wavefronts) used by the backward pass, the complex
+//     STFT / iSTFT of the source pipeline and (VCVITS_STFT_RADIX2=1) the round-3 forward: radix-2 decimation in frequency over
+//     11 index bits held as  [wave : 2][lane : 6][register : 3]:
 //   * stages of bits 10, 9, 8: every thread holds the 8 elements n = t + 256 r, so these butterflies are register-local;
 //   * ONE exchange through LDS re-deals the elements so that bits 7..2 are the LANE index;
 //   * stages of bits 7..2: wavefront shuffles (lane ^ 32, 16, 8, 4, 2, 1) -- the twiddle products are reduced across
@@ -142,6 +147,213 @@ __device__ __forceinline__ void load_frame(float2 (&x)[8], const float* yb, cons
     const int n = threadIdx.x + 256 * r;
     const int o = src_index(start + n, pad, T, reflect);
     x[r] = make_float2(o >= 0 ? yb[o] * window[n] : 0.f, 0.f);
+  }
+}
+
+// ---- forward, one WAVEFRONT per frame: 2048 real samples as a 1024-point complex transform ---------------------------------
+// z[m] = x[2m] + i x[2m+1];  Z = FFT_1024(z);  X[k] = E + W_2048^k O,  X[1024 - k] = conj(E - W_2048^k O)  with
+// E = (Z[k] + conj Z[1024-k]) / 2,  O = -i (Z[k] - conj Z[1024-k]) / 2  -- half the butterflies of a 2048-point complex
+// transform of a real frame, and both magnitudes of a pair from one E and one product.
+// The 64 lanes hold 16 complex values each; 1024 = 4 x 16 x 16 with m = a + 16 b + 256 c and k = kc + 4 kb + 64 ka:
+//   pass 1  4-point DFTs over c          lane (a, b & 3), registers (b >> 2, c)          -- register-local
+//   pass 2  x W_64^(b kc), 16-point DFTs over b      lane (a, kc), registers b           -- after an exchange through LDS
+//   pass 3  x W_1024^(a (kc + 4 kb)), 16-point DFTs over a   lane (kb, kc), registers a  -- after a second exchange
+//   then Z goes to LDS in natural order and every lane combines the pairs (k, 1024 - k), k = lane + 64 j.
+// The three exchanges use ONE wave-private LDS region (LDS operations of a wave execute in order; pitches 80 / 65 / a skew of
+// two slots per 32 keep the 8-byte accesses of a half-wave on 32 different bank pairs); there is no workgroup barrier inside
+// a transform and no cross-lane shuffle: the 16-point DFTs are straight-line register code with constant twiddles, the
+// lane-dependent twiddles (32 + 8 per lane) are loaded once per kernel.  ~1000 vector instructions per frame on one wave
+// against 4 waves x ~850 (+ ~180 LDS operations each, 2 barriers) for the radix-2 form above.
+__device__ __forceinline__ float2 tw2048(const float2* __restrict__ twg, int idx) {  // exp(-2 pi i idx / 2048), any idx >= 0
+  float2 w = twg[idx & 1023];
+  if (idx & 1024) w = make_float2(-w.x, -w.y);
+  return w;
+}
+
+// in-place 16-point DFT (forward), natural order in and out; radix-2 decimation in frequency with constant twiddles
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+  auto bf = [&](int i, int j, float wx, float wy) {  // v[i], v[j] <- v[i] + v[j], (v[i] - v[j]) * (wx, wy)
+    const float2 a = v[i], b = v[j];
+    v[i] = make_float2(a.x + b.x, a.y + b.y);
+    const float dx = a.x - b.x, dy = a.y - b.y;
+    v[j] = make_float2(dx * wx - dy * wy, dx * wy + dy * wx);
+  };
+  auto bf1 = [&](int i, int j) {  // twiddle 1
+    const float2 a = v[i], b = v[j];
+    v[i] = make_float2(a.x + b.x, a.y + b.y);
+    v[j] = make_float2(a.x - b.x, a.y - b.y);
+  };
+  auto bfi = [&](int i, int j) {  // twiddle -i
+    const float2 a = v[i], b = v[j];
+    v[i] = make_float2(a.x + b.x, a.y + b.y);
+    v[j] = make_float2(a.y - b.y, b.x - a.x);
+  };
+  bf1(0, 8); bf(1, 9, C1, -S1); bf(2, 10, R, -R); bf(3, 11, S1, -C1); bfi(4, 12); bf(5, 13, -S1, -C1); bf(6, 14, -R, -R); bf(7, 15, -C1, -S1);
+#pragma unroll
+  for (int g = 0; g < 16; g += 8) { bf1(g, g + 4); bf(g + 1, g + 5, R, -R); bfi(g + 2, g + 6); bf(g + 3, g + 7, -R, -R); }
+#pragma unroll
+  for (int g = 0; g < 16; g += 4) { bf1(g, g + 2); bfi(g + 1, g + 3); }
+#pragma unroll
+  for (int g = 0; g < 16; g += 2) bf1(g, g + 1);
+  // position p holds X[rev4(p)]: back to natural order (register naming)
+  float2 t[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = v[((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3)];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = t[k];
+}
+
+constexpr int WREG = 1264;  // float2 slots of a wave's exchange region (the largest of the three layouts: 15 * 80 + 63 + 1)
+constexpr int WTW = 2 * 16 * 64;  // float2 slots of the workgroup's lane-dependent twiddle tables (passes 2 and 3)
+
+template <int WAVES, int FPW>
+__global__ void __launch_bounds__(64 * WAVES)
+stft_mag_fwd_wave_kernel(const float* __restrict__ y, const float* __restrict__ window, const float2* __restrict__ twg,
+                         float* __restrict__ mag, int T, int F, int hop, int pad, int reflect, float eps) {
+  constexpr int NFW = WAVES * FPW;
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2* Ltw = reinterpret_cast<float2*>(smem_);  // [2][16][64]: W_64^(b kc) and W_1024^(a (kc + 4 kb)) per (register, lane)
+  float2* L = Ltw + WTW + wave * WREG;
+  float* tile = reinterpret_cast<float*>(Ltw + WTW + WAVES * WREG);  // [NBIN][NFW] (NFW > 1)
+  const int b = blockIdx.y, f0 = blockIdx.x * NFW;
+  const float* yb = y + (size_t)b * T;
+  float* mb = mag + (size_t)b * NBIN * F;
+  const int a = lane & 15, hi = lane >> 4;  // (a, b & 3) / (a, kc) / (kb, kc) in the three passes
+  // lane-dependent twiddles of passes 2 and 3: the same for every wave and frame, kept in LDS ([register][lane]: the reads
+  // are lane-contiguous); 64 registers of them per lane pushed the two-frames-per-wave form into scratch
+  for (int e = threadIdx.x; e < 16 * 64; e += 64 * WAVES) {
+    const int r = e >> 6, ln = e & 63, aa = ln & 15, hh = ln >> 4;
+    Ltw[e] = tw2048(twg, 32 * r * hh);                    // W_64^(b kc): lane (a, kc = hh), register b = r
+    Ltw[16 * 64 + e] = tw2048(twg, 2 * r * (hh + 4 * aa));  // W_1024^(a' (kc + 4 kb)): lane (kb = aa, kc = hh), register a' = r
+  }
+  float2 tw4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) tw4[j] = twg[lane + 64 * j];  // W_2048^k, k = lane + 64 j < 512
+  __syncthreads();
+  // zero pad with 8-byte aligned frames: range-checked 8-byte buffer loads, issued one frame ahead
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool fast = !reflect && ((pad | hop) & 1) == 0;
+  __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, T * 4, 0x00020000);
+  f32x2 raw[16];
+  auto load_raw = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      unsigned voff = (unsigned)(st - pad + 2 * (lane + 64 * q)) * 4u;  // before the first sample: wraps -> out of range -> 0
+      asm volatile("" : "+v"(voff));  // (whole offset in one register: see conv_pk_kernel.h)
+      raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsy, voff, 0, 0));
+    }
+  };
+  if (fast && f0 + wave * FPW < F) load_raw((f0 + wave * FPW) * hop);
+#pragma unroll 1
+  for (int i = 0; i < FPW; ++i) {
+    const int fi = wave * FPW + i, f = f0 + fi;
+    if (f >= F) break;  // (wave-uniform)
+    const int start = f * hop;
+    float2 v[16];
+    if (fast) {
+      // the samples were loaded one frame ahead (raw[]); this frame's are windowed now, the next frame's go in flight
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float2 w = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * q));
+        v[q] = make_float2(raw[q][0] * w.x, raw[q][1] * w.y);
+      }
+      if (i + 1 < FPW && f + 1 < F) load_raw(start + hop);
+    } else if (!reflect && ((start - pad) & 1) == 0) {
+      // zero pad: 8-byte buffer loads through a range-checked descriptor of the utterance -- positions before the first
+      // sample wrap to huge offsets, positions past the last fall outside, both read 0: no branch per load (a
+      // `cond ? y[o] : 0` per element compiles to a branch around every load, i.e. 32 serialised load latencies)
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, T * 4, 0x00020000);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = lane + 64 * q;
+        unsigned voff = (unsigned)(start - pad + 2 * m) * 4u;
+        asm volatile("" : "+v"(voff));  // (whole offset in one register: see conv_pk_kernel.h)
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+        const float2 w = *reinterpret_cast<const float2*>(window + 2 * m);
+        v[q] = make_float2(t[0] * w.x, t[1] * w.y);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = lane + 64 * q;
+        const int o0 = src_index(start + 2 * m, pad, T, reflect), o1 = src_index(start + 2 * m + 1, pad, T, reflect);
+        const float2 w = *reinterpret_cast<const float2*>(window + 2 * m);
+        v[q] = make_float2(o0 >= 0 ? yb[o0] * w.x : 0.f, o1 >= 0 ? yb[o1] * w.y : 0.f);
+      }
+    }
+    // pass 1: registers q = bl + 4 c; 4-point DFTs over c, result kc in register bl + 4 kc
+#pragma unroll
+    for (int bl = 0; bl < 4; ++bl) {
+      const float2 p0 = v[bl], p1 = v[bl + 4], p2 = v[bl + 8], p3 = v[bl + 12];
+      const float2 s02 = make_float2(p0.x + p2.x, p0.y + p2.y), d02 = make_float2(p0.x - p2.x, p0.y - p2.y);
+      const float2 s13 = make_float2(p1.x + p3.x, p1.y + p3.y), d13 = make_float2(p1.x - p3.x, p1.y - p3.y);
+      v[bl] = make_float2(s02.x + s13.x, s02.y + s13.y);
+      v[bl + 8] = make_float2(s02.x - s13.x, s02.y - s13.y);
+      v[bl + 4] = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i d13
+      v[bl + 12] = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+    }
+    // exchange 1: (a, bh = hi; bl, kc) -> slot b * 80 + kc * 16 + a, b = bh + 4 bl; read back slot b * 80 + lane
+#pragma unroll
+    for (int q = 0; q < 16; ++q) L[(hi + 4 * (q & 3)) * 80 + (q >> 2) * 16 + a] = v[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 t = L[r * 80 + lane], w2 = Ltw[r * 64 + lane];
+      v[r] = make_float2(t.x * w2.x - t.y * w2.y, t.x * w2.y + t.y * w2.x);
+    }
+    dft16(v);  // over b: register kb
+    // exchange 2: (a, kc = hi; kb) -> slot a * 65 + kb + 16 kc; read back slot a' * 65 + lane  (lane = kb + 16 kc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[a * 65 + r + 16 * hi] = v[r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 t = L[r * 65 + lane], w3 = Ltw[(16 + r) * 64 + lane];
+      v[r] = make_float2(t.x * w3.x - t.y * w3.y, t.x * w3.y + t.y * w3.x);
+    }
+    dft16(v);  // over a: register ka holds Z[kc + 4 kb + 64 ka]
+    // exchange 3: Z in natural order (slot k + 2 (k >> 5)); then the pairs (k, 1024 - k), k = lane + 64 j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = hi + 4 * a + 64 * r;
+      L[k + 2 * (k >> 5)] = v[r];
+    }
+    auto slot = [](int k) { return k + 2 * (k >> 5); };
+    auto put = [&](int k, float m) {
+      if (NFW > 1) tile[k * NFW + fi] = m;
+      else mb[(size_t)k * F + f] = m;
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lane + 64 * j;
+      const float2 zk = L[slot(k)], zm = L[slot((1024 - k) & 1023)];
+      const float ex = 0.5f * (zk.x + zm.x), ey = 0.5f * (zk.y - zm.y);   // E = (Zk + conj Zm) / 2
+      const float ox = 0.5f * (zk.y + zm.y), oy = -0.5f * (zk.x - zm.x);  // O = -i (Zk - conj Zm) / 2
+      const float tx = ox * tw4[j].x - oy * tw4[j].y, ty = ox * tw4[j].y + oy * tw4[j].x;
+      put(k, sqrtf((ex + tx) * (ex + tx) + (ey + ty) * (ey + ty) + eps));
+      put(1024 - k, sqrtf((ex - tx) * (ex - tx) + (ey - ty) * (ey - ty) + eps));
+    }
+    if (lane == 0) {
+      const float2 z5 = L[slot(512)];
+      put(512, sqrtf(z5.x * z5.x + z5.y * z5.y + eps));
+    }
+  }
+  if (NFW > 1) {
+    __syncthreads();
+    int nf = F - f0;
+    if (nf > NFW) nf = NFW;
+    if (NFW % 4 == 0 && (F & 3) == 0) {
+      for (int idx = threadIdx.x; idx < NBIN * (NFW / 4); idx += 64 * WAVES) {
+        const int k = idx / (NFW / 4), q = idx - k * (NFW / 4);
+        if (4 * q < nf) *reinterpret_cast<f32x4*>(mb + (size_t)k * F + f0 + 4 * q) = *reinterpret_cast<const f32x4*>(tile + k * NFW + 4 * q);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < NBIN * NFW; idx += 64 * WAVES) {
+        const int k = idx / NFW, fi = idx - k * NFW;
+        if (fi < nf) mb[(size_t)k * F + f0 + fi] = tile[idx];
+      }
+    }
   }
 }
 
@@ -507,6 +719,19 @@ static int launch_fwd(const float* y, const float* window, const float* twiddle,
   return vcv_check_launch();
 }
 
+template <int WAVES, int FPW>
+static int launch_fwd_wave(const float* y, const float* window, const float* twiddle, float* mag, int B, int T, int F, int hop,
+                           int pad, int reflect, float eps, hipStream_t st) {
+  constexpr int NFW = WAVES * FPW;
+  const size_t lds = sizeof(float2) * ((size_t)WTW + (size_t)WAVES * WREG) + (NFW > 1 ? sizeof(float) * (size_t)NBIN * NFW : 0);
+  auto kern = stft_mag_fwd_wave_kernel<WAVES, FPW>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  hipLaunchKernelGGL(kern, dim3(vcv_cdiv(F, NFW), B), dim3(64 * WAVES), lds, st, y, window, (const float2*)twiddle, mag, T, F, hop,
+                     pad, reflect, eps);
+  return vcv_check_launch();
+}
+
 extern "C" int vcv_stft_mag_fwd(const float* y, const float* window, const float* twiddle, float* mag,
                                 int B, int T, int n_fft, int hop, int pad, int reflect, float eps,
                                 void* stream) {
@@ -517,7 +742,13 @@ extern "C" int vcv_stft_mag_fwd(const float* y, const float* window, const float
   if (F <= 0) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long frames = (long long)B * F;
-  // few frames: one per workgroup (the chip has 256 CUs); more: wider rows per store, the next frame's loads in flight
+  static const bool old_form = getenv("VCVITS_STFT_RADIX2") != nullptr;  // (A/B switch: the 256-threads-per-frame radix-2 form)
+  if (!old_form) {
+    // one wavefront per frame (stft_mag_fwd_wave_kernel): few frames -> one frame per workgroup; more -> wider output rows
+    if (frames <= 1024) return launch_fwd_wave<1, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
+    if (frames <= 4096) return launch_fwd_wave<4, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
+    return launch_fwd_wave<8, 2>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
+  }
   if (frames <= 1024) return launch_fwd<1, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
   if (frames <= 4096) return launch_fwd<4, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);
   return launch_fwd<4, 4>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);

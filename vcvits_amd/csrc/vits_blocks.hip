@@ -235,16 +235,30 @@ layernorm_c_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
   const size_t base = (size_t)b * C * T + t;
   const float mu = ok ? mean[(size_t)b * T + t] : 0.f, rs = ok ? rstd[(size_t)b * T + t] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  for (int c = wv; c < C; c += 4) {
-    float dyv = 0.f, xh = 0.f;
-    if (ok) {
-      xh = (x[base + (size_t)c * T] + (y ? y[base + (size_t)c * T] : 0.f) - mu) * rs;
-      dyv = dout[base + (size_t)c * T];
+  // eight channels per round with their loads issued together: one channel per iteration paid a global-load latency per
+  // channel (the wave reductions and atomics between the loads keep the compiler from overlapping them): 172 us per launch
+  // at B = 32, C = 256, T = 204
+  for (int c0 = wv; c0 < C; c0 += 32) {
+    float xv[8], yv[8], dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + 4 * u;
+      const bool in = ok && c < C;
+      xv[u] = in ? x[base + (size_t)c * T] : 0.f;
+      yv[u] = (in && y) ? y[base + (size_t)c * T] : 0.f;
+      dv[u] = in ? dout[base + (size_t)c * T] : 0.f;
     }
-    const float gd = dyv * gamma[c];
-    s1 += gd; s2 += gd * xh;
-    const float pg = wsum(dyv * xh), pb = wsum(dyv);
-    if (lane == 0) { unsafeAtomicAdd(dgamma + c, pg); unsafeAtomicAdd(dbeta + c, pb); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + 4 * u;
+      if (c >= C) break;
+      const float xh = ok ? (xv[u] + yv[u] - mu) * rs : 0.f;
+      const float dyv = dv[u];
+      const float gd = dyv * gamma[c];
+      s1 += gd; s2 += gd * xh;
+      const float pg = wsum(dyv * xh), pb = wsum(dyv);
+      if (lane == 0) { unsafeAtomicAdd(dgamma + c, pg); unsafeAtomicAdd(dbeta + c, pb); }
+    }
   }
   red[0][wv][lane] = s1; red[1][wv][lane] = s2;
   __syncthreads();
