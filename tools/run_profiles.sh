@@ -2,9 +2,9 @@
 # Run on the GPU box (gpurun): rocprofv3 kernel trace + the two HBM-traffic PMC passes (each in its own run, per
 # MI355X_MICROARCH.md) of the bench workloads, an MFMA-busy PMC pass of the dominant kernels, raw CSVs under
 # gpurun_out/<tag>_*/..., condensed by tools/profile_summary.py / tools/pmc_busy_summary.py into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r3'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r4'
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out profiles
@@ -12,9 +12,10 @@ run() {  # name, workload key, bench flags...
   local name=$1 key=$2; shift 2
   local out=gpurun_out/$name
   rm -rf $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $out.trace.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof "$@" > $out.fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof "$@" > $out.write.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-extra "$@" > $out.trace.log 2>&1
+  # (counter passes: eager launches only -- the discriminator step's graph replay is switched off, same kernels)
+  VCVITS_GRAPHS=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-extra --no-prof "$@" > $out.fetch.log 2>&1
+  VCVITS_GRAPHS=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-extra --no-prof "$@" > $out.write.log 2>&1
   python3 tools/profile_summary.py $out profiles/$name $key > $out.summary.log 2>&1
   rm -rf $out/*/*/*.db $out/*/*_kernel_trace.csv $out/*/*/*_kernel_trace.csv $out/*/*counter_collection.csv $out/*/*/*counter_collection.csv
 }
@@ -40,11 +41,16 @@ python3 tools/conv_layer_bench.py --reps 10 > profiles/${TAG}_conv_layers.txt 2>
 python3 tools/conv_layer_bench.py --reps 10 --split 0 > profiles/${TAG}_conv_layers_fp32_mfma.txt 2>/dev/null
 python3 tools/attn_bench.py > profiles/${TAG}_attn_bench.txt 2>/dev/null
 python3 tools/thin_bench.py > profiles/${TAG}_thin_bench.txt 2>/dev/null
+# STFT launches: kernel-only durations (the segment launch is shorter than a host-side timing loop can resolve)
+rm -rf gpurun_out/${TAG}_stft
+( cd /tmp && rocprofv3 --kernel-trace -d "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_stft" -o stft -- python3 "$GRAFT_REPO_ROOT/tools/stft_bench.py" > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_stft.log" 2>&1 )
+{ echo "# rocprofv3 --kernel-trace -- python3 tools/stft_bench.py: kernel-only durations by (kernel, grid); bytes: tools/stft_bench.py"; python3 tools/rocpd_kernel_times.py $(ls gpurun_out/${TAG}_stft/*.db gpurun_out/${TAG}_stft/*/*.db 2>/dev/null | head -1) stft; } > profiles/${TAG}_stft_kernels.txt 2>/dev/null
+rm -rf gpurun_out/${TAG}_stft
 python3 bench.py --steps 10 --warmup 3 > profiles/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > profiles/${TAG}_bench_line_bf16.json 2>/dev/null
-python3 bench.py --dtype bf16 --workload full --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2.json 2>/dev/null
-python3 bench.py --dtype bf16 --config 48k --workload full --steps 5 --warmup 2 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg3_1gpu.json 2>/dev/null
-python3 bench.py --dtype bf16 --config 48k --workload infer --steps 3 --warmup 1 > profiles/${TAG}_bench_line_cfg4.json 2>/dev/null
+python3 bench.py --dtype bf16 --workload full --batch 32 --steps 10 --warmup 5 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2.json 2>/dev/null
+python3 bench.py --dtype bf16 --config 48k --workload full --steps 10 --warmup 5 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg3_1gpu.json 2>/dev/null
+python3 bench.py --dtype bf16 --config 48k --workload infer --steps 5 --warmup 2 > profiles/${TAG}_bench_line_cfg4.json 2>/dev/null
 python3 bench.py --config 48k --workload infer --steps 3 --warmup 1 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg4_f32.json 2>/dev/null
 cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
 ls profiles/ | grep ${TAG}_ | head -80
