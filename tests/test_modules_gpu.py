@@ -255,6 +255,30 @@ def test_generator_vs_oracle(gpu):
         close("d" + n, p.grad, sdo["g." + n].grad, tol=2e-4)
 
 
+def test_generator_two_resblocks_per_stage(gpu):
+    """A stage with a number of ResBlocks other than the configs' three (the stage mean is then a sum + one scaling pass)."""
+    from oracle import vits_oracle as O
+    from vcvits_amd.model.generator import Generator
+    gen = Generator(16, "1", [3, 5], [[1, 3, 5]] * 2, [4, 4], 32, [8, 8])
+    sd = fill_state_dict(keys_shapes_of(gen), 12)
+    gen.load_state_dict(sd)
+    gen = gen.to(gpu)
+    rng = np.random.default_rng(6)
+    x = torch.from_numpy(rng.standard_normal((2, 16, 40)).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((2, 1, 40 * 16)).astype(np.float32))
+    sdo = {"g." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xc = x.clone().requires_grad_(True)
+    yc = O.generator_forward(sdo, "g", xc, (4, 4), (8, 8), (3, 5), ((1, 3, 5),) * 2)
+    (yc * r).sum().backward()
+    xg = x.clone().to(gpu).requires_grad_(True)
+    yg = gen(xg)
+    (yg * r.to(gpu)).sum().backward()
+    close("y", yg, yc.detach())
+    close("dx", xg.grad, xc.grad)
+    for n, p in gen.named_parameters():
+        close("d" + n, p.grad, sdo["g." + n].grad, tol=2e-4)
+
+
 def test_weight_cache_follows_parameter_changes(gpu):
     """Cached weight-norm results / packed weights are dropped when a parameter changes in place (torch version
     counter) or through an optimizer's raw-pointer update (ops.invalidate_weights)."""

@@ -17,6 +17,7 @@ struct BfGeom {
   int JA;         // taps stored per channel in a weight slab (K, or ceil(K/phases) for a phased launch)
   int phases;     // > 1: transposed / strided-data-gradient launch, one residue per blockIdx.z
   int ks;         // > 1: the chunks are split over ks blocks per tile, partial sums go to a scratch slab each
+  int xcd;        // 1: XCD-aware tile order (xcd_tile_id below)
   int vec;        // 1: rows of the output are contiguous in the column index and the LDS has room for a 32 x 40 tile per
                   // wave: the epilogue goes through LDS and stores 16 bytes per lane (4 consecutive columns of one row)
 };
@@ -25,6 +26,29 @@ struct BfGeom {
 // columns (wn*TN + tn)*32 ..), `smem` the workgroup's LDS (free: the caller's main loop ended with a barrier), `part`
 // the partial-sum slabs of a split launch.  b: batch element, kz: split index, u0 / m0: first column / row of the tile,
 // oo: output row offset (phase residue included).
+// Tile of this workgroup, XCD-aware.  The grid is (column tiles x splits, m-tiles, phases); all m-tiles (and phases) of one
+// column tile read the SAME input span, but in dispatch order they are a whole grid row apart, and workgroups are dealt to the
+// 8 XCDs round robin (MI355X_MICROARCH.md: blocks b and b + 8 share an XCD, each XCD has its own L2): the span was fetched
+// into up to 8 L2s (round 3: 2.2x the algorithmic HBM bytes on the dominant class).  Here the linear workgroup id is
+// re-dealt so that consecutive ids sit on ONE XCD (the bijective form of cdna_hip_programming.md T1) and the m-tile /
+// phase index runs fastest: the workgroups sharing a span are neighbours in time on one L2.  A speed-only mapping: any
+// placement is correct.  VCVITS_NO_XCD_REMAP=1 (read once by the planners: BfGeom.xcd) restores the plain order.
+__device__ __forceinline__ void xcd_tile_id(int& bxk, int& mt, int& r, int remap) {
+  if (!remap) {
+    bxk = blockIdx.x, mt = blockIdx.y, r = blockIdx.z;
+    return;
+  }
+  const unsigned nmt = gridDim.y, nph = gridDim.z;
+  const unsigned n = gridDim.x * nmt * nph;
+  const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + nmt * blockIdx.z);  // dispatch order: x fastest
+  const unsigned q = n >> 3, rem = n & 7, xcd = id & 7;
+  unsigned lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+  mt = (int)(lid % nmt);
+  lid /= nmt;
+  r = (int)(lid % nph);
+  bxk = (int)(lid / nph);
+}
+
 // Storage kinds of an activation tensor in HBM: 0 = fp32, 1 = bf16, 2 = fp16 (IEEE half: the residual stream of the decoder
 // in bf16-activation mode -- 11 significand bits, so re-rounding the stream at every residual add costs 1/64 of the error
 // energy a bf16 stream would; values are clamped to the finite fp16 range before the conversion)

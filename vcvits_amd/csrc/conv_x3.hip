@@ -120,11 +120,11 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int kz = blockIdx.x % tg.ks;
-  const int bx = blockIdx.x / tg.ks;
+  int bxk, mt, r;  // (column-tile, split) index, m-tile, output residue of a phased launch (0 otherwise)
+  xcd_tile_id(bxk, mt, r, tg.xcd);
+  const int kz = bxk % tg.ks;
+  const int bx = bxk / tg.ks;
   const int b = bx / tg.ntu, ut = bx % tg.ntu;
-  const int mt = blockIdx.y;
-  const int r = blockIdx.z;  // output residue of a phased launch (0 otherwise)
   const int JA = tg.JA, P = p.P, U = p.Q * P, Cg = p.Cg;
   const int K = tg.phases > 1 ? (r < p.K ? (p.K - r + tg.phases - 1) / tg.phases : 0) : p.K;
   const int oo = p.oo + (tg.phases > 1 ? r : 0);
@@ -385,6 +385,8 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
   g.vec = 0;
+  static const int xcd_remap = getenv("VCVITS_NO_XCD_REMAP") ? 0 : 1;
+  g.xcd = xcd_remap;
   pl.pack_bytes = (size_t)g.phases * g.nmt * g.nch * g.JA * (3 * 2 * BM * 16);
   pl.scratch_floats = 0;
   return true;

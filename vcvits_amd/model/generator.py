@@ -18,8 +18,6 @@ class Generator(nn.Module):
         super().__init__()
         self.num_kernels = len(resblock_kernel_sizes)
         self.num_upsamples = len(upsample_rates)
-        if self.num_kernels != 3:
-            raise NotImplementedError("stage mean is fused for 3 resblocks per stage (configs/base.json:57)")
         self.conv_pre = Conv(initial_channel, upsample_initial_channel, 7, padding=3)
         block = modules.ResBlock1 if str(resblock) == "1" else modules.ResBlock2
         self.ups = nn.ModuleList()
@@ -75,6 +73,12 @@ class Generator(nn.Module):
         for i in range(self.num_upsamples):
             x = self.ups[i](x, in_leaky=True, slope=LRELU_SLOPE)
             r = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
-            x = ops.avg3(r[0], r[1], r[2])
+            if len(r) == 3:  # (both reference configs: configs/base.json:57)
+                x = ops.avg3(r[0], r[1], r[2])
+            else:  # any other count: sum (autograd's own accumulation adds) and one scaling pass
+                acc = r[0]
+                for t in r[1:]:
+                    acc = acc + t
+                x = ops.scale_grad(acc, 1.0 / len(r))
         # F.leaky_relu default slope 0.01 -> conv_post -> tanh, all in one launch
         return self.conv_post(x, in_leaky=True, slope=0.01, out_act=ACT_TANH)

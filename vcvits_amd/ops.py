@@ -1204,6 +1204,22 @@ def scale(x, alpha):
     return y
 
 
+class _ScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return scale(x, alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return scale(_f32c(dy), ctx.alpha), None
+
+
+def scale_grad(x, alpha):
+    """alpha * x with autograd (scale() is the raw launch)."""
+    return _ScaleFn.apply(x, float(alpha))
+
+
 class _Avg3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, c):
