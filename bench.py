@@ -303,13 +303,13 @@ def cpu_baseline(cfg, workload, periods, frames, also_full=False):
 
 def cpu_baseline_subprocess(config, workload, frames, also_full):
     """The CPU baseline in a fresh CHILD process (started, not exec'ed: this process holds the GPU) that never touches the
-    GPU and whose OpenMP runtime starts with threads bound to cores (OMP_PROC_BIND=close, OMP_PLACES=cores: settings that
-    only take effect at process start) -- the box's best, not an artefact of an unpinned pool.  Falls back to measuring
-    in-process if the child fails."""
+    GPU: its thread pools and allocator are its own, and `host` reports what the container really grants (CPUs the
+    process may run on, cgroup CPU quota, NUMA nodes).  Falls back to measuring in-process if the child fails."""
     import subprocess
     env = dict(os.environ)
-    env.setdefault("OMP_PROC_BIND", "close")
-    env.setdefault("OMP_PLACES", "cores")
+    # (OMP_PROC_BIND=close / OMP_PLACES=cores were tried here: 8 / 16 bound threads took 1.14 / 1.29 s per batch on a box where
+    # 16 unbound threads take 0.93 s -- the container's cgroup grants 16 CPUs of quota (`host.cgroup_cpu_quota`) wherever the
+    # scheduler likes to place them, which is also why more than 16 threads only add throttling)
     env.pop("OMP_NUM_THREADS", None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "--config", config, "--workload", workload,
            "--frames", str(frames)] + ([] if also_full else ["--no-cpu-baseline-full"])
@@ -318,7 +318,7 @@ def cpu_baseline_subprocess(config, workload, frames, also_full):
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and lines:
             out = json.loads(lines[-1])
-            out["measured_in"] = "child process, OpenMP threads bound to cores"
+            out["measured_in"] = "child process (no GPU context)"
             return out
         sys.stderr.write("bench.py: CPU-baseline child failed (rc %s): %s\n" % (r.returncode, r.stderr[-400:]))
     except Exception as e:  # noqa: BLE001

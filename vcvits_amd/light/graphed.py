@@ -31,7 +31,7 @@ def set_enabled(on):
 
 
 class GraphedNoGrad:
-    def __init__(self, fn, warmup=3):
+    def __init__(self, fn, warmup=1):
         self.fn, self.warmup = fn, int(warmup)
         self.entries, self.counts = {}, {}
         self.failed = False
@@ -49,7 +49,9 @@ class GraphedNoGrad:
         if ent is None:
             n = self.counts[key] = self.counts.get(key, 0) + 1
             if n <= self.warmup:
-                return self.fn(batch)  # eager warm-up: plans, device tables and allocator pools exist before the capture
+                # eager warm-up: plans, device tables and allocator pools exist before the capture (one pass: the capture --
+                # tens of milliseconds -- then falls into a run's warm-up steps, not into its steady state)
+                return self.fn(batch)
             ent = self._capture(key, batch)
             if ent is None:
                 return self.fn(batch)
