@@ -386,7 +386,9 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
   g.ks = 1;
   g.vec = 0;
   static const int xcd_remap = getenv("VCVITS_NO_XCD_REMAP") ? 0 : 1;
-  g.xcd = xcd_remap;
+  // nothing to share when a column tile has one workgroup (measured: the re-deal alone costs the 64 x 10 s decode 11 %:
+  // eight XCDs walking eight far-apart regions of the tensor instead of one)
+  g.xcd = xcd_remap && g.nmt * (g.phases > 1 ? g.phases : 1) > 1;
   pl.pack_bytes = (size_t)g.phases * g.nmt * g.nch * g.JA * (3 * 2 * BM * 16);
   pl.scratch_floats = 0;
   return true;
