@@ -108,7 +108,10 @@ conv_pk_kernel(const VcvConvArgs p, const BfGeom tg, const typename EL::frag* __
   const int sw = NP ? wave - NW : wave;  // index among the staging waves (negative: an MFMA wave of a specialised launch)
 
   int bxk, mt, r;  // (column-tile, split) index, m-tile, output residue of a phased launch (0 otherwise)
-  xcd_tile_id(bxk, mt, r, tg.xcd);
+  // (16-bit-activation kernels: plain order, compiled without the re-deal -- measured on the 64 x 10 s decode the mere
+  // presence of its code, switched off at run time, cost them 10 %: RTF 0.000205 vs 0.000186, same box, profiles/r4_xcd_ab.txt)
+  if constexpr (IO != 0) bxk = blockIdx.x, mt = blockIdx.y, r = blockIdx.z;
+  else xcd_tile_id(bxk, mt, r, tg.xcd);
   const int kz = bxk % tg.ks;
   const int bx = bxk / tg.ks;
   const int b = bx / tg.ntu, ut = bx % tg.ntu;
