@@ -15,6 +15,14 @@ CASES = [  # B, H, dk, T, window, pdrop
     (2, 2, 8, 37, 4, 0.0),     # the goldens' width, one ragged tile
     (2, 4, 64, 333, 4, 0.1),   # tile edges on both axes
     (1, 4, 32, 800, 4, 0.0),   # 16 s of content frames (inference); past 896 frames the unfused path runs
+    # edges of the wave-per-query-tile forward (T <= 256, 32 / 64 channels per head): one partial tile, exact tile
+    # multiples, all eight key tiles, idle waves in the last workgroup, narrow and wide windows
+    (2, 2, 32, 31, 4, 0.0),
+    (2, 2, 64, 32, 4, 0.1),
+    (2, 1, 32, 33, 2, 0.0),
+    (2, 2, 64, 225, 7, 0.1),
+    (1, 2, 32, 256, 4, 0.0),
+    (2, 2, 64, 129, 1, 0.1),
 ]
 
 
@@ -44,6 +52,8 @@ def test_fused_attention_matches_unfused(gpu, case):
     mask = torch.ones(B, T, device=gpu)
     if B > 1:
         mask[1, T - T // 5:] = 0.0
+        if T > 40:
+            mask[0, T // 3] = 0.0  # an interior hole: a masked query row and a masked key column
     try:
         a = _run(ops, True, q, k, v, ek, ev, mask, H, w, p, gy, 77)
         b = _run(ops, False, q, k, v, ek, ev, mask, H, w, p, gy, 77)

@@ -15,6 +15,8 @@
 // Softmax, the banded relative terms, the -1e4 fill and dropout (counter-based mask regenerated from (seed, index): the
 // dropped probabilities are never stored for the backward pass) are VALU phases on the LDS tile between the two
 // contractions.  The probabilities go to HBM only when the caller wants them (training: the backward pass; `attn`).
+#include <type_traits>
+
 #include "common.h"
 #include "prof.h"
 
@@ -458,6 +460,357 @@ __global__ void __launch_bounds__(NTH) rel_attn_bwd_cols_kernel(const AttnArgs p
   }
 }
 
+// =====================================================================================================================
+// Forward, round 4: ONE WAVE PER 32 QUERY ROWS, the whole score tile of those rows in registers (T <= 256, 32 or 64
+// channels per head).
+//
+// The kernel above gives a 32-row tile to a workgroup of 8 waves and walks through five barrier-separated phases with the
+// tile in LDS; at the content encoder's sizes (T ~ 200, 64 channels per head) each phase is a few microseconds of
+// latency and the matrix pipe ran 5-15 % of the time.  Here a wave owns its 32 queries from the first load to the output
+// store and never meets another wave after the prologue:
+//   * scores TRANSPOSED: S^T tile = K^T-tile (A: rows = keys) x Q (B: columns = queries), so in the accumulator layout a
+//     lane IS a query (column l31) and its registers are that query's keys (rows (e & 3) + 8 (e >> 2) + 4 h of tile jt):
+//     the softmax is a reduction over the lane's own registers plus ONE exchange with lane ^ 32 -- no LDS, no barrier;
+//   * P V: O^T[d][i] = sum_j V[d][j] Pd[i][j] with B = the probability registers AS THEY ARE (reduction index of step s',
+//     half h := key (s' & 3) + 8 (s' >> 2) + 4 h of the tile -- any order of the reduction is fine as long as A uses the
+//     same one) and A = V read from an LDS image [d][j] of odd pitch (one conflict-free ds_read_b32 per MFMA); V is the
+//     only operand staged through LDS, once per workgroup of FW waves (the prologue's single barrier);
+//   * the two banded relative-position products ride on the matrix cores too, always in exact fp32
+//     (v_mfma_f32_32x32x2_f32): R^T = embk (9 rows of a 32-row A tile) x Q before the softmax, embv^T x band(Pd) after
+//     it; the band of a lane is exchanged through a wave-private [32][17] LDS scratch;
+//   * probabilities (training: the backward pass reads P; `attn`) leave through a wave-private 32 x 33 transpose tile so
+//     that the global stores are 128-byte runs of one row.
+// K goes through LDS the same way ([d][j]: the A fragments of S^T read consecutive keys per lane -- conflict-free): fragments
+// straight from global memory, double-buffered one key tile ahead, left each tile's MFMAs waiting for an L2 round trip.
+constexpr int FW = 4;    // waves = query tiles per workgroup
+constexpr int RWP = 17;  // pitch of the wave-private [32 queries][relative position] scratch
+constexpr int PTP = 33;  // pitch of the wave-private 32 x 32 transpose tile
+
+// compile-time loop (indices stay literals whatever the unroll thresholds say: the accumulator tiles must be registers)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ f32x16 mma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// rows of a [DK][T] fp32 matrix at one column per lane: byte offset = col_off (0x80000000 for a column >= T: out of range,
+// reads 0) + row * T4, the row term a scalar -- one v_add per load, no multiply, no compare
+struct ColLoader {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned T4;
+  __device__ __forceinline__ float operator()(unsigned col_off, int row) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, col_off + (unsigned)row * T4, 0, 0));
+  }
+};
+__device__ __forceinline__ ColLoader col_loader(const float* p, int rows, int T) {
+  ColLoader c;
+  c.rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, rows * T * 4, 0x00020000);
+  c.T4 = (unsigned)T * 4u;
+  return c;
+}
+
+// diagnostic build only (-DVCV_ATTN_STAMPS, tools/probes/attn_stamps.py): 100 MHz time stamps at the phase boundaries of
+// every wave into a buffer of their own; the product build executes none of this
+#ifdef VCV_ATTN_STAMPS
+#define VCV_STAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (p.dS && lane == 0)                                                                                        \
+      ((unsigned long long*)p.dS)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * FW + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define VCV_STAMP(k)
+#endif
+
+template <bool BF, int NKT, int DK>
+__global__ void __launch_bounds__(64 * FW) rel_attn_fwd_rows_kernel(const AttnArgs p) {
+  typedef Op<BF> O;
+  constexpr int NS = DK / O::KS;  // reduction steps of the channel contraction
+  constexpr int NT = DK / 32;     // 32-channel output tiles
+  constexpr int TPV = NKT * 32 + 1;
+  constexpr float LOG2E = 1.4426950408889634f;
+  static_assert(NKT * 32 == 64 * FW, "one staged column per thread");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T, w = p.w, nr = 2 * p.w + 1;
+  const int nkt = (T + 31) >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* bias = sm;                // [NKT * 32]: 0 for a key < T, -inf past the end (16-byte aligned: read four at a time)
+  float* Vs = bias + NKT * 32;     // [DK][TPV] (columns >= T: zero)
+  float* Ks = Vs + DK * TPV;       // [DK][TPV]
+  float* etab = Ks + DK * TPV;     // embv as [RELP][DK], rows >= nr zero
+  float* relw = etab + RELP * DK + wave * (32 * RWP + 32 * PTP);  // wave-private: [32][RWP] ...
+  float* ptile = relw + 32 * RWP;                                  // ... and [32][PTP]
+  const int g = blockIdx.y, b = g / p.H;
+  const int it = blockIdx.x * FW + wave;  // this wave's query tile (>= nkt: an idle wave that only helps staging)
+  const ColLoader lq = col_loader(p.q + (size_t)g * DK * T, DK, T), lk = col_loader(p.k + (size_t)g * DK * T, DK, T),
+                  lv = col_loader(p.v + (size_t)g * DK * T, DK, T);
+
+  VCV_STAMP(0);
+  // ---- prologue: this lane's Q column (fp32, lane half h holds channels 2 s + h) and its row of the relative-key table, then
+  // the K column of this THREAD (staging: thread = key column, all DK rows in flight); the mask words and the R^T MFMAs
+  // run under the K loads, the V loads under the S^T MFMAs
+  const int i = it * 32 + l31;  // this lane's query (>= T in the last tile or an idle wave: loads come back 0, nothing is stored)
+  const unsigned ioff = i < T ? (unsigned)i * 4u : 0x80000000u;
+  float q32[DK / 2];
+#pragma unroll
+  for (int s = 0; s < DK / 2; ++s) q32[s] = lq(ioff + h * lq.T4, 2 * s);
+  float ea[DK / 2];  // row r = l31 of the relative-key table (A operand of R^T)
+  {
+    const float* erow = p.embk + (l31 < nr ? l31 : 0) * DK + h;
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) ea[s] = erow[2 * s];
+  }
+  const unsigned joff = tid < T ? (unsigned)tid * 4u : 0x80000000u;
+  float stg[DK];
+#pragma unroll
+  for (int u = 0; u < DK; ++u) stg[u] = lk(joff, u);
+
+  // key-validity mask of the batch element as wave-wide bit masks (64 keys each); keys >= T count as unmasked here.  A
+  // masked QUERY masks its whole row: folded into the lane's copy of the bits
+  const float mi = i < T ? p.mask[(size_t)b * T + i] : 1.f;
+  unsigned long long mb[NKT / 2];
+  bool allone = true;
+#pragma unroll
+  for (int c = 0; c < NKT / 2; ++c) {
+    const int j = 64 * c + lane;
+    const float m = j < T ? p.mask[(size_t)b * T + j] : 1.f;
+    mb[c] = __ballot(m != 0.f);
+    allone = allone && mb[c] == ~0ull;
+  }
+  bias[tid] = tid < T ? 0.f : -INFINITY;
+  for (int idx = tid; idx < RELP * DK; idx += 64 * FW) etab[idx] = idx < nr * DK ? p.embv[idx] : 0.f;
+
+  // ---- relative-key logits R^T = embk x Q (exact fp32): row r of the tile = relative position r
+  {
+    f32x16 racc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) racc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) racc = mma32(l31 < nr ? ea[s] : 0.f, q32[s], racc);
+    // wave-private scratch row of this query: slot 1 + r = logit of relative position r; slots 0 and RWP - 1 stay zero, so a
+    // gather with the index clamped into [0, RWP - 1] needs no select (and a clamped scatter later dumps into them)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = acc_row(e, h);  // rows >= nr of the tile are zero (A rows l31 >= nr were zeroed)
+      if (r < RWP - 2) relw[l31 * RWP + 1 + r] = racc[e];
+    }
+    if (h == 0) relw[l31 * RWP] = 0.f; else relw[l31 * RWP + RWP - 1] = 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < DK; ++u) Ks[u * TPV + tid] = stg[u];
+#pragma unroll
+  for (int u = 0; u < DK; ++u) stg[u] = lv(joff, u);
+  __syncthreads();
+  VCV_STAMP(1);
+  VCV_STAMP(2);
+
+  // ---- S^T = K^T Q: accumulators acc[jt][e] = score of (query i, key jt * 32 + acc_row(e, h))
+  typename O::frag qo[NS];
+  if constexpr (BF) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qo[s] = O::make(s, h, [&](int d) { return lq(ioff, d); });
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qo[s] = q32[s];
+  }
+  f32x16 acc[NKT];
+  static_for<0, NKT>([&](auto JT) {
+    constexpr int jt = decltype(JT)::value;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+  });
+  const float* Kl = Ks + (BF ? 8 * h : h) * TPV + l31;  // A fragments: rows = keys (lane l31), channels by lane half
+  static_for<0, NKT>([&](auto JT) {
+    constexpr int jt = decltype(JT)::value;
+    if (jt < nkt && it < nkt) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        typename O::frag a;
+        if constexpr (BF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = (__bf16)Kl[(16 * s + e) * TPV + jt * 32];
+        } else {
+          a = Kl[2 * s * TPV + jt * 32];
+        }
+        acc[jt] = O::mma(a, qo[s], acc[jt]);
+      }
+    }
+  });
+#pragma unroll
+  for (int u = 0; u < DK; ++u) Vs[u * TPV + tid] = stg[u];
+  __syncthreads();
+  if (it >= nkt) return;
+  VCV_STAMP(3);
+
+  // ---- everything after the scores, twice: MASKED = false when every key and query of the batch element is valid (the
+  // content encoder's training batches: the mask is all ones there) skips the -1e4 fill.  ONE uniform branch picks a copy and
+  // the two never join again: a uniform `if` around work on the accumulator tiles inside a straight-line phase made the
+  // compiler shuttle all of them between AGPRs and VGPRs at every join (2,560 accvgpr reads, 9 us in the softmax phase).
+  auto rest = [&](auto MASKED) __attribute__((always_inline)) {
+    constexpr bool masked = decltype(MASKED)::value;
+    // scores in the log2 domain: v = (S + R) * qscale * log2(e) (+ -inf for a key past T, from the bias table); row maximum
+    const float qs = p.qscale * LOG2E;
+    float mx = -INFINITY;
+    static_for<0, NKT>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+      float rv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      if (jt + 1 >= it && jt <= it + 1) {  // (a branch that leaves the accumulators alone is cheap)
+        const int r1 = jt * 32 + 4 * h - i + w + 1;  // 1 + relative position of key row 0
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned idx = (unsigned)(r1 + (e & 3) + 8 * (e >> 2));  // (negative: wraps, clamps to the zero slot at the end)
+          rv[e] = relw[l31 * RWP + (idx < (unsigned)(RWP - 1) ? idx : (unsigned)(RWP - 1))];
+        }
+      }
+      unsigned wl = 0;
+      if constexpr (masked) {
+        wl = (unsigned)(mb[jt >> 1] >> ((jt & 1) * 32)) >> (4 * h);  // bit ce: key row ce + 4 h of this tile unmasked
+        wl = mi != 0.f ? wl : 0u;
+      }
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const f32x4 bz = *reinterpret_cast<const f32x4*>(bias + jt * 32 + 8 * e4 + 4 * h);
+#pragma unroll
+        for (int e1 = 0; e1 < 4; ++e1) {
+          const int e = 4 * e4 + e1, ce = e1 + 8 * e4;
+          float v = (acc[jt][e] + rv[e]) * qs;
+          if constexpr (masked) v = (wl & (1u << ce)) ? v : -1e4f * LOG2E;
+          v += bz[e1];
+          acc[jt][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    });
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    static_for<0, NKT>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float ex = __builtin_amdgcn_exp2f(acc[jt][e] - mx);
+        acc[jt][e] = ex;
+        sum += ex;
+      }
+    });
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;  // (stays factored out: everything below is linear in the probabilities; applied at the output)
+
+    VCV_STAMP(4);
+    // ---- probability stores through the transpose tile (training: the backward pass reads P; `attn`) and dropout (mask
+    // regenerated from (seed, element index)); each behind one uniform branch around its whole tile loop
+    auto store_tiles = [&](float* dst) __attribute__((always_inline)) {
+      static_for<0, NKT>([&](auto JT) {
+        constexpr int jt = decltype(JT)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ptile[l31 * PTP + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[jt][e] * inv;
+        const int jj = jt * 32 + l31;
+        float* drow = dst + ((size_t)g * T + it * 32 + h) * T + jj;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          const float v = ptile[(2 * k2 + h) * PTP + l31];
+          if (it * 32 + 2 * k2 + h < T && jj < T) drow[(size_t)(2 * k2) * T] = v;
+        }
+      });
+    };
+    if (p.P) store_tiles(p.P);
+    if (p.pdrop > 0.f) {
+      const float inv_keep = 1.f / (1.f - p.pdrop);
+      const unsigned long long seed = p.seed + (p.seed_off ? *p.seed_off : 0ull);
+      const size_t rowoff = ((size_t)g * T + i) * T + 4 * h;
+      static_for<0, NKT>([&](auto JT) {
+        constexpr int jt = decltype(JT)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[jt][e] *= drop_scale(seed, rowoff + jt * 32 + (e & 3) + 8 * (e >> 2), p.pdrop, inv_keep);
+      });
+    }
+    if (p.Pd) store_tiles(p.Pd);
+
+    // ---- band of the (dropped, un-normalised) probabilities: band[r] = Pd[i][i + r - w] into slot 1 + r of the scratch row
+    // (every element of the three tiles around the diagonal stores, with the index clamped: off-band elements land in the
+    // two dump slots)
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) relw[l31 * RWP + 1 + 8 * h + r8] = 0.f;
+    static_for<0, NKT>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+      if (jt + 1 >= it && jt <= it + 1) {
+        const int r1 = jt * 32 + 4 * h - i + w + 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned idx = (unsigned)(r1 + (e & 3) + 8 * (e >> 2));
+          relw[l31 * RWP + (idx < (unsigned)(RWP - 1) ? idx : (unsigned)(RWP - 1))] = acc[jt][e];
+        }
+      }
+    });
+
+    VCV_STAMP(5);
+    // ---- O^T = V Pd^T (+ embv^T band)
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[t][e] = 0.f;
+    const float* Vl = Vs + l31 * TPV + 4 * h;
+    static_for<0, NKT>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+      if (jt < nkt) {
+        if constexpr (BF) {
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2) {
+            bf16x8 bfr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bfr[e] = (__bf16)acc[jt][8 * m2 + e];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              bf16x8 afr;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int s2 = 8 * m2 + e;
+                afr[e] = (__bf16)Vl[32 * t * TPV + jt * 32 + (s2 & 3) + 8 * (s2 >> 2)];
+              }
+              oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, oacc[t], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              oacc[t] = mma32(Vl[32 * t * TPV + jt * 32 + (s2 & 3) + 8 * (s2 >> 2)], acc[jt][s2], oacc[t]);
+          }
+        }
+      }
+    });
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (2 * s < nr) {
+        const float bfr = relw[l31 * RWP + 1 + 2 * s + h];  // band[r = 2 s + h] of this lane's query (r >= nr: times a zero table row)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) oacc[t] = mma32(etab[(2 * s + h) * DK + 32 * t + l31], bfr, oacc[t]);
+      }
+    VCV_STAMP(6);
+    if (i < T) {
+      float* og = p.out + (size_t)g * DK * T + i;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) og[(size_t)(32 * t + acc_row(e, h)) * T] = oacc[t][e] * inv;
+    }
+    VCV_STAMP(7);
+  };
+  if (allone && __ballot(mi == 0.f) == 0ull) rest(std::false_type());
+  else rest(std::true_type());
+}
+
+size_t lds_rows(int nkt_max, int dk) {
+  return sizeof(float) * ((size_t)nkt_max * 32 + (size_t)2 * dk * (nkt_max * 32 + 1) + RELP * dk + FW * (32 * RWP + 32 * PTP));
+}
+
 // (the BSF floats hold the band-logit staging (64 * QP + RELP * 64) and the partial-output tiles (NWV * 32 * OP) too)
 size_t lds_bytes(int TP) { return sizeof(float) * ((size_t)32 * TP + 32 * RELP + TP + RELP * 64 + BSF); }
 
@@ -467,6 +820,11 @@ bool ok_shape(int B, int H, int dk, int T, int w) {
 }
 
 }  // namespace
+
+#ifdef VCV_ATTN_STAMPS
+static void* g_attn_stamps = nullptr;
+extern "C" void vcv_attn_set_stamps(void* p) { g_attn_stamps = p; }
+#endif
 
 // 0: this shape runs on the fused kernels (dk <= 64 even, T <= 896, window <= 7); else the caller keeps the unfused path
 extern "C" int vcv_rel_attn_supported(int B, int H, int dk, int T, int w) { return ok_shape(B, H, dk, T, w) ? 0 : VCV_EINVAL; }
@@ -481,6 +839,31 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
   a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.out = out, a.P = P, a.Pd = Pd;
   a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
   a.seed_off = (const unsigned long long*)vcv_get_seed_offset_ptr();
+#ifdef VCV_ATTN_STAMPS
+  a.dS = (float*)g_attn_stamps;
+#endif
+  // T <= 512: one wave per 32 query rows, scores in registers (rel_attn_fwd_rows_kernel); VCVITS_ATTN_ROWS=0 keeps the
+  // workgroup-per-tile kernel
+  static const bool rows_on = [] { const char* e = getenv("VCVITS_ATTN_ROWS"); return !(e && e[0] == '0'); }();
+  // (T <= 256: the 8 x 16 score registers of a query; a 16-tile instance spills ~500 registers and measured slower than the
+  // workgroup-per-tile kernel at T = 500, so longer sequences stay there)
+  if (rows_on && T <= 256 && (dk == 32 || dk == 64) && 2 * w + 1 <= RELP) {
+    const int nkt_max = 8;
+    const size_t ldsr = lds_rows(nkt_max, dk);
+    void (*kr)(const AttnArgs);
+#define VCV_ATTN_ROWS_PICK(BFV) kr = dk == 64 ? rel_attn_fwd_rows_kernel<BFV, 8, 64> : rel_attn_fwd_rows_kernel<BFV, 8, 32>
+    if (bf16) { VCV_ATTN_ROWS_PICK(true); } else { VCV_ATTN_ROWS_PICK(false); }
+#undef VCV_ATTN_ROWS_PICK
+    if (ldsr > 64 * 1024 && hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess)
+      return VCV_EHIP;
+    const double flops = 4.0 * B * H * (double)T * T * dk;
+    const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 100, 32 * 1000 + nkt_max * 32, 1};
+    hipEvent_t ev0, ev1;
+    vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
+    const int nqt = (T + 31) / 32;
+    VCV_LAUNCH_EV(kr, dim3((nqt + FW - 1) / FW, B * H), dim3(64 * FW), (unsigned)ldsr, (hipStream_t)stream, ev0, ev1, a);
+    return vcv_check_launch();
+  }
   const size_t lds = lds_bytes(a.TP);
   auto kern = bf16 ? rel_attn_fwd_kernel<true> : rel_attn_fwd_kernel<false>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
