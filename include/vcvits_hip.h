@@ -414,6 +414,13 @@ int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, const float
                      const float* mask, const float* P, const float* dO, float* dS, float* dq, float* dk_out, float* dv,
                      float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale, float pdrop,
                      uint64_t seed, int bf16, void* stream);
+/* The same with the forward's output `out` [B, H*dk, T] (null: as vcv_rel_attn_bwd); with `out`, dS must hold
+ * B*H*T*T + B*H*ceil(T/32)*2*(2w+1)*dk floats (per-tile partial tables of dembk / dembv follow dS; summed in a fixed order).  Given it, shapes with T <= 256 and
+ * 32 or 64 channels per head run the wave-per-tile backward (dS formed in one pass: sum_j dPd Pd = sum_d dO out). */
+int vcv_rel_attn_bwd2(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                      const float* mask, const float* P, const float* out, const float* dO, float* dS, float* dq,
+                      float* dk_out, float* dv, float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale,
+                      float pdrop, uint64_t seed, int bf16, void* stream);
 /* nn.Dropout (relative_attention_transformer.py:40,44,292): y = x * mask(seed, index) / (1-p); the
  * backward is the same call on dy with the same seed */
 int vcv_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);

@@ -20,6 +20,11 @@
 #include "common.h"
 #include "prof.h"
 
+#ifdef VCV_ATTN_STAMPS
+static void* g_attn_stamps = nullptr;
+extern "C" void vcv_attn_set_stamps(void* p) { g_attn_stamps = p; }
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -518,8 +523,8 @@ __device__ __forceinline__ ColLoader col_loader(const float* p, int rows, int T)
 #ifdef VCV_ATTN_STAMPS
 #define VCV_STAMP(k)                                                                                              \
   do {                                                                                                            \
-    if (p.dS && lane == 0)                                                                                        \
-      ((unsigned long long*)p.dS)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * FW + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if (p.Pd && lane == 0)                                                                                        \
+      ((unsigned long long*)p.Pd)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * FW + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define VCV_STAMP(k)
@@ -807,6 +812,449 @@ __global__ void __launch_bounds__(64 * FW) rel_attn_fwd_rows_kernel(const AttnAr
   else rest(std::true_type());
 }
 
+// =====================================================================================================================
+// Backward, round 4, in the forward's style (T <= 256, 32 / 64 channels per head): a ROW pass with lane = query and a
+// COLUMN pass with lane = key, every contraction with the probability-shaped operand taken from registers.
+//
+// Row pass (one wave per 32 queries): dPd^T = V^T dO on the matrix cores (A = V image in LDS, B = this lane's dO column) plus the
+// banded embv x dO product (the forward's R^T with other operands); P of the lane's rows arrives through the transpose tile
+// (coalesced 128-byte row loads); dot_i = sum_j dPd Pd and dS = P (c dPd - dot_i) (c: dropout factor) stay in registers;
+// dS leaves through the transpose tile for the column pass; dQ^T = K dS^T + embk^T band(dS) is the forward's P V with K in
+// the LDS image (the image buffer is re-staged: V first, K after the dPd MFMAs); the two table gradients are small MFMA
+// products band^T x Q^T / band^T x dO^T over the wave's 32 queries, added to HBM with atomics (as before).
+// Column pass (one wave per 32 keys): P and dS tiles are loaded with lane = key (rows of the matrices: coalesced), dropout
+// regenerated, dV^T = dO Pd and dK^T = Q dS accumulated over the query tiles with A = the LDS images of dO / Q.
+template <bool BF, int NKT, int DK>
+__global__ void __launch_bounds__(64 * FW) rel_attn_bwd_rows2_kernel(const AttnArgs p) {
+  typedef Op<BF> O;
+  constexpr int NS = DK / O::KS, NT = DK / 32, TPV = NKT * 32 + 1;
+  static_assert(NKT * 32 == 64 * FW, "one staged column per thread");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T, w = p.w, nr = 2 * p.w + 1;
+  const int nkt = (T + 31) >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Xs = sm;                  // [DK][TPV]: V, later K
+  float* etab = Xs + DK * TPV;     // embk as [RELP][DK], rows >= nr zero
+  float* relw = etab + RELP * DK + wave * (3 * 32 * RWP + 32 * PTP);  // wave-private band scratch rows: embv x dO ...
+  float* relp = relw + 32 * RWP;                                      // ... band(Pd) ...
+  float* rels = relp + 32 * RWP;                                      // ... band(dS) ...
+  float* ptile = rels + 32 * RWP;                                     // ... and the 32 x 32 transpose tile
+  const int g = blockIdx.y, b = g / p.H;
+  const int it = blockIdx.x * FW + wave;
+  const ColLoader lq = col_loader(p.q + (size_t)g * DK * T, DK, T), lk = col_loader(p.k + (size_t)g * DK * T, DK, T),
+                  lv = col_loader(p.v + (size_t)g * DK * T, DK, T), lo = col_loader(p.dO + (size_t)g * DK * T, DK, T);
+  const ColLoader lp = col_loader(p.Pin + (size_t)g * T * T, T, T);  // P of this head: rows = queries, columns = keys
+
+  VCV_STAMP(0);
+  const int i = it * 32 + l31;
+  const unsigned ioff = i < T ? (unsigned)i * 4u : 0x80000000u;
+  float do32[DK / 2];
+#pragma unroll
+  for (int s = 0; s < DK / 2; ++s) do32[s] = lo(ioff + h * lo.T4, 2 * s);
+  // dot_i = sum_j dPd[i][j] Pd[i][j] = sum_d dO[d][i] out[d][i] (the forward's output, band values included: both sides are
+  // sum_d dO[d][i] (sum_j Pd[i][j] (V[d][j] + band table))): known BEFORE the first tile, so dS is formed tile by tile in one pass
+  float dot = 0.f;
+  {
+    const ColLoader lout = col_loader(p.out + (size_t)g * DK * T, DK, T);
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) dot += do32[s] * lout(ioff + h * lout.T4, 2 * s);
+    dot += __shfl_xor(dot, 32, 64);
+  }
+  float ea[DK / 2];
+  {
+    const float* erow = p.embv + (l31 < nr ? l31 : 0) * DK + h;
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) ea[s] = erow[2 * s];
+  }
+  const unsigned joff = tid < T ? (unsigned)tid * 4u : 0x80000000u;
+  float stg[DK];
+#pragma unroll
+  for (int u = 0; u < DK; ++u) stg[u] = lv(joff, u);
+  const float mi = i < T ? p.mask[(size_t)b * T + i] : 1.f;
+  unsigned long long mb[NKT / 2];
+  bool allone = true;
+#pragma unroll
+  for (int c = 0; c < NKT / 2; ++c) {
+    const int j = 64 * c + lane;
+    const float m = j < T ? p.mask[(size_t)b * T + j] : 1.f;
+    mb[c] = __ballot(m != 0.f);
+    allone = allone && mb[c] == ~0ull;
+  }
+  for (int idx = tid; idx < RELP * DK; idx += 64 * FW) etab[idx] = idx < nr * DK ? p.embk[idx] : 0.f;
+  {  // band part of dPd: slot 1 + r of the scratch row = sum_d embv[r][d] dO[d][i]
+    f32x16 racc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) racc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) racc = mma32(l31 < nr ? ea[s] : 0.f, do32[s], racc);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = acc_row(e, h);
+      if (r < RWP - 2) relw[l31 * RWP + 1 + r] = racc[e];
+    }
+    if (h == 0) relw[l31 * RWP] = 0.f; else relw[l31 * RWP + RWP - 1] = 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < DK; ++u) Xs[u * TPV + tid] = stg[u];
+#pragma unroll
+  for (int u = 0; u < DK; ++u) stg[u] = lk(joff, u);
+  __syncthreads();
+  VCV_STAMP(1);
+
+  // ---- dPd^T = V^T dO
+  typename O::frag dob[NS];
+  if constexpr (BF) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dob[s] = O::make(s, h, [&](int d) { return lo(ioff, d); });
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dob[s] = do32[s];
+  }
+  f32x16 acc[NKT];
+  static_for<0, NKT>([&](auto JT) {
+    constexpr int jt = decltype(JT)::value;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+  });
+  const float* Xl = Xs + (BF ? 8 * h : h) * TPV + l31;
+  static_for<0, NKT>([&](auto JT) {
+    constexpr int jt = decltype(JT)::value;
+    if (jt < nkt && it < nkt) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        typename O::frag a;
+        if constexpr (BF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = (__bf16)Xl[(16 * s + e) * TPV + jt * 32];
+        } else {
+          a = Xl[2 * s * TPV + jt * 32];
+        }
+        acc[jt] = O::mma(a, dob[s], acc[jt]);
+      }
+    }
+  });
+  VCV_STAMP(2);
+  __syncthreads();  // every wave is done with the V image
+#pragma unroll
+  for (int u = 0; u < DK; ++u) Xs[u * TPV + tid] = stg[u];
+  __syncthreads();  // the K image is there
+  if (it >= nkt) return;
+  VCV_STAMP(3);
+
+  auto rest = [&](auto MASKED) __attribute__((always_inline)) {
+    constexpr bool masked = decltype(MASKED)::value;
+    const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
+    const size_t rowoff = ((size_t)g * T + i) * T + 4 * h;
+    // ---- one pass over the key tiles: dPd = MFMA + band; P through the transpose tile (loads issued two tiles ahead); c =
+    // dropout factor; dS = P (c dPd - dot), zero where masked, kept in the accumulators for dQ and sent out through the
+    // transpose tile for the column pass; band(Pd) and band(dS) into their scratch rows
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) relp[l31 * RWP + 1 + 8 * h + r8] = 0.f, rels[l31 * RWP + 1 + 8 * h + r8] = 0.f;
+    float pring[3][16];
+    auto issue_p = [&](float (&t16)[16], int jt) __attribute__((always_inline)) {
+      const int jj = jt * 32 + l31;
+      const unsigned coff = (jj < T ? (unsigned)jj * 4u : 0x80000000u) + (unsigned)(it * 32 + h) * lp.T4;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) t16[k2] = lp(coff, 2 * k2);
+    };
+    issue_p(pring[0], 0);
+    issue_p(pring[1], 1);
+    static_for<0, NKT>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+      const bool near = jt + 1 >= it && jt <= it + 1;
+      const int r1 = jt * 32 + 4 * h - i + w + 1;
+      float rv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      if (near) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned idx = (unsigned)(r1 + (e & 3) + 8 * (e >> 2));
+          rv[e] = relw[l31 * RWP + (idx < (unsigned)(RWP - 1) ? idx : (unsigned)(RWP - 1))];
+        }
+      }
+      if (jt + 2 < NKT) issue_p(pring[(jt + 2) % 3], jt + 2);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) ptile[(2 * k2 + h) * PTP + l31] = pring[jt % 3][k2];
+      float cd[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cd[e] = 1.f;
+      if (p.pdrop > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cd[e] = drop_scale(p.seed, rowoff + jt * 32 + (e & 3) + 8 * (e >> 2), p.pdrop, inv_keep);
+      }
+      unsigned wl = 0;
+      if constexpr (masked) {
+        wl = (unsigned)(mb[jt >> 1] >> ((jt & 1) * 32)) >> (4 * h);
+        wl = mi != 0.f ? wl : 0u;
+      }
+      float pd[16], dsv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = ptile[l31 * PTP + (e & 3) + 8 * (e >> 2) + 4 * h];
+        const float dpc = (acc[jt][e] + rv[e]) * cd[e];
+        float ds = pv * (dpc - dot);
+        if constexpr (masked) ds = (wl & (1u << ((e & 3) + 8 * (e >> 2)))) ? ds : 0.f;
+        pd[e] = pv * cd[e];
+        dsv[e] = ds;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[jt][e] = dsv[e];
+        ptile[l31 * PTP + (e & 3) + 8 * (e >> 2) + 4 * h] = dsv[e];
+      }
+      const int jj = jt * 32 + l31;
+      float* drow = p.dS + ((size_t)g * T + it * 32 + h) * T + jj;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const float v = ptile[(2 * k2 + h) * PTP + l31];
+        if (it * 32 + 2 * k2 + h < T && jj < T) drow[(size_t)(2 * k2) * T] = v;
+      }
+      if (near) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned idx = (unsigned)(r1 + (e & 3) + 8 * (e >> 2));
+          const unsigned ic = idx < (unsigned)(RWP - 1) ? idx : (unsigned)(RWP - 1);
+          relp[l31 * RWP + ic] = pd[e];
+          rels[l31 * RWP + ic] = dsv[e];
+        }
+      }
+    });
+
+    VCV_STAMP(4);
+    // ---- dQ^T = qscale (K dS^T + embk^T band(dS))
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[t][e] = 0.f;
+    const float* Kr = Xs + l31 * TPV + 4 * h;
+    static_for<0, NKT>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+      if (jt < nkt) {
+        if constexpr (BF) {
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2) {
+            bf16x8 bfr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bfr[e] = (__bf16)acc[jt][8 * m2 + e];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              bf16x8 afr;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int s2 = 8 * m2 + e;
+                afr[e] = (__bf16)Kr[32 * t * TPV + jt * 32 + (s2 & 3) + 8 * (s2 >> 2)];
+              }
+              oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, oacc[t], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              oacc[t] = mma32(Kr[32 * t * TPV + jt * 32 + (s2 & 3) + 8 * (s2 >> 2)], acc[jt][s2], oacc[t]);
+          }
+        }
+      }
+    });
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (2 * s < nr) {
+        const float bfr = rels[l31 * RWP + 1 + 2 * s + h];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) oacc[t] = mma32(etab[(2 * s + h) * DK + 32 * t + l31], bfr, oacc[t]);
+      }
+    if (i < T) {
+      float* og = p.dq + (size_t)g * DK * T + i;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) og[(size_t)(32 * t + acc_row(e, h)) * T] = oacc[t][e] * p.qscale;
+    }
+
+    VCV_STAMP(5);
+    // ---- table gradients of this query tile: D[r][d] = sum_i band[i][r] X[d][i] (X = Q with band(dS), dO with band(Pd)):
+    // A = the band scratch read with lane = r, B = X rows d at the wave's queries (row-strided loads, once per wave)
+    // Out as this tile's PARTIAL table (workspace behind dS: [head][query tile][dembk | dembv][r][d]); rel_attn_demb_reduce_kernel
+    // adds the partials in a fixed order (the 896 waves of a B = 32 launch adding into the same 1,152 words with atomics
+    // took 20 us of this kernel's 78, and left the two gradients order-dependent)
+    auto table_grad = [&](const float* band, const ColLoader& lx, float* dst, float scale) __attribute__((always_inline)) {
+      f32x16 dacc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dacc[t][e] = 0.f;
+      const int rl = l31 < RWP - 2 ? l31 : RWP - 2;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = band[(2 * s + h) * RWP + 1 + rl];
+        const int ii = it * 32 + 2 * s + h;
+        const unsigned coff = ii < T ? (unsigned)ii * 4u : 0x80000000u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dacc[t] = mma32(a, lx(coff + (unsigned)l31 * lx.T4, 32 * t), dacc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = acc_row(e, h);
+          if (r < nr) dst[r * DK + 32 * t + l31] = dacc[t][e] * scale;
+        }
+    };
+    float* part = p.dS + (size_t)p.B * p.H * T * T + ((size_t)g * nkt + it) * 2 * nr * DK;
+    table_grad(rels, lq, part, p.qscale);
+    table_grad(relp, lo, part + nr * DK, 1.f);
+    VCV_STAMP(6);
+    VCV_STAMP(7);
+  };
+  if (allone && __ballot(mi == 0.f) == 0ull) rest(std::false_type());
+  else rest(std::true_type());
+}
+
+template <bool BF, int NKT, int DK>
+__global__ void __launch_bounds__(64 * FW) rel_attn_bwd_cols2_kernel(const AttnArgs p) {
+  constexpr int NT = DK / 32, TPV = NKT * 32 + 1;
+  static_assert(NKT * 32 == 64 * FW, "one staged column per thread");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T;
+  const int nkt = (T + 31) >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Os = sm;               // dO image [DK][TPV]
+  float* Qs = Os + DK * TPV;    // Q image
+  const int g = blockIdx.y;
+  const int jt = blockIdx.x * FW + wave;  // this wave's key tile
+  const ColLoader lq = col_loader(p.q + (size_t)g * DK * T, DK, T), lo = col_loader(p.dO + (size_t)g * DK * T, DK, T);
+  const ColLoader lp = col_loader(p.Pin + (size_t)g * T * T, T, T), ls = col_loader(p.dS + (size_t)g * T * T, T, T);
+  {
+    const unsigned coff = tid < T ? (unsigned)tid * 4u : 0x80000000u;
+    float stg[DK];
+#pragma unroll
+    for (int u = 0; u < DK; ++u) stg[u] = lo(coff, u);
+#pragma unroll
+    for (int u = 0; u < DK; ++u) Os[u * TPV + tid] = stg[u];
+#pragma unroll
+    for (int u = 0; u < DK; ++u) stg[u] = lq(coff, u);
+#pragma unroll
+    for (int u = 0; u < DK; ++u) Qs[u * TPV + tid] = stg[u];
+  }
+  __syncthreads();
+  if (jt >= nkt) return;
+  const int j = jt * 32 + l31;
+  const unsigned joff = j < T ? (unsigned)j * 4u : 0x80000000u;
+  const float inv_keep = p.pdrop > 0.f ? 1.f / (1.f - p.pdrop) : 1.f;
+  f32x16 av[NT], ak[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) av[t][e] = ak[t][e] = 0.f;
+  const float* Ol = Os + l31 * TPV + 4 * h;
+  const float* Ql = Qs + l31 * TPV + 4 * h;
+  float pv[2][16], ds[2][16];
+  auto load_tiles = [&](float (&pq)[16], float (&dq_)[16], int it) __attribute__((always_inline)) {
+    const unsigned roff = joff + (unsigned)(it * 32 + 4 * h) * lp.T4;  // (a row past T lands past the matrix: 0)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pq[e] = lp(roff, (e & 3) + 8 * (e >> 2));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq_[e] = ls(roff, (e & 3) + 8 * (e >> 2));
+  };
+  load_tiles(pv[0], ds[0], 0);
+  static_for<0, NKT>([&](auto IT) {
+    constexpr int it = decltype(IT)::value;
+    if (it < nkt) {
+      if (it + 1 < nkt) load_tiles(pv[(it + 1) & 1], ds[(it + 1) & 1], it + 1);
+      float (&pc)[16] = pv[it & 1];
+      float (&dc)[16] = ds[it & 1];
+      if (p.pdrop > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          pc[e] *= drop_scale(p.seed, ((size_t)g * T + it * 32 + 4 * h + (e & 3) + 8 * (e >> 2)) * T + j, p.pdrop, inv_keep);
+      }
+      if constexpr (BF) {
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          bf16x8 bp, bd;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bp[e] = (__bf16)pc[8 * m2 + e], bd[e] = (__bf16)dc[8 * m2 + e];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            bf16x8 ao, aq;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int s2 = 8 * m2 + e, off = 32 * t * TPV + it * 32 + (s2 & 3) + 8 * (s2 >> 2);
+              ao[e] = (__bf16)Ol[off], aq[e] = (__bf16)Ql[off];
+            }
+            av[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, bp, av[t], 0, 0, 0);
+            ak[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ak[t], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int off = 32 * t * TPV + it * 32 + (s2 & 3) + 8 * (s2 >> 2);
+            av[t] = mma32(Ol[off], pc[s2], av[t]);
+            ak[t] = mma32(Ql[off], dc[s2], ak[t]);
+          }
+        }
+      }
+    }
+  });
+  if (j < T) {
+    float* dvp = p.dv + (size_t)g * DK * T + j;
+    float* dkp = p.dk_ + (size_t)g * DK * T + j;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const size_t ro = (size_t)(32 * t + acc_row(e, h)) * T;
+        dvp[ro] = av[t][e];
+        dkp[ro] = ak[t][e] * p.qscale;
+      }
+  }
+}
+
+// dembk / dembv [nr * dk] = sum over the (head, query tile) partial tables, in index order (deterministic).  Block = 64 table
+// elements x 16 slices of the partial range; the slices meet in LDS.
+__global__ void __launch_bounds__(1024) rel_attn_demb_reduce_kernel(const float* __restrict__ part, float* __restrict__ dembk,
+                                                                   float* __restrict__ dembv, int npart, int ne) {
+  __shared__ float red[16][65];
+  const int x = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int el = blockIdx.x * 64 + x;  // element of the concatenated [dembk | dembv] table (2 * ne floats per partial)
+  float a = 0.f;
+  if (el < 2 * ne) {
+    const int per = (npart + 15) / 16;
+    const int p0 = sl * per, p1 = p0 + per < npart ? p0 + per : npart;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int q = p0;
+    for (; q + 3 < p1; q += 4) {
+      a0 += part[(size_t)q * 2 * ne + el];
+      a1 += part[(size_t)(q + 1) * 2 * ne + el];
+      a2 += part[(size_t)(q + 2) * 2 * ne + el];
+      a3 += part[(size_t)(q + 3) * 2 * ne + el];
+    }
+    for (; q < p1; ++q) a0 += part[(size_t)q * 2 * ne + el];
+    a = (a0 + a1) + (a2 + a3);
+  }
+  red[sl][x] = a;
+  __syncthreads();
+  if (sl == 0 && el < 2 * ne) {
+    float t = red[0][x];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) t += red[k2][x];
+    if (el < ne) dembk[el] = t; else dembv[el - ne] = t;
+  }
+}
+
+size_t lds_bwd_rows2(int nkt_max, int dk) {
+  return sizeof(float) * ((size_t)dk * (nkt_max * 32 + 1) + RELP * dk + FW * (3 * 32 * RWP + 32 * PTP));
+}
+size_t lds_bwd_cols2(int nkt_max, int dk) { return sizeof(float) * ((size_t)2 * dk * (nkt_max * 32 + 1)); }
+
 size_t lds_rows(int nkt_max, int dk) {
   return sizeof(float) * ((size_t)nkt_max * 32 + (size_t)2 * dk * (nkt_max * 32 + 1) + RELP * dk + FW * (32 * RWP + 32 * PTP));
 }
@@ -820,11 +1268,6 @@ bool ok_shape(int B, int H, int dk, int T, int w) {
 }
 
 }  // namespace
-
-#ifdef VCV_ATTN_STAMPS
-static void* g_attn_stamps = nullptr;
-extern "C" void vcv_attn_set_stamps(void* p) { g_attn_stamps = p; }
-#endif
 
 // 0: this shape runs on the fused kernels (dk <= 64 even, T <= 896, window <= 7); else the caller keeps the unfused path
 extern "C" int vcv_rel_attn_supported(int B, int H, int dk, int T, int w) { return ok_shape(B, H, dk, T, w) ? 0 : VCV_EINVAL; }
@@ -840,7 +1283,7 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
   a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
   a.seed_off = (const unsigned long long*)vcv_get_seed_offset_ptr();
 #ifdef VCV_ATTN_STAMPS
-  a.dS = (float*)g_attn_stamps;
+  if (!Pd) a.Pd = (float*)g_attn_stamps;
 #endif
   // T <= 512: one wave per 32 query rows, scores in registers (rel_attn_fwd_rows_kernel); VCVITS_ATTN_ROWS=0 keeps the
   // workgroup-per-tile kernel
@@ -878,18 +1321,55 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
 
 // Gradients of vcv_rel_attn_fwd.  P: the probabilities the forward saved; dS: [B*H, T, T] workspace; dembk / dembv
 // [2w+1, dk] are overwritten.
-extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,
-                                const float* mask, const float* P, const float* dO, float* dS, float* dq, float* dk_out,
-                                float* dv, float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale,
-                                float pdrop, uint64_t seed, int bf16, void* stream) {
+// vcv_rel_attn_bwd2: the same with the forward's output `out` [B, H*dk, T] (may be null); dS is then a workspace of
+// B*H*T*T + B*H*ceil(T/32)*2*(2w+1)*dk floats (the per-tile partial tables of the two table gradients follow dS).  With it the row pass knows
+// sum_j dPd Pd of every query (= sum_d dO out) before its first tile and forms dS in one pass (T <= 256, dk 32 / 64:
+// rel_attn_bwd_rows2_kernel / rel_attn_bwd_cols2_kernel); without it, or for other shapes, the workgroup-per-tile kernels run.
+extern "C" int vcv_rel_attn_bwd2(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                                 const float* mask, const float* P, const float* out, const float* dO, float* dS, float* dq,
+                                 float* dk_out, float* dv, float* dembk, float* dembv, int B, int H, int dk, int T, int w,
+                                 float qscale, float pdrop, uint64_t seed, int bf16, void* stream) {
   if (!q || !k || !v || !embk || !embv || !mask || !P || !dO || !dS || !dq || !dk_out || !dv || !dembk || !dembv ||
       !ok_shape(B, H, dk, T, w) || pdrop < 0.f || pdrop >= 1.f)
     return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   AttnArgs a = {};
-  a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.Pin = P, a.dO = dO;
+  a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.Pin = P, a.dO = dO, a.out = (float*)out;
+#ifdef VCV_ATTN_STAMPS
+  a.Pd = (float*)g_attn_stamps;
+#endif
   a.dS = dS, a.dq = dq, a.dk_ = dk_out, a.dv = dv, a.dembk = dembk, a.dembv = dembv;
   a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
+  static const bool rows_on = [] { const char* e = getenv("VCVITS_ATTN_ROWS"); return !(e && e[0] == '0'); }();
+  if (rows_on && out && T <= 256 && (dk == 32 || dk == 64) && 2 * w + 1 <= RELP) {
+    void (*kr)(const AttnArgs);
+    void (*kc)(const AttnArgs);
+    if (bf16) {
+      kr = dk == 64 ? rel_attn_bwd_rows2_kernel<true, 8, 64> : rel_attn_bwd_rows2_kernel<true, 8, 32>;
+      kc = dk == 64 ? rel_attn_bwd_cols2_kernel<true, 8, 64> : rel_attn_bwd_cols2_kernel<true, 8, 32>;
+    } else {
+      kr = dk == 64 ? rel_attn_bwd_rows2_kernel<false, 8, 64> : rel_attn_bwd_rows2_kernel<false, 8, 32>;
+      kc = dk == 64 ? rel_attn_bwd_cols2_kernel<false, 8, 64> : rel_attn_bwd_cols2_kernel<false, 8, 32>;
+    }
+    const size_t l1 = lds_bwd_rows2(8, dk), l2 = lds_bwd_cols2(8, dk);
+    if ((l1 > 64 * 1024 && hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1) != hipSuccess) ||
+        (l2 > 64 * 1024 && hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess))
+      return VCV_EHIP;
+    const double flops = 4.0 * B * H * (double)T * T * dk;
+    const int nqt = (T + 31) / 32;
+    const dim3 grid((nqt + FW - 1) / FW, B * H), block(64 * FW);
+    hipEvent_t ev0, ev1;
+    const int tag[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 101, 32 * 1000 + 256, 1};
+    vcv_prof_events(VCV_PROF_ATTN, flops, tag, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
+    VCV_LAUNCH_EV(kr, grid, block, (unsigned)l1, st, ev0, ev1, a);
+    const int tag2[12] = {B, bf16 ? 2 : 4, dk, H, 0, T, 1, 1, 1, 102, 32 * 1000 + 256, 1};
+    vcv_prof_events(VCV_PROF_ATTN, flops, tag2, 12, &ev0, &ev1, 0.0, bf16 ? flops / VCV_PEAK_BF16_MFMA : 0.0);
+    VCV_LAUNCH_EV(kc, grid, block, (unsigned)l2, st, ev0, ev1, a);
+    const int nel = (2 * w + 1) * dk;
+    hipLaunchKernelGGL(rel_attn_demb_reduce_kernel, dim3((2 * nel + 63) / 64), dim3(1024), 0, st,
+                       (const float*)(dS + (size_t)B * H * T * T), dembk, dembv, B * H * nqt, nel);
+    return vcv_check_launch();
+  }
   const size_t ne = sizeof(float) * (2 * w + 1) * dk;
   if (hipMemsetAsync(dembk, 0, ne, st) != hipSuccess || hipMemsetAsync(dembv, 0, ne, st) != hipSuccess) return VCV_EHIP;
   const size_t lds = lds_bytes(a.TP);
@@ -909,4 +1389,12 @@ extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, 
     return VCV_EHIP;
   VCV_LAUNCH_EV(cols, dim3((T + 31) / 32, B * H), dim3(NTH), (unsigned)lds2, st, ev0, ev1, a);
   return vcv_check_launch();
+}
+
+extern "C" int vcv_rel_attn_bwd(const float* q, const float* k, const float* v, const float* embk, const float* embv,
+                                const float* mask, const float* P, const float* dO, float* dS, float* dq, float* dk_out,
+                                float* dv, float* dembk, float* dembv, int B, int H, int dk, int T, int w, float qscale,
+                                float pdrop, uint64_t seed, int bf16, void* stream) {
+  return vcv_rel_attn_bwd2(q, k, v, embk, embv, mask, P, nullptr, dO, dS, dq, dk_out, dv, dembk, dembv, B, H, dk, T, w, qscale,
+                           pdrop, seed, bf16, stream);
 }

@@ -1846,7 +1846,7 @@ class _RelAttnFusedFn(torch.autograd.Function):
                                      B, H, dk, T, window, qscale, pdrop, seed, bf, stream()), "vcv_rel_attn_fwd")
         LAUNCH_COUNTS["attn_fused"] += 1
         ctx.cfg = (H, window, qscale, pdrop, seed, bf)
-        ctx.save_for_backward(q, k, v, embk, embv, mask, P)
+        ctx.save_for_backward(q, k, v, embk, embv, mask, P, out)
         attn = None
         if want_attn:
             attn = (Pd if pdrop > 0 else P).view(B, H, T, T)
@@ -1855,17 +1855,19 @@ class _RelAttnFusedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dattn):
-        q, k, v, embk, embv, mask, P = ctx.saved_tensors
+        q, k, v, embk, embv, mask, P, out = ctx.saved_tensors
         H, window, qscale, pdrop, seed, bf = ctx.cfg
         dout = _f32c(dout)
         B, C, T = q.shape
         dk = C // H
-        dS = torch.empty_like(P)
+        # workspace: dS [G, T, T] + the per-(head, query tile) partial tables of the two table gradients
+        dS = torch.empty((P.numel() + B * H * ((T + 31) // 32) * 2 * embk.shape[-2] * dk,), device=P.device, dtype=torch.float32)
         dq, dkk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dembk, dembv = torch.empty_like(embk), torch.empty_like(embv)
-        check(lib().vcv_rel_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(embk), ptr(embv), ptr(mask), ptr(P), ptr(dout), ptr(dS),
-                                     ptr(dq), ptr(dkk), ptr(dv), ptr(dembk), ptr(dembv), B, H, dk, T, window, qscale, pdrop,
-                                     seed, bf, stream()), "vcv_rel_attn_bwd")
+        # (the forward's output rides along: sum_j dPd Pd = sum_d dO out lets the row pass form dS tile by tile)
+        check(lib().vcv_rel_attn_bwd2(ptr(q), ptr(k), ptr(v), ptr(embk), ptr(embv), ptr(mask), ptr(P), ptr(out), ptr(dout),
+                                      ptr(dS), ptr(dq), ptr(dkk), ptr(dv), ptr(dembk), ptr(dembv), B, H, dk, T, window, qscale,
+                                      pdrop, seed, bf, stream()), "vcv_rel_attn_bwd2")
         return dq, dkk, dv, dembk, dembv, None, None, None, None, None, None
 
 
