@@ -39,6 +39,19 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// diagnostic build only (-DVCV_X3_STAMPS, tools/probes/x3_stamps.py): 100 MHz stamps of workgroup phases; the product build
+// executes none of this
+#ifdef VCV_X3_STAMPS
+__device__ unsigned long long* g_x3_stamps;
+#define VCV_X3_STAMP(k)                                                                                          \
+  do {                                                                                                          \
+    if (g_x3_stamps && lane == 0)                                                                               \
+      g_x3_stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define VCV_X3_STAMP(k)
+#endif
+
 constexpr int NPROD = 4;  // producer waves: 1 weight-DMA wave + 3 input-staging waves
 constexpr int NXW = 3;
 constexpr int MAXT = 2;   // pipelined staging tasks per input wave and stage
@@ -149,6 +162,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
     if (S <= 0) return;
     const int pw = wave - NW;
     if (pw == 0) {
+      VCV_X3_STAMP(4);
       // ---- weight DMA wave: the slab of stage s + NRING - 1 is issued while stage s is multiplied (NRING-slot ring); it
       // passes the barrier of stage s as soon as the slab of stage s + 1 has landed, with later slabs still in flight
       const char* wtile = wp + ((size_t)r * gridDim.y + mt) * (size_t)tg.nch * JA * TAPB;
@@ -185,6 +199,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
         if (fly >= 2) wait_vm<2 * nA>(); else if (fly == 1) wait_vm<nA>(); else wait_vm<0>();
         asm volatile("s_barrier" ::: "memory");
       }
+      VCV_X3_STAMP(5);
       return;
     }
     // ---- input staging waves.  A task = (half h of the 16-channel group, block of 256 positions): 8 channels x 4
@@ -264,6 +279,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
     }
     int g = g_begin, j = 0;
     load_stage(P0(), g, j);
+    if (xi == 0) VCV_X3_STAMP(6);
     barrier_lds();
     for (int s = 0; s < S; s += 2) {
       {  // even stage: its tasks sit in set 0; the next stage's loads go to set 1
@@ -287,6 +303,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
   }
 
   // ==================================================================================================== MFMA waves
+  if (wave == 0) VCV_X3_STAMP(0);
   const int wm = wave / WN, wn = wave % WN;
   int laneoff[TN];
 #pragma unroll
@@ -306,6 +323,7 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
 
   if (S > 0) {
     __syncthreads();
+    if (wave == 0) VCV_X3_STAMP(1);
     const int aoff = (h * BM + wm * TM * 32 + l31) * 16;
     int g = g_begin, sj = 0;
     for (int s = 0; s < S; ++s) {
@@ -345,7 +363,9 @@ conv_x3_kernel(const VcvConvArgs p, const BfGeom tg, const char* __restrict__ wp
       __syncthreads();  // publishes stage s + 1 (LDS writes + the weight DMA) and retires the reads of stage s
     }
   }
+  if (wave == 0) VCV_X3_STAMP(2);
   conv_tile_epilogue<TM, TN>(p, tg, acc, smem, part, wave, wm, wn, lane, b, kz, u0, m0, oo, BM);
+  if (wave == 0) VCV_X3_STAMP(3);
 }
 
 struct Plan {
@@ -558,3 +578,10 @@ extern "C" int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* s
   return g_terms == 6 ? run_n<6>(*args, pl, (char*)pack_ws, scratch_ws, flip, pack_valid != 0, st)
                       : run_n<9>(*args, pl, (char*)pack_ws, scratch_ws, flip, pack_valid != 0, st);
 }
+
+#ifdef VCV_X3_STAMPS
+extern "C" int vcv_x3_set_stamps(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_x3_stamps), &q, sizeof(q)) == hipSuccess ? 0 : 1;
+}
+#endif
