@@ -415,7 +415,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
 }
 
 // variants: 0: 128x256 (8 MFMA waves of 2x2 tiles)   1: 128x128 (8 waves of 2x1)   2: 256x128 (8 waves of 2x2)   3: 64x256 (8 waves of 1x2)
-//           4: 64x128 (8 waves of 1x1)   5: 32x256 (8 waves of 1x1)
+//           4: 64x128 (8 waves of 1x1)   5: 32x256 (8 waves of 1x1)   6: 64x512 (8 waves of 1x4)
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
   if (U < 96) return false;
@@ -436,7 +436,14 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     else if (a.Mg >= 256 && eff(256, 128) >= e128 - 0.1 && make_plan(a, 256, 128, 8, pl, 2)) pl.variant = 2, ok = true;
     else if (make_plan(a, 128, 128, 8, pl)) pl.variant = 1, ok = true;
   } else if (a.Mg >= 48) {
-    if (U > 160 && eff(64, 256) >= eff(64, 128) - 0.02 && make_plan(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
+    // 64 x 512 (8 waves of 1 x 4 tiles: 15 fragment reads per 24 MFMAs instead of 9 per 12) where 64 x 256 needs more than one
+    // round of 256 workgroups and the wider tile still fills the chip: the generator's 64-channel layers ran two full
+    // rounds, each with its own 4 us prologue and 6 us store burst (tools/probes/x3_stamps.py)
+    static const bool no_v6 = getenv("VCVITS_X3_NO_V6") != nullptr;
+    if (!no_v6 && nph == 1 && blocks(64, 256) > 256 && blocks(64, 512) >= 192 && eff(64, 512) >= eff(64, 256) - 0.02 &&
+        make_plan(a, 64, 512, 8, pl))
+      pl.variant = 6, ok = true;
+    else if (U > 160 && eff(64, 256) >= eff(64, 128) - 0.02 && make_plan(a, 64, 256, 8, pl)) pl.variant = 3, ok = true;
     else if (make_plan(a, 64, 128, 8, pl)) pl.variant = 4, ok = true;
   } else {
     if (make_plan(a, 32, 256, 8, pl)) pl.variant = 5, ok = true;
@@ -451,7 +458,16 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // too few tiles for 256 CUs: split the channel groups over ks workgroups per tile (deterministic slabs + finishing pass)
   const long long nb = blocks(pl.BM, pl.BN);
   if (nph == 1 && nb < 192 && pl.g.nch >= 4) {
-    long long ks = (256 + nb / 2) / nb;
+    // the split that costs the fewest (rounds of 256 workgroups) x (channel groups per workgroup): rounding to the nearest
+    // count put 288 and 260 workgroups -- a second round for 32 and for 4 of them -- on two of DiscriminatorS's last layers
+    long long ks = 1, best = (long long)1 << 60;
+    static const bool old_ks = getenv("VCVITS_X3_OLD_KS") != nullptr;
+    for (long long c = 2; c <= pl.g.nch / 2; ++c) {
+      // (+ 3: a workgroup's prologue and epilogue cost about three channel groups of a 128-row tile; + c: the finishing pass reads c slabs)
+      const long long cost = ((nb * c + 255) / 256) * ((pl.g.nch + c - 1) / c + 3) * 64 + c;
+      if (cost < best) best = cost, ks = c;
+    }
+    if (old_ks) ks = (256 + nb / 2) / nb;
     if (ks > pl.g.nch / 2) ks = pl.g.nch / 2;
     if (ks >= 2) {
       pl.g.ks = (int)ks;
@@ -514,6 +530,7 @@ int run_n(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip,
     case 2: return launch<NTERM, 2, 2, 4, 2, 2>(a, pl, wp, part, flip, pv, st);  // 256 x 128
     case 3: return launch<NTERM, 1, 2, 2, 4>(a, pl, wp, part, flip, pv, st);
     case 4: return launch<NTERM, 1, 1, 2, 4>(a, pl, wp, part, flip, pv, st);
+    case 6: return launch<NTERM, 1, 4, 2, 4>(a, pl, wp, part, flip, pv, st);  // 64 x 512
     default: return launch<NTERM, 1, 1, 1, 8>(a, pl, wp, part, flip, pv, st);
   }
 }
