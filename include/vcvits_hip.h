@@ -184,6 +184,9 @@ int vcv_conv_x3_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
 int vcv_conv_pk_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
 int vcv_conv_bf16_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
 int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* stream);
+/* Host table -> device on `stream`; inside a stream capture the copy is replayed from `src`, which the caller keeps alive
+ * and unchanged for the life of the graph (the python layer's device tables of a captured pass). */
+int vcv_upload_table(void* dst, const void* src, int64_t bytes, void* stream);
 int vcv_conv_x3_plan(const VcvConvArgs* args, int flip, int64_t* out);
 int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, int flip, int pack_valid, void* stream);
 int vcv_conv_x3_set_terms(int n);

@@ -101,3 +101,142 @@ def test_graph_replays_draw_fresh_dropout_masks(gpu):
     for i in range(len(outs)):
         for j in range(i + 1, len(outs)):
             assert not torch.equal(outs[i][0], outs[j][0]) and not torch.equal(outs[i][1], outs[j][1]), (i, j)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graphed_step_equals_eager(gpu, dtype):
+    """zero_grad + forward + backward of each optimizer index replayed from a HIP graph (graphed.GraphedStep) against the
+    eager loop: same losses step for step from identical state, both indices captured, the optimizer still steps."""
+    from vcvits_amd import ops
+    from vcvits_amd.light import graphed
+    from vcvits_amd.light.vcvits import VCVITS
+    cfg = _cfg(0.0)
+    torch.manual_seed(11)
+    ref = VCVITS(**cfg)
+    sd = copy.deepcopy(ref.state_dict())
+    batches = _batches(cfg, 2, gpu, with_draws=True)
+    losses, params = {}, {}
+    ops.set_compute_dtype(dtype)
+    try:
+        for mode in (False, True):
+            graphed.set_step_enabled(mode)
+            torch.manual_seed(12)
+            mod = VCVITS(**cfg)
+            mod.load_state_dict(sd)
+            mod = mod.to(gpu)
+            mod.configure_optimizers()
+            ls = []
+            for i in range(9):
+                out = mod.fit_batch(batches[i % 2])
+                ls.append((float(out["g"]), float(out["d"])))
+            losses[mode] = ls
+            params[mode] = (mod.optim_g.flat.clone(), mod.optim_d.flat.clone())
+            if mode:
+                sg = mod.__dict__["_step_graph"]
+                assert not sg.failed and sg.replays >= 8, (sg.failed, sg.replays)  # two batch shapes x two indices, then replays
+            else:
+                assert "_step_graph" not in mod.__dict__ or mod.__dict__["_step_graph"].replays == 0
+            mod.optim_g.close()
+            mod.optim_d.close()
+    finally:
+        graphed.set_step_enabled(False)
+        ops.set_compute_dtype("f32")
+    tol = 2e-5 if dtype == "f32" else 2e-3  # (weight-gradient atomics / split orders move the parameters in the last bits)
+    for (g0, d0), (g1, d1) in zip(losses[False], losses[True]):
+        assert abs(g0 - g1) <= tol * abs(g0) and abs(d0 - d1) <= tol * abs(d0), (losses[False], losses[True])
+    # parameters: an Adam step moves an element by about the learning rate whatever the gradient's size, so a gradient that
+    # differs in its last bits (atomics, split orders) around zero can move it the other way: a few learning rates per element
+    lr = float(cfg["train"]["learning_rate"])
+    for a, b in zip(params[False], params[True]):
+        assert float((a - b).abs().max()) <= 2.5 * lr * 9 + 1e-4 * float(a.abs().max()), float((a - b).abs().max())
+    assert losses[True][0] != losses[True][-1]  # the parameters moved
+
+
+def test_graphed_step_vocoder_workload(gpu):
+    """The benchmark's module (VocoderGAN, BASELINE configs[1]) at reduced width: graph steps equal eager steps."""
+    from vcvits_amd import configs, synthetic
+    from vcvits_amd.light import graphed
+    from vcvits_amd.light.vcvits import VocoderGAN
+    cfg = configs.base()
+    cfg["model"].update({"inter_channels": 16, "upsample_initial_channel": 32, "multi_period_discriminator_periods": [2, 3]})
+    cfg["data"]["n_mel_channels"] = 40
+    cfg["train"]["segment_size"] = 4096
+    torch.manual_seed(5)
+    sd = copy.deepcopy(VocoderGAN(**cfg).state_dict())
+    batch = {k: v.to(gpu) for k, v in synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3).items()}
+    res = {}
+    try:
+        for mode in (False, True):
+            graphed.set_step_enabled(mode)
+            mod = VocoderGAN(**cfg)
+            mod.load_state_dict(sd)
+            mod = mod.to(gpu)
+            mod.configure_optimizers()
+            ls = []
+            for _ in range(7):
+                out = mod.fit_batch(batch)
+                ls.append((float(out["g"]), float(out["d"])))
+            res[mode] = ls
+            if mode:
+                sg = mod.__dict__["_step_graph"]
+                assert not sg.failed and sg.replays >= 8, (sg.failed, sg.replays)
+            mod.optim_g.close()
+            mod.optim_d.close()
+    finally:
+        graphed.set_step_enabled(False)
+    for (g0, d0), (g1, d1) in zip(res[False], res[True]):
+        assert abs(g0 - g1) <= 2e-5 * abs(g0) and abs(d0 - d1) <= 2e-5 * abs(d0), (res[False], res[True])
+
+
+def test_captured_backward_regenerates_the_replays_dropout_mask(gpu):
+    """Inside a captured pass the attention backward (and vcv_dropout's) must regenerate the mask of ITS replay: the
+    device-side seed offset read by the forward.  A replay with offset k equals the eager pass run with host seed S + k."""
+    from vcvits_amd import ops
+    from vcvits_amd._lib import lib
+    gen = torch.Generator().manual_seed(4)
+    q = torch.randn(2, 64, 120, generator=gen).to(gpu).requires_grad_(True)
+    x = torch.randn(4, 32, 200, generator=gen).to(gpu).requires_grad_(True)
+    ek = (torch.randn(1, 9, 32, generator=gen) * 0.1).to(gpu).requires_grad_(True)
+    mask = torch.ones(2, 120, device=gpu)
+    gy = torch.randn(2, 64, 120, generator=gen).to(gpu)
+
+    def run():
+        o, _ = ops.rel_attention(q, q, q, ek, ek, mask, 2, 4, pdrop=0.3, training=True, want_attn=False)
+        y = ops.dropout(x, 0.3, True)
+        gq, gek, gx = torch.autograd.grad([o, y], [q, ek, x], [gy, torch.ones_like(y)])
+        return o, y, gq, gek, gx
+
+    seeds = []
+    real_next = ops.next_seed
+    L = lib()
+    off = torch.zeros(1, dtype=torch.int64, device=gpu)
+    try:
+        def recording():
+            s = real_next()
+            seeds.append(s)
+            return s
+        ops.next_seed = recording
+        run()  # warm-up (plans, allocator)
+        seeds.clear()
+        graph = torch.cuda.CUDAGraph()
+        L.vcv_set_seed_offset_ptr(off.data_ptr())
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            outs = run()
+        L.vcv_set_seed_offset_ptr(None)
+        baked = list(seeds)
+        assert len(baked) == 2, baked  # attention, dropout
+        for k in (1, 5):
+            off.fill_(k)
+            graph.replay()
+            torch.cuda.synchronize()
+            got = [t.clone() for t in outs]
+            it = iter((s + k) % (1 << 64) for s in baked)
+            ops.next_seed = lambda: next(it)
+            want = run()
+            for a, b in zip(got, want):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
+            assert float((got[1] == 0).float().mean()) > 0.2
+    finally:
+        ops.next_seed = real_next
+        L.vcv_set_seed_offset_ptr(None)

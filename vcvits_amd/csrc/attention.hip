@@ -57,7 +57,7 @@ struct AttnArgs {
   int B, H, dk, T, w, TP;
   float qscale, pdrop;
   unsigned long long seed;
-  const unsigned long long* seed_off;  // forward launches only: *seed_off is added to seed (graph replays: version.hip)
+  const unsigned long long* seed_off;  // non-null while a launch sequence is captured: *seed_off is added to seed (graph replays: version.hip)
 };
 
 // One MFMA step: F32: 2 reduction elements (lane half h supplies element 2s + h); BF16: 16 (lane half h supplies
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(NTH) rel_attn_bwd_rows_kernel(const AttnArgs p
       if (r >= 0 && r < nr) v += rel[m * RELP + r];
       Dr[j] = v;
       const float pv = p.Pin[rowoff + j];
-      const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, rowoff + j, p.pdrop, inv_keep) : pv;
+      const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), rowoff + j, p.pdrop, inv_keep) : pv;
       dot += v * pd;
     }
     dot = wsum_all(dot);
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(NTH) rel_attn_bwd_rows_kernel(const AttnArgs p
       float ds = 0.f;
       if (j < T) {
         const float pv = p.Pin[rowoff + j];
-        const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, rowoff + j, p.pdrop, inv_keep) : pv;
+        const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), rowoff + j, p.pdrop, inv_keep) : pv;
         ds = pd * Dr[j] - pv * dot;
         if (mi * mrow[j] == 0.f) ds = 0.f;
         p.dS[rowoff + j] = ds;
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(NTH) rel_attn_bwd_rows_kernel(const AttnArgs p
       if (i >= T || j < 0 || j >= T) continue;
       const size_t off = ((size_t)g * T + i) * T + j;
       const float pv = p.Pin[off];
-      const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed, off, p.pdrop, inv_keep) : pv;
+      const float pd = p.pdrop > 0.f ? pv * drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), off, p.pdrop, inv_keep) : pv;
       ek += D[m * TP + j] * qg[(size_t)d * T + i];
       ev += pd * og[(size_t)d * T + i];
     }
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(NTH) rel_attn_bwd_cols_kernel(const AttnArgs p
       const typename O::frag fp = O::make(s, h, [&](int ii) {
         const int i = c0 + ii;
         const float pv = ldm(mP, i, j);  // (0 past the matrix)
-        return p.pdrop > 0.f ? pv * drop_scale(p.seed, ((size_t)g * T + i) * T + j, p.pdrop, inv_keep) : pv;
+        return p.pdrop > 0.f ? pv * drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), ((size_t)g * T + i) * T + j, p.pdrop, inv_keep) : pv;
       });
       const typename O::frag fs = O::make(s, h, [&](int ii) { return ldm(mS, c0 + ii, j); });
       const typename O::frag fo = O::make(s, h, [&](int ii) { return orow[ii]; });
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(64 * FW) rel_attn_bwd_rows2_kernel(const AttnA
       for (int e = 0; e < 16; ++e) cd[e] = 1.f;
       if (p.pdrop > 0.f) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cd[e] = drop_scale(p.seed, rowoff + jt * 32 + (e & 3) + 8 * (e >> 2), p.pdrop, inv_keep);
+        for (int e = 0; e < 16; ++e) cd[e] = drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), rowoff + jt * 32 + (e & 3) + 8 * (e >> 2), p.pdrop, inv_keep);
       }
       unsigned wl = 0;
       if constexpr (masked) {
@@ -1171,7 +1171,7 @@ __global__ void __launch_bounds__(64 * FW) rel_attn_bwd_cols2_kernel(const AttnA
       if (p.pdrop > 0.f) {
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          pc[e] *= drop_scale(p.seed, ((size_t)g * T + it * 32 + 4 * h + (e & 3) + 8 * (e >> 2)) * T + j, p.pdrop, inv_keep);
+          pc[e] *= drop_scale(p.seed + (p.seed_off ? *p.seed_off : 0ull), ((size_t)g * T + it * 32 + 4 * h + (e & 3) + 8 * (e >> 2)) * T + j, p.pdrop, inv_keep);
       }
       if constexpr (BF) {
 #pragma unroll
@@ -1335,6 +1335,7 @@ extern "C" int vcv_rel_attn_bwd2(const float* q, const float* k, const float* v,
   hipStream_t st = (hipStream_t)stream;
   AttnArgs a = {};
   a.q = q, a.k = k, a.v = v, a.embk = embk, a.embv = embv, a.mask = mask, a.Pin = P, a.dO = dO, a.out = (float*)out;
+  a.seed_off = (const unsigned long long*)vcv_get_seed_offset_ptr();  // (a captured training pass: the same offset as its forward)
 #ifdef VCV_ATTN_STAMPS
   a.Pd = (float*)g_attn_stamps;
 #endif

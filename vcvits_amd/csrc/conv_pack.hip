@@ -220,3 +220,10 @@ extern "C" int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* str
     hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const VcvPackJob*)table_dev + nt, n - nt);
   return vcv_check_launch();
 }
+
+// Host table -> device on `stream` (hipMemcpyAsync).  Inside a stream capture this becomes a memcpy node that reads `src`
+// at every replay: the caller keeps the host array alive and unchanged for as long as the graph lives (ops._upload_table).
+extern "C" int vcv_upload_table(void* dst, const void* src, int64_t bytes, void* stream) {
+  if (!dst || !src || bytes <= 0) return VCV_EINVAL;
+  return hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? VCV_OK : VCV_EHIP;
+}

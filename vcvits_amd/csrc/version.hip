@@ -18,8 +18,8 @@ extern "C" int vcv_get_deterministic(void) { return g_det; }
 // Device-side seed offset for the counter-based dropout masks: when set (non-null), the forward dropout / attention
 // launchers pass the pointer to their kernels, which add *ptr to the host-supplied seed.  A launch sequence captured in a
 // HIP graph bakes the host seed into its kernel arguments; bumping the device word between replays gives every replay
-// fresh masks (vcvits_amd/light/graphed.py).  Forward-only: passes that regenerate a mask in a backward kernel run with
-// the pointer unset.
+// fresh masks (vcvits_amd/light/graphed.py).  A backward kernel that regenerates a mask reads the same pointer: inside a
+// captured training pass forward and backward see the same value; eager passes run with the pointer unset.
 static const unsigned long long* g_seed_off = nullptr;
 extern "C" int vcv_set_seed_offset_ptr(const void* dev_ptr) {
   g_seed_off = (const unsigned long long*)dev_ptr;

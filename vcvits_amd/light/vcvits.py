@@ -239,12 +239,22 @@ class VCVITS(nn.Module):
         out = {}
         for idx, opt in ((0, self.optim_g), (1, self.optim_d)):
             self._toggle(idx)
-            opt.zero_grad()
-            loss = self.training_step(batch, batch_idx, idx)
-            loss.backward()
-            if after_backward is not None:
-                opt.finish_grad_sync()
-                after_backward(idx, opt)
+            loss = None
+            if after_backward is None:
+                # zero_grad + forward + backward replayed from a HIP graph once the batch shapes repeat (light/graphed.py)
+                sg = self.__dict__.get("_step_graph")
+                if sg is None:
+                    from .graphed import GraphedStep
+                    sg = self.__dict__["_step_graph"] = GraphedStep(self)
+                loss = sg.run(idx, opt, batch, extra=(ops.compute_dtype(), ops._USE_X3[0], ops._USE_X3_WGRAD[0], ops._USE_PK[0],
+                                                      ops.bf16_activations(), ops._DETERMINISTIC[0]))
+            if loss is None:
+                opt.zero_grad()
+                loss = self.training_step(batch, batch_idx, idx)
+                loss.backward()
+                if after_backward is not None:
+                    opt.finish_grad_sync()
+                    after_backward(idx, opt)
             opt.step()
             out["g" if idx == 0 else "d"] = loss.detach()
         for p in itertools.chain(self.optim_g.params, self.optim_d.params):

@@ -92,6 +92,21 @@ def set_bf16_activations(on):
 CAPTURING = [None]
 
 
+def _upload_table(tab, dev):
+    """int64 host table (numpy) -> device tensor on the current stream.  Eager: through a pinned staging copy.  While a
+    launch sequence is being captured (CAPTURING): a plain asynchronous copy from the numpy array itself, which is kept
+    alive with the graph -- the captured copy node re-reads it at every replay, and pinning memory is not a capturable
+    operation."""
+    if CAPTURING[0] is None:
+        return torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
+    import numpy as np
+    tab = np.ascontiguousarray(tab)
+    out = torch.empty(tab.shape, device=dev, dtype=torch.int64)
+    check(lib().vcv_upload_table(ptr(out), ctypes.c_void_p(tab.ctypes.data), tab.nbytes, stream()), "vcv_upload_table")
+    CAPTURING[0].append(tab)
+    return out
+
+
 def bf16_activations():
     """True when no-grad decoder passes keep their intermediate activations in bf16."""
     return _BF16_ACT[0] and _COMPUTE[0] == "bf16"
@@ -358,6 +373,10 @@ def wgrad_arena_reset():
     if a["buf"] is not None and a["off"] > 0:
         a["buf"][:a["off"]].zero_()
     if a["need"] > (a["buf"].numel() if a["buf"] is not None else 0) and torch.cuda.is_available():
+        if a["buf"] is not None:
+            # a captured pass (light/graphed.py) may have slices of the old buffer baked into its kernels: retire it, never
+            # free it (a freed buffer under a replayed graph was a memory fault in the eager step that grew the arena)
+            a.setdefault("retired", []).append(a["buf"])
         a["buf"] = torch.zeros((int(a["need"] * 1.1) + 1024,), device=torch.device("cuda", torch.cuda.current_device()),
                                dtype=torch.float32)
     a["off"] = a["need"] = 0
@@ -1156,7 +1175,7 @@ class _WeightNormManyFn(torch.autograd.Function):
                 tab[i, 7], tab[i, 8], tab[i, 9] = dvs[i].data_ptr(), dgs[i].data_ptr(), 0
                 o += R * C
                 r0 += R
-        tab_dev = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
+        tab_dev = _upload_table(tab, dev)
         check(lib().vcv_weight_norm_many_bwd(ptr(tab_dev), n, rows, ptr(holder.norm[first_row:first_row + rows]), stream()),
               "vcv_weight_norm_many_bwd")
         for sv, sg in ctx.sinks:
@@ -1340,7 +1359,7 @@ class _LossTermsFn(torch.autograd.Function):
                       struct.unpack("<i", struct.pack("<f", sc))[0], off)
             blk += max(1, min((n + 2047) // 2048, 512))
             off += n
-        tab_dev = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
+        tab_dev = _upload_table(tab, dev)
         check(lib().vcv_loss_many_sum(ptr(tab_dev), n_a, blk, target, mode, ptr(out), stream()), "vcv_loss_many_sum")
         ctx.mode, ctx.target, ctx.n_a, ctx.blocks, ctx.total = mode, target, n_a, blk, off
         ctx.offs = [int(o) for o in tab[:, 5]]
