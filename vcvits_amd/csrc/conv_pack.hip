@@ -95,11 +95,21 @@ __global__ void __launch_bounds__(256) pack_x3_tile_kernel(const VcvPackJob* __r
   const int nsl = J.BM / PK_RT;  // row slices per m-tile
   int t = (int)(bx - J.block0);
   const int sl = t % nsl; t /= nsl;
-  const int g = t % J.nch; t /= J.nch;
+  // kind 0: one 16-channel group g of the split layout.  kind 2 (bf16 elements of conv_pk.hip, round 4: the thread-per-item
+  // body ran the bf16 steps' packs at 0.65 TB/s, 1.6-1.8 ms per step): 16-channel pair `cg` of reduction chunk `ch`
+  int g, cg = 0, ch = 0;
+  const int ncg = J.kind == 2 ? J.BKC / 16 : 1;
+  if (J.kind == 2) {
+    cg = t % ncg; t /= ncg;
+    ch = t % J.nch; t /= J.nch;
+    g = 0;
+  } else {
+    g = t % J.nch; t /= J.nch;
+  }
   const int mt = t % J.nmt;
   const int r = t / J.nmt;
   const int tid = threadIdx.x;
-  const int ml0 = sl * PK_RT, m0 = mt * J.BM + ml0, c0 = g * 16;
+  const int ml0 = sl * PK_RT, m0 = mt * J.BM + ml0, c0 = J.kind == 2 ? ch * J.BKC + cg * 16 : g * 16;
   const int K = J.K;
   int rows, L;
   if (J.mode == 0) rows = PK_RT, L = 16 * K; else rows = 16, L = PK_RT * K;
@@ -131,6 +141,26 @@ __global__ void __launch_bounds__(256) pack_x3_tile_kernel(const VcvPackJob* __r
   }
   __syncthreads();
   const int items = J.JA * 2 * PK_RT;
+  if (J.kind == 2) {
+    // wp[phase][m-tile][chunk][j][cg][h][m][8 bf16]: one 16-byte item per (j, h, row)
+    const size_t chunk0 = (((size_t)r * J.nmt + mt) * J.nch + ch) * J.JA;
+    for (int it = tid; it < items; it += 256) {
+      const int mr = it % PK_RT;
+      const int hh = (it / PK_RT) & 1;
+      const int j = it / (2 * PK_RT);
+      const int kk = J.mode == 0 ? j : J.mode == 1 ? K - 1 - j : r + j * J.phases;
+      const bool kok = J.mode == 2 ? kk < K : j < K;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = 0.f;
+        if (kok) f = J.mode == 0 ? src[mr * pitch + (hh * 8 + e) * K + kk] : src[(hh * 8 + e) * pitch + mr * K + kk];
+        v[e] = (__bf16)f;
+      }
+      ((bf16x8*)J.wp)[((((chunk0 + j) * ncg + cg) * 2 + hh) * (size_t)J.BM) + ml0 + mr] = v;
+    }
+    return;
+  }
   const size_t slab0 = (((size_t)r * J.nmt + mt) * J.nch + g) * J.JA;
   for (int it = tid; it < items; it += 256) {
     const int mr = it % PK_RT;
@@ -190,8 +220,9 @@ extern "C" int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* str
   for (int i = 0; i < n; ++i) {
     VcvPackJob& j = jobs[i];
     if (!j.w || !j.wp || j.total <= 0 || j.kind < 0 || j.kind > 2) return VCV_EINVAL;
-    const bool tile = j.kind == 0 && !no_tile && j.BM % PK_RT == 0 && tile_lds(j) <= TILE_LDS_MAX &&
-                      j.total % ((int64_t)j.JA * 2 * j.BM) == 0;
+    static const bool no_tile2 = getenv("VCVITS_PACK_NO_TILE_BF16") != nullptr;
+    const bool tile = (j.kind == 0 || (j.kind == 2 && !no_tile2 && j.BKC % 16 == 0 && j.mode <= 2)) && !no_tile &&
+                      j.BM % PK_RT == 0 && tile_lds(j) <= TILE_LDS_MAX && j.total % ((int64_t)j.JA * 2 * j.BM) == 0;
     j.reserved = tile ? 1 : 0;
     if (tile) {
       const VcvPackJob tmp = jobs[nt];

@@ -222,6 +222,60 @@ layernorm_c_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
   if (wv == 0 && ok) { mean[(size_t)b * T + t] = mu; rstd[(size_t)b * T + t] = rs; }
 }
 
+// C = 4 * CPW (32 / 64 channels per wave): x + y is loaded ONCE into registers (rounds of 8 channels x 2 tensors in flight),
+// mean, variance and the output come from there -- the generic kernel above walks the channels three times, and its last
+// pass (a store per iteration) is a chain of C / 4 serial load latencies.
+template <int CPW>
+__global__ void __launch_bounds__(256)
+layernorm_c_fwd_regs_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float* __restrict__ out, float* __restrict__ mean,
+                            float* __restrict__ rstd, int T, float eps) {
+  constexpr int C = 4 * CPW;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
+  const bool ok = t < T;
+  const size_t base = (size_t)b * C * T + (ok ? t : 0);
+  float v[CPW];
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < CPW / 8; ++r) {
+    float xv[8], yv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = base + (size_t)(wv + 4 * (8 * r + u)) * T;
+      xv[u] = x[o];
+      yv[u] = y ? y[o] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[8 * r + u] = xv[u] + yv[u];
+      s += v[8 * r + u];
+    }
+  }
+  red[0][wv][lane] = s;
+  __syncthreads();
+  const float mu = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPW; ++k) {
+    v[k] -= mu;
+    q += v[k] * v[k];
+  }
+  red[1][wv][lane] = q;
+  __syncthreads();
+  const float var = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / C;
+  const float rs = rsqrtf(var + eps);
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const int c = wv + 4 * k;
+      out[base + (size_t)c * T] = v[k] * rs * gamma[c] + beta[c];
+    }
+    if (wv == 0) { mean[(size_t)b * T + t] = mu; rstd[(size_t)b * T + t] = rs; }
+  }
+}
+
 // dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)); dgamma += dy*xhat, dbeta += dy (atomics)
 __global__ void __launch_bounds__(256)
 layernorm_c_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gamma,
@@ -607,9 +661,89 @@ extern "C" int vcv_layernorm_c_fwd(const float* x, const float* y, const float* 
                                    float* out, float* mean, float* rstd, int B, int C, int T, float eps,
                                    void* stream) {
   if (!x || !gamma || !beta || !out || !mean || !rstd || B <= 0 || C <= 0 || T <= 0) return VCV_EINVAL;
-  hipLaunchKernelGGL(layernorm_c_fwd_kernel, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, beta, out,
-                     mean, rstd, C, T, eps);
+  static const bool regs_on = [] { const char* e = getenv("VCVITS_LN_REGS"); return !(e && e[0] == '0'); }();
+  if (regs_on && C == 256)
+    hipLaunchKernelGGL(layernorm_c_fwd_regs_kernel<64>, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, beta, out, mean, rstd, T, eps);
+  else if (regs_on && C == 128)
+    hipLaunchKernelGGL(layernorm_c_fwd_regs_kernel<32>, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, beta, out, mean, rstd, T, eps);
+  else
+    hipLaunchKernelGGL(layernorm_c_fwd_kernel, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, beta, out,
+                       mean, rstd, C, T, eps);
   return vcv_check_launch();
+}
+
+// The same for C = 4 * CPW (CPW = 32 / 64: both configs' hidden widths) with the wave's CPW channels of x-hat and g * dy
+// kept in REGISTERS between the two passes: the generic kernel's second pass re-loaded x, y and dy one channel per iteration
+// -- 64 serial global-load latencies per wave, ~100 of its 170 us at B = 32, C = 256, T = 204 -- and its 512 atomics per
+// workgroup hit the same 512 words from all 128 workgroups.  Here every load of a wave is issued in rounds of 8 channels
+// x 3 tensors, nothing is loaded twice, and the per-channel sums of a workgroup leave as ONE partial row per workgroup
+// ([workgroup][2][C] behind no atomics; layernorm_c_bwd_reduce_kernel adds them in index order: deterministic).
+template <int CPW>
+__global__ void __launch_bounds__(256)
+layernorm_c_bwd_regs_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gamma,
+                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dout,
+                            float* __restrict__ dx, float* __restrict__ part, int T) {
+  constexpr int C = 4 * CPW;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
+  const bool ok = t < T;
+  const size_t base = (size_t)b * C * T + (ok ? t : 0);
+  const float mu = ok ? mean[(size_t)b * T + t] : 0.f, rs = ok ? rstd[(size_t)b * T + t] : 0.f;
+  float xh[CPW], gd[CPW];
+  float s1 = 0.f, s2 = 0.f;
+  float* prow = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+  for (int r = 0; r < CPW / 8; ++r) {
+    float xv[8], yv[8], dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = base + (size_t)(wv + 4 * (8 * r + u)) * T;
+      xv[u] = x[o];
+      yv[u] = y ? y[o] : 0.f;
+      dv[u] = dout[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = wv + 4 * (8 * r + u);
+      const float h = ok ? (xv[u] + yv[u] - mu) * rs : 0.f;
+      const float d = ok ? dv[u] : 0.f;
+      const float g = d * gamma[c];
+      xh[8 * r + u] = h;
+      gd[8 * r + u] = g;
+      s1 += g;
+      s2 += g * h;
+      const float pg = wsum(d * h), pb = wsum(d);
+      if (lane == 0) prow[c] = pg, prow[C + c] = pb;
+    }
+  }
+  red[0][wv][lane] = s1;
+  red[1][wv][lane] = s2;
+  __syncthreads();
+  const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) * (1.f / C);
+  const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) * (1.f / C);
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) dx[base + (size_t)(wv + 4 * k) * T] = rs * (gd[k] - m1 - xh[k] * m2);
+  }
+}
+
+// dgamma / dbeta [C] = sum over the workgroups' partial rows, in index order
+__global__ void __launch_bounds__(256)
+layernorm_c_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int nwg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // element of [dgamma | dbeta]
+  if (i >= 2 * C) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int q = 0;
+  for (; q + 3 < nwg; q += 4) {
+    a0 += part[(size_t)q * 2 * C + i];
+    a1 += part[(size_t)(q + 1) * 2 * C + i];
+    a2 += part[(size_t)(q + 2) * 2 * C + i];
+    a3 += part[(size_t)(q + 3) * 2 * C + i];
+  }
+  for (; q < nwg; ++q) a0 += part[(size_t)q * 2 * C + i];
+  const float v = (a0 + a1) + (a2 + a3);
+  if (i < C) dgamma[i] = v; else dbeta[i - C] = v;
 }
 
 extern "C" int vcv_layernorm_c_bwd(const float* x, const float* y, const float* gamma, const float* mean,
@@ -617,6 +751,28 @@ extern "C" int vcv_layernorm_c_bwd(const float* x, const float* y, const float* 
                                    int B, int C, int T, void* stream) {
   if (!x || !gamma || !mean || !rstd || !dout || !dx || !dgamma || !dbeta || B <= 0 || C <= 0 || T <= 0)
     return VCV_EINVAL;
+  // C = 128 / 256: the register-resident form; its per-workgroup partial rows live in a library-owned scratch (grown on
+  // demand, one per process: launches on one stream are ordered, and the partials are consumed by the next launch)
+  static const bool regs_on = [] { const char* e = getenv("VCVITS_LN_REGS"); return !(e && e[0] == '0'); }();
+  if (regs_on && (C == 128 || C == 256)) {
+    static float* scratch = nullptr;
+    static size_t scratch_floats = 0;
+    const int nwg = vcv_cdiv(T, 64) * B;
+    const size_t need = (size_t)nwg * 2 * C;
+    if (need > scratch_floats) {
+      // (the old buffer may still be read by an enqueued reduce: keep it -- a few hundred KB, grown a handful of times)
+      float* nb = nullptr;
+      if (hipMalloc((void**)&nb, need * 2 * sizeof(float)) != hipSuccess) return VCV_EHIP;
+      scratch = nb;
+      scratch_floats = need * 2;
+    }
+    if (C == 256)
+      hipLaunchKernelGGL(layernorm_c_bwd_regs_kernel<64>, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, mean, rstd, dout, dx, scratch, T);
+    else
+      hipLaunchKernelGGL(layernorm_c_bwd_regs_kernel<32>, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, mean, rstd, dout, dx, scratch, T);
+    hipLaunchKernelGGL(layernorm_c_bwd_reduce_kernel, dim3(vcv_cdiv(2 * C, 256)), dim3(256), 0, ST, (const float*)scratch, dgamma, dbeta, C, nwg);
+    return vcv_check_launch();
+  }
   if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, ST) != hipSuccess) return VCV_EHIP;
   if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, ST) != hipSuccess) return VCV_EHIP;
   hipLaunchKernelGGL(layernorm_c_bwd_kernel, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, mean, rstd,
