@@ -272,10 +272,20 @@ int vcv_thin_wgrad(const float* a, const float* bsh, const float* aaux, const fl
  * wgrad accumulates into dw. */
 int vcv_grouped41_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg, int Tin,
                       int Tout, int out_act, float slope, void* stream);
+/* The forward with bf16 operands (v_mfma_f32_16x16x16_bf16: K = 4 taps x the group's 4 input channels; fp32 accumulate) for the
+ * 16-channel groups (Mg == 16, else VCV_EINVAL): the library's bf16 mode. */
+int vcv_grouped41_fwd_bf16(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg, int Tin, int Tout,
+                           int out_act, float slope, void* stream);
 int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg, int Tin,
                         int Tout, int dtf, float slope, void* stream);
+/* bf16-operand form for the 16-channel groups (Mg == 16, else VCV_EINVAL): K of the bf16 MFMA = the group's 16 output channels. */
+int vcv_grouped41_dgrad_bf16(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg, int Tin, int Tout,
+                             int dtf, float slope, void* stream);
 int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg, int Tin,
                         int Tout, int dtf, float slope, void* stream);
+/* bf16-operand form for the 16-channel groups (Mg == 16, else VCV_EINVAL): K of the bf16 MFMA = 16 consecutive output times. */
+int vcv_grouped41_wgrad_bf16(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg, int Tin, int Tout,
+                             int dtf, float slope, void* stream);
 
 /* sum over (b, t) of tf(dy) per channel -> dbias[C] (overwrites, or adds onto dbias when `accumulate`).
  * dy: [B, C, T] (T = Tout*P) */

@@ -220,3 +220,45 @@ def test_infer_waveform_rms_bf16_48k(gpu, bf16_mode):
         z1 = net.flow(z_p[1:], mask[1:].to(gpu), g=spk[1:], reverse=True)
         o1 = net.dec(ops.mask_mul(z1, mask[1:].to(gpu).reshape(1, -1)))
     assert _rms(o1[0], o[1].cpu()) <= 2e-5
+
+
+def test_grouped41_forward_bf16_operands(gpu):
+    """DiscriminatorS's grouped k = 41 stride-4 convs in bf16 mode (vcv_grouped41_fwd_bf16: 4 taps x 4 channels per bf16 MFMA
+    step): exact -- up to the accumulation order -- on operands that are bf16 numbers already; ragged time tiles."""
+    from vcvits_amd import ops
+    g0 = torch.Generator().manual_seed(41)
+    for B, G, Tin in ((2, 4, 1000), (3, 16, 4096), (2, 64, 37 * 4 + 3)):
+        x = torch.randn(B, G * 4, Tin, generator=g0).bfloat16().float().to(gpu)
+        w = (torch.randn(G * 16, 4, 41, generator=g0) * 0.1).bfloat16().float().to(gpu)
+        b = torch.randn(G * 16, generator=g0).to(gpu)
+        ops.set_compute_dtype("f32")
+        ref = ops.conv_forward(x, w, b, stride=4, pad=20, groups=G, out_act=ops.ACT_LEAKY)
+        try:
+            ops.set_compute_dtype("bf16")
+            got = ops.conv_forward(x, w, b, stride=4, pad=20, groups=G, out_act=ops.ACT_LEAKY)
+        finally:
+            ops.set_compute_dtype("f32")
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, (B, G, Tin, err)
+        # data gradient (vcv_grouped41_dgrad_bf16: K of the MFMA = the group's 16 output channels): exact without the fused
+        # activation derivative; with it the masked gradient 0.1 * dy is rounded to bf16 (2^-9)
+        dy = torch.randn(ref.shape, generator=g0).bfloat16().float().to(gpu)
+        for tf, aux, tol in ((ops.TF_NONE, None, 1e-5), (ops.TF_DLEAKY, ref, 6e-3)):
+            ops.set_compute_dtype("f32")
+            dref = ops.conv_dgrad(dy, w, x.shape, stride=4, pad=20, groups=G, in_tf=tf, xaux=aux, slope=0.1)
+            try:
+                ops.set_compute_dtype("bf16")
+                dgot = ops.conv_dgrad(dy, w, x.shape, stride=4, pad=20, groups=G, in_tf=tf, xaux=aux, slope=0.1)
+            finally:
+                ops.set_compute_dtype("f32")
+            derr = float((dgot - dref).abs().max() / dref.abs().max())
+            assert derr < tol, ("dgrad", B, G, Tin, tf, derr)
+            ops.set_compute_dtype("f32")
+            wref = ops.conv_wgrad(dy, x, w.shape, stride=4, pad=20, groups=G, a_tf=tf, aaux=aux, slope=0.1)
+            try:
+                ops.set_compute_dtype("bf16")
+                wgot = ops.conv_wgrad(dy, x, w.shape, stride=4, pad=20, groups=G, a_tf=tf, aaux=aux, slope=0.1)
+            finally:
+                ops.set_compute_dtype("f32")
+            werr = float((wgot - wref).abs().max() / wref.abs().max())
+            assert werr < (2e-5 if tf == ops.TF_NONE else tol), ("wgrad", B, G, Tin, tf, werr)

@@ -333,6 +333,97 @@ grouped_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w
 }
 }  // namespace
 
+namespace {
+// ---- forward, bf16 operands (bf16 mode of the library: operands rounded on their way into the matrix cores, fp32
+// accumulate).  v_mfma_f32_16x16x16_bf16 takes K = 16 = (4 taps) x (the group's 4 input channels): lane quarter kq holds
+// tap 4 tg + kq and, as its four bf16 elements, the four channels -- 11 MFMA steps per 16 x 16 tile instead of 41 with the
+// fp32 shape (the fp32-input kernel above is at 69 % of the fp32 MFMA peak: in bf16 mode these three layers were the one
+// GEMM-shaped launch family still on the fp32 pipe, 5.7 ms of the 84 ms configs[2] step).  With the taps grouped in fours the
+// stride-4 input index 4 (t0 + n) + 4 tg + kq has residue kq: the input span is staged as [residue][q] items of four
+// channels (8 bytes of bf16: one ds_read_b64 per B fragment), the weights as [tap group][kq][m] items of four channels.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4_t pack_bf16x4(float a, float b, float c, float d) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  bf16x4_t v;
+  v[0] = (__bf16)a, v[1] = (__bf16)b, v[2] = (__bf16)c, v[3] = (__bf16)d;
+  return __builtin_bit_cast(s16x4_t, v);
+}
+
+__global__ void __launch_bounds__(256)
+grouped_fwd_mfma_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                             float* __restrict__ y, int G, int Tin, int Tout, int act, float slope) {
+  constexpr int TT = 256, MG = 16, NTG = KP / 4;  // 11 tap groups
+  constexpr int QN = TT + 11;                     // quarter-rate samples per residue
+  __shared__ s16x4_t xs[4][QN + 1];               // [residue][q]: channels 0..3 of input 4 q + residue
+  __shared__ s16x4_t wsb[NTG][4][MG];             // [tap group][kq][m]: channels 0..3 of tap 4 tg + kq (taps >= 41: zero)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
+  const float* xb = x + ((size_t)b * G * CG + (size_t)g * CG) * Tin;
+  const int in0 = t0 * S - PAD;  // a multiple of 4
+  // input span: thread = position, the four channel rows loaded together (coalesced per row), five positions in flight
+  for (int j0 = tid; j0 < 4 * QN; j0 += 256 * 5) {
+    float v[5][4];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int j = j0 + u * 256, ti = in0 + j;
+      const bool ok = j < 4 * QN && ti >= 0 && ti < Tin;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) v[u][ci] = ok ? xb[(size_t)ci * Tin + ti] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int j = j0 + u * 256;
+      if (j < 4 * QN) xs[j & 3][j >> 2] = pack_bf16x4(v[u][0], v[u][1], v[u][2], v[u][3]);
+    }
+  }
+  // weights: item (tap group, kq, m) = w[g*16 + m][0..3][4 tg + kq]
+  const float* wg = w + (size_t)g * MG * CG * K;
+  for (int i = tid; i < NTG * 4 * MG; i += 256) {
+    const int m = i % MG, kq = (i / MG) & 3, tg = i / (4 * MG);
+    const int k = 4 * tg + kq;
+    float v[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) v[ci] = k < K ? wg[((size_t)m * CG + ci) * K + k] : 0.f;
+    wsb[tg][kq][m] = pack_bf16x4(v[0], v[1], v[2], v[3]);
+  }
+  __syncthreads();
+  const int n = lane & 15, kq = lane >> 4;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int tw = wave * 64;
+#pragma unroll
+  for (int tg = 0; tg < NTG; ++tg) {
+    const s16x4_t a = wsb[tg][kq][n];  // A[m = n][k = (kq, ci)]
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)     // B[k = (kq, ci)][column]: input 4 (tw + 16 tl + n) + 4 tg + kq
+      acc[tl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, xs[kq][tw + tl * 16 + n + tg], acc[tl], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) {
+    const int t = t0 + tw + tl * 16 + n;
+    if (t >= Tout) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = kq * 4 + r;
+      float v = acc[tl][r] + (bias ? bias[g * MG + m] : 0.f);
+      y[((size_t)b * G * MG + (size_t)g * MG + m) * Tout + t] = vcv_act(v, act, slope);
+    }
+  }
+}
+}  // namespace
+
+// bf16-operand form of vcv_grouped41_fwd for the 16-channel groups (Mg == 16; other group widths: VCV_EINVAL, the caller
+// keeps vcv_grouped41_fwd)
+extern "C" int vcv_grouped41_fwd_bf16(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg,
+                                      int Tin, int Tout, int out_act, float slope, void* stream) {
+  if (!x || !w || !y || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || Mg != 16) return VCV_EINVAL;
+  hipLaunchKernelGGL(grouped_fwd_mfma_bf16_kernel, dim3(vcv_cdiv(Tout, 256), G, B), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     y, G, Tin, Tout, out_act, slope);
+  return vcv_check_launch();
+}
+
 extern "C" int vcv_grouped41_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Mg,
                                  int Tin, int Tout, int out_act, float slope, void* stream) {
   if (!x || !w || !y || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
@@ -418,6 +509,92 @@ grouped_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
 }
 }  // namespace
 
+namespace {
+// ---- data gradient, bf16 operands: rows = (ci, r) as above, K of v_mfma_f32_16x16x16_bf16 = ALL 16 output channels of the
+// group, so each of the 11 tap groups is ONE MFMA per 16 x 16 tile (four with the fp32 shape).  dye = dy * leaky'(y) is
+// staged as [m / 4][position] items of four channels (8 bytes of bf16), the weights as [tap group][kq][row] items.
+__global__ void __launch_bounds__(256)
+grouped_dgrad_mfma_bf16_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ w,
+                               float* __restrict__ dx, int G, int Tin, int Tout, int dtf, float slope) {
+  constexpr int MG = 16, QT = 256, NJ = 11;
+  constexpr int DSP = QT + 10 + 1;
+  __shared__ s16x4_t dsb[4][DSP];      // [m chunk kq][position]: channels 4 kq .. 4 kq + 3 of dye at q0 - 5 + position
+  __shared__ s16x4_t wsd[NJ][4][16];   // [tap group j][kq][row = ci * 4 + r]: channels 4 kq .. + 3 of w[m][ci][r + 4 j]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.x * QT, g = blockIdx.y, b = blockIdx.z;
+  const size_t ybase = ((size_t)b * G * MG + (size_t)g * MG) * Tout;
+  // dye: thread = position, the 16 channel rows loaded together (coalesced per row), two positions in flight
+  for (int p0 = tid; p0 < DSP; p0 += 256 * 2) {
+    float v[2][MG], a[2][MG];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pp = p0 + u * 256, t = q0 - 5 + pp;
+      const bool ok = pp < DSP && t >= 0 && t < Tout;
+#pragma unroll
+      for (int m = 0; m < MG; ++m) {
+        v[u][m] = ok ? dy[ybase + (size_t)m * Tout + t] : 0.f;
+        a[u][m] = (ok && dtf == VCV_TF_DLEAKY) ? yaux[ybase + (size_t)m * Tout + t] : 1.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pp = p0 + u * 256;
+      if (pp < DSP) {
+#pragma unroll
+        for (int mc = 0; mc < 4; ++mc)
+          dsb[mc][pp] = pack_bf16x4(v[u][4 * mc] * vcv_dleaky(a[u][4 * mc], slope), v[u][4 * mc + 1] * vcv_dleaky(a[u][4 * mc + 1], slope),
+                                    v[u][4 * mc + 2] * vcv_dleaky(a[u][4 * mc + 2], slope), v[u][4 * mc + 3] * vcv_dleaky(a[u][4 * mc + 3], slope));
+      }
+    }
+  }
+  const float* wg = w + (size_t)g * MG * CG * K;
+  for (int i = tid; i < NJ * 4 * 16; i += 256) {
+    const int row = i & 15, kq = (i >> 4) & 3, j = i >> 6;
+    const int ci = row >> 2, k = (row & 3) + 4 * j;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = k < K ? wg[((size_t)(4 * kq + e) * CG + ci) * K + k] : 0.f;
+    wsd[j][kq][row] = pack_bf16x4(v[0], v[1], v[2], v[3]);
+  }
+  __syncthreads();
+  const int n = lane & 15, kq = lane >> 4;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int qw = wave * 64;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const s16x4_t a = wsd[j][kq][n];  // A[row = n][k = m = 4 kq + e]
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)    // B[k = m][column q]: dye[m][q + 5 - j]
+      acc[tl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, dsb[kq][qw + tl * 16 + n + 10 - j], acc[tl], 0, 0, 0);
+  }
+  float* dxr = dx + ((size_t)b * G * CG + (size_t)g * CG + kq) * Tin;
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl) {
+    const int q = q0 + qw + tl * 16 + n;
+    const int u = 4 * q;
+    if (u + 3 < Tin && (Tin & 3) == 0) {
+      *reinterpret_cast<f32x4_t*>(dxr + u) = acc[tl];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (u + r < Tin) dxr[u + r] = acc[tl][r];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int vcv_grouped41_dgrad_bf16(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg,
+                                        int Tin, int Tout, int dtf, float slope, void* stream) {
+  if (!dy || !w || !dx || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || Mg != 16) return VCV_EINVAL;
+  if (dtf != VCV_TF_NONE && dtf != VCV_TF_DLEAKY) return VCV_EINVAL;
+  if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
+  hipLaunchKernelGGL(grouped_dgrad_mfma_bf16_kernel, dim3(vcv_cdiv(vcv_cdiv(Tin, 4), 256), G, B), dim3(256), 0, (hipStream_t)stream, dy,
+                     yaux, w, dx, G, Tin, Tout, dtf, slope);
+  return vcv_check_launch();
+}
+
 extern "C" int vcv_grouped41_dgrad(const float* dy, const float* yaux, const float* w, float* dx, int B, int G, int Mg,
                                    int Tin, int Tout, int dtf, float slope, void* stream) {
   if (!dy || !w || !dx || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
@@ -447,6 +624,9 @@ namespace {
 // the padding columns are clamped reads and never stored).  Workgroup = (group, batch element, time chunk); its
 // four waves take a quarter of each 256-time stage, add their partial tiles into one LDS tile and the workgroup
 // leaves with one atomic per weight.
+// BF: bf16 operands (bf16 mode): v_mfma_f32_16x16x16_bf16 with K = 16 consecutive output times per step (lane quarter kk
+// holds times 4 kk .. 4 kk + 3) -- a quarter of the MFMA steps of the fp32 shape at the same number of LDS reads.
+template <bool BF>
 __global__ void __launch_bounds__(256)
 grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ yaux, const float* __restrict__ x,
                           float* __restrict__ dw, int G, int Tin, int Tout, int dtf, float slope, int nstage, int uper,
@@ -468,7 +648,7 @@ grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
     int n = nt * 16 + j16;
     if (n > NW - 1) n = NW - 1;
     const int ci = n / K, k = n - ci * K;
-    boff[nt] = ci * SPAN + S * kk + k;
+    boff[nt] = ci * SPAN + (BF ? 0 : S * kk) + k;
   }
   f32x4_t acc[NT];
 #pragma unroll
@@ -498,13 +678,27 @@ grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
         [&](int i, float v, float a) { ds[i / TT][i % TT] = v * vcv_dleaky(a, slope); });
     __syncthreads();
     const float* xf = &xs[0][0];
-#pragma unroll 2
-    for (int tq = wave * 64; tq < wave * 64 + 64; tq += 4) {
-      const float a = ds[j16][tq + kk];            // A[m = j16][kk]
-      const float* xq = xf + S * tq;
+    if constexpr (BF) {
+#pragma unroll 1
+      for (int tq = wave * 64; tq < wave * 64 + 64; tq += 16) {
+        const float* ar = &ds[j16][tq + 4 * kk];   // A[m = j16][k = times tq + 4 kk + e]
+        const s16x4_t a = pack_bf16x4(ar[0], ar[1], ar[2], ar[3]);
+        const float* xq = xf + S * (tq + 4 * kk);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xq[boff[nt]], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          const float* xp = xq + boff[nt];        // B[k = time][column (ci, tap)]: x[ci][4 (t + e) + tap - 20]
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, pack_bf16x4(xp[0], xp[S], xp[2 * S], xp[3 * S]), acc[nt], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int tq = wave * 64; tq < wave * 64 + 64; tq += 4) {
+        const float a = ds[j16][tq + kk];            // A[m = j16][kk]
+        const float* xq = xf + S * tq;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xq[boff[nt]], acc[nt], 0, 0, 0);
+      }
     }
   }
   // the four waves' partial tiles meet in LDS one wave after the other: a fixed order (LDS atomics would add them in
@@ -527,9 +721,10 @@ grouped_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict_
 }
 }  // namespace
 
-extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
-                                   int Tin, int Tout, int dtf, float slope, void* stream) {
+static int grouped41_wgrad_impl(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
+                                int Tin, int Tout, int dtf, float slope, void* stream, bool bf) {
   if (!dy || !x || !dw || B <= 0 || G <= 0 || Tin <= 0 || Tout <= 0 || (Mg != 4 && Mg != 16)) return VCV_EINVAL;
+  if (bf && Mg != 16) return VCV_EINVAL;
   if (dtf != VCV_TF_NONE && dtf != VCV_TF_DLEAKY) return VCV_EINVAL;  // (the staging applies the leaky-ReLU derivative only)
   if (dtf >= VCV_TF_DLEAKY && !yaux) return VCV_EINVAL;
   // time chunks so that the grid has >= ~1000 workgroups
@@ -541,8 +736,12 @@ extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const flo
     if (wg_per_group > nunit) wg_per_group = nunit;
     if (vcv_get_deterministic()) wg_per_group = 1;  // one workgroup per group: a single writer per weight
     const int uper = vcv_cdiv(nunit, wg_per_group);
-    hipLaunchKernelGGL(grouped_wgrad_mfma_kernel, dim3(G, vcv_cdiv(nunit, uper)), dim3(256), 0, (hipStream_t)stream, dy, yaux,
-                       x, dw, G, Tin, Tout, dtf, slope, nstage, uper, nunit);
+    if (bf)
+      hipLaunchKernelGGL(grouped_wgrad_mfma_kernel<true>, dim3(G, vcv_cdiv(nunit, uper)), dim3(256), 0, (hipStream_t)stream, dy, yaux,
+                         x, dw, G, Tin, Tout, dtf, slope, nstage, uper, nunit);
+    else
+      hipLaunchKernelGGL(grouped_wgrad_mfma_kernel<false>, dim3(G, vcv_cdiv(nunit, uper)), dim3(256), 0, (hipStream_t)stream, dy, yaux,
+                         x, dw, G, Tin, Tout, dtf, slope, nstage, uper, nunit);
     return vcv_check_launch();
   }
   while ((long long)G * B * nchunk < 1024 && Tout / (nchunk * 2) >= 128) nchunk *= 2;
@@ -557,4 +756,14 @@ extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const flo
   if (Mg == 16) hipLaunchKernelGGL(grouped_wgrad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk, bper, B);
   else hipLaunchKernelGGL(grouped_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, yaux, x, dw, G, Tin, Tout, dtf, slope, tchunk, bper, B);
   return vcv_check_launch();
+}
+
+extern "C" int vcv_grouped41_wgrad(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
+                                   int Tin, int Tout, int dtf, float slope, void* stream) {
+  return grouped41_wgrad_impl(dy, yaux, x, dw, B, G, Mg, Tin, Tout, dtf, slope, stream, false);
+}
+// bf16-operand form for the 16-channel groups (Mg == 16, else VCV_EINVAL): K of the bf16 MFMA = 16 consecutive output times
+extern "C" int vcv_grouped41_wgrad_bf16(const float* dy, const float* yaux, const float* x, float* dw, int B, int G, int Mg,
+                                        int Tin, int Tout, int dtf, float slope, void* stream) {
+  return grouped41_wgrad_impl(dy, yaux, x, dw, B, G, Mg, Tin, Tout, dtf, slope, stream, true);
 }

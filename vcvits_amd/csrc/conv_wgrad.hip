@@ -407,11 +407,12 @@ extern "C" int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream) {
 // Short rows (T <= 1024, T % 4 == 0: the 1 x 1 convs of the encoders / flow at 200-400 frames): the kernel above gives a
 // (b, c) row to the whole workgroup per iteration -- 51-96 of its 256 threads load, B iterations one after the other
 // (17 us for 9 MB).  Here the (b, t / 4) items of a channel are dealt to the threads flat, eight 16-byte loads in flight each.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 bias_grad_rows_kernel(const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ db, int B, int C, int T,
                       int tf, float slope, int acc) {
   const int c = blockIdx.x;
-  const int t4n = T >> 2, total = B * t4n;
+  const int t4n = VEC ? T >> 2 : T, total = B * t4n;  // items of a channel: 16-byte pieces (VEC) or single elements
   float s = 0.f;
   for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
     float4 v[8], y[8];
@@ -421,18 +422,27 @@ bias_grad_rows_kernel(const float* __restrict__ dy, const float* __restrict__ au
       const int i = i0 + u * 256;
       in[u] = i < total;
       const int b = in[u] ? i / t4n : 0, t4 = in[u] ? i - b * t4n : 0;
-      const size_t o = ((size_t)b * C + c) * (size_t)T + 4 * t4;
-      v[u] = *reinterpret_cast<const float4*>(dy + o);
-      if (tf >= VCV_TF_DLEAKY) y[u] = *reinterpret_cast<const float4*>(aux + o);
+      const size_t o = ((size_t)b * C + c) * (size_t)T + (VEC ? 4 * t4 : t4);
+      if (VEC) {
+        v[u] = *reinterpret_cast<const float4*>(dy + o);
+        if (tf >= VCV_TF_DLEAKY) y[u] = *reinterpret_cast<const float4*>(aux + o);
+      } else {
+        v[u].x = dy[o];
+        if (tf >= VCV_TF_DLEAKY) y[u].x = aux[o];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (in[u]) {
-        if (tf >= VCV_TF_DLEAKY)
-          s += bias_term(v[u].x, y[u].x, tf, slope) + bias_term(v[u].y, y[u].y, tf, slope) + bias_term(v[u].z, y[u].z, tf, slope) +
-               bias_term(v[u].w, y[u].w, tf, slope);
-        else
-          s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        if (VEC) {
+          if (tf >= VCV_TF_DLEAKY)
+            s += bias_term(v[u].x, y[u].x, tf, slope) + bias_term(v[u].y, y[u].y, tf, slope) + bias_term(v[u].z, y[u].z, tf, slope) +
+                 bias_term(v[u].w, y[u].w, tf, slope);
+          else
+            s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        } else {
+          s += bias_term(v[u].x, tf >= VCV_TF_DLEAKY ? y[u].x : 0.f, tf, slope);
+        }
       }
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
@@ -452,7 +462,11 @@ extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, in
   hipStream_t st = (hipStream_t)stream;
   static const bool rows_on = [] { const char* e = getenv("VCVITS_BIAS_ROWS"); return !(e && e[0] == '0'); }();
   if (rows_on && T <= 1024 && T % 4 == 0 && (long long)B * (T / 4) <= 256 * 64) {
-    hipLaunchKernelGGL(bias_grad_rows_kernel, dim3(C), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf, slope, accumulate);
+    hipLaunchKernelGGL(bias_grad_rows_kernel<true>, dim3(C), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf, slope, accumulate);
+    return vcv_check_launch();
+  }
+  if (rows_on && T <= 1024 && (long long)B * T <= 256 * 64) {  // (rows of any length: element by element, still flat)
+    hipLaunchKernelGGL(bias_grad_rows_kernel<false>, dim3(C), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf, slope, accumulate);
     return vcv_check_launch();
   }
   // enough workgroups to fill the chip, each with at least ~8 pieces of 1024 floats

@@ -80,6 +80,8 @@ LAUNCH_COUNTS = {"bf16": 0, "bf16io": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, 
 # reference's fp16 autocast does to every conv output, train.py:104-106); VCVITS_BF16_ACT=0 / set_bf16_activations(False)
 # keeps them fp32 (operands still rounded on their way into the matrix cores)
 _BF16_ACT = [__import__("os").environ.get("VCVITS_BF16_ACT", "1") == "1"]
+# bf16 mode: DiscriminatorS's grouped k = 41 forward on the bf16 matrix pipe (VCVITS_GROUPED_BF16=0: fp32-input MFMA)
+_GROUPED_BF16 = [__import__("os").environ.get("VCVITS_GROUPED_BF16", "1") == "1"]
 
 
 def set_bf16_activations(on):
@@ -262,8 +264,10 @@ def conv_forward(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, out=None, **
     if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
             and M // groups in (4, 16) and plain and kw.get("in_tf", TF_NONE) == TF_NONE
             and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_LEAKY)):
-        check(lib().vcv_grouped41_fwd(ptr(x), ptr(w), ptr(bias), ptr(out), B, groups, M // groups, Tin, Tout,
-                                      kw.get("out_act", ACT_NONE), kw.get("slope", 0.1), stream()), "vcv_grouped41_fwd")
+        # bf16 mode: the 16-channel groups on the bf16 matrix pipe (4 taps x 4 channels per MFMA step)
+        fn = "vcv_grouped41_fwd_bf16" if (_COMPUTE[0] == "bf16" and M // groups == 16 and _GROUPED_BF16[0]) else "vcv_grouped41_fwd"
+        check(getattr(lib(), fn)(ptr(x), ptr(w), ptr(bias), ptr(out), B, groups, M // groups, Tin, Tout,
+                                 kw.get("out_act", ACT_NONE), kw.get("slope", 0.1), stream()), fn)
         return out
     if (C == 1 and groups == 1 and M <= 64 and K <= 16 and plain and kw.get("in_tf", TF_NONE) == TF_NONE
             and kw.get("out_act", ACT_NONE) in (ACT_NONE, ACT_LEAKY)):
@@ -299,9 +303,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
     if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
             and M // groups in (4, 16) and set(kw) <= {"in_tf", "xaux", "slope"}
             and kw.get("in_tf", TF_NONE) in (TF_NONE, TF_DLEAKY)):
-        check(lib().vcv_grouped41_dgrad(ptr(dy), ptr(kw.get("xaux")), ptr(w), ptr(out), B, groups, M // groups, Tin,
-                                        Tout, kw.get("in_tf", TF_NONE), kw.get("slope", 0.1), stream()),
-              "vcv_grouped41_dgrad")
+        fn = "vcv_grouped41_dgrad_bf16" if (_COMPUTE[0] == "bf16" and M // groups == 16 and _GROUPED_BF16[0]) else "vcv_grouped41_dgrad"
+        check(getattr(lib(), fn)(ptr(dy), ptr(kw.get("xaux")), ptr(w), ptr(out), B, groups, M // groups, Tin,
+                                 Tout, kw.get("in_tf", TF_NONE), kw.get("slope", 0.1), stream()), fn)
         return out
     if (C == 1 and groups == 1 and M <= 64 and K <= 16 and kw.get("in_tf", TF_NONE) == TF_NONE
             and set(kw) <= {"in_tf", "xaux", "slope"}):
@@ -414,8 +418,9 @@ def conv_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, groups=1, out=None, a_tf=
         dbias = None
     if (groups > 1 and Cg == 4 and K == 41 and stride == 4 and pad == 20 and dil == 1 and P == 1
             and M // groups in (4, 16) and b_tf == TF_NONE and a_tf in (TF_NONE, TF_DLEAKY) and alpha == 1.0):
-        check(lib().vcv_grouped41_wgrad(ptr(dy), ptr(aaux), ptr(x), ptr(out), B, groups, M // groups, Tin, Tout, a_tf,
-                                        slope, stream()), "vcv_grouped41_wgrad")
+        fn = "vcv_grouped41_wgrad_bf16" if (_COMPUTE[0] == "bf16" and M // groups == 16 and _GROUPED_BF16[0]) else "vcv_grouped41_wgrad"
+        check(getattr(lib(), fn)(ptr(dy), ptr(aaux), ptr(x), ptr(out), B, groups, M // groups, Tin, Tout, a_tf,
+                                 slope, stream()), fn)
         return out
     if groups == 1 and min(M, C) == 1 and K <= 16:
         check(lib().vcv_thin_wgrad(ptr(dy), ptr(x), ptr(aaux), ptr(baux), ptr(out), B, M, C, Tout, Tin, P, K, stride,
