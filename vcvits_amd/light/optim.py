@@ -113,6 +113,8 @@ class FlatAdamW:
         if dev.type == "cuda" and os.environ.get("VCVITS_GRAD_SINK", "1") == "1":
             for p in self.params:
                 ops.register_grad_sink(p, p.grad)
+        if dev.type == "cuda":
+            ops.register_param_region(self.flat)  # packed copies of plain conv weights: cached per optimizer step, batched
 
     # -- gradient buckets ------------------------------------------------------------------------
     def _make_buckets(self, cap):
@@ -151,6 +153,7 @@ class FlatAdamW:
         self._hook_handles = []
         for p in self.params:
             ops.unregister_grad_sink(p)
+        ops.unregister_param_region(self.flat)
 
     def _launch_bucket(self, b):
         view = self.grad[b["lo"]:b["hi"]]

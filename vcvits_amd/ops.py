@@ -140,7 +140,7 @@ def _cur_dev():
     return d
 
 
-def _launch_conv(a, flip_w=None):
+def _launch_conv(a, flip_w=None, wt=None):
     """Forward-type launches go to the packed-weight kernels when one is eligible -- the bf16-operand kernel
     (vcv_conv_bf16_*) under set_compute_dtype("bf16"), else the fp32 LDS-DMA kernel (vcv_conv_dma_*) -- everything else to
     the register-staged fp32 kernel.  flip_w: original [C, M, K] weight of a stride-1 data gradient (the pack flips it;
@@ -170,8 +170,17 @@ def _launch_conv(a, flip_w=None):
                 continue
             dev = _cur_dev()
             ent = _stable_entry(a.w)
+            wver = 0
+            if ent is not None and "dirty" in ent:
+                # a parameter region: the pack is valid for the weight tensor's version it was made from (an in-place write
+                # that did not go through the optimizer bumps it); callers that do not hand the tensor over pack per use
+                wtt = wt if wt is not None else flip_w
+                if wtt is None:
+                    ent = None
+                else:
+                    wver = wtt._version
             packs = ent["packs"] if ent is not None else None
-            key = (a.w, plan[0], plan[2])
+            key = (a.w, plan[0], plan[2]) if wver == 0 else (a.w, plan[0], plan[2], wver)
             pack = packs.get(key) if packs is not None else None
             valid = 1 if pack is not None else 0
             if pack is None:
@@ -185,7 +194,9 @@ def _launch_conv(a, flip_w=None):
                     jobs = _PACK_JOBS.get(ent["key"])
                     if jobs is None or jobs["shapes"] != ent["shapes"]:  # (a recycled address set is another module's)
                         jobs = _PACK_JOBS[ent["key"]] = {"shapes": ent["shapes"], "jobs": {}}
-                    jobs["jobs"][(a.w - ent["lo"], int(plan[0]), int(plan[2]), name)] = (bytes(a), flip)
+                    # (a region's job remembers the tensor version it was recorded at: the optimizer's raw update leaves
+                    # versions alone, so the replay registers the pack under the version the next use will ask for)
+                    jobs["jobs"][(a.w - ent["lo"], int(plan[0]), int(plan[2]), name)] = (bytes(a), flip, wver)
             scratch = torch.empty((plan[1],), device=dev, dtype=torch.float32) if plan[1] > 0 else None
             check(run_fn(ctypes.byref(a), ptr(pack), ptr(scratch), flip, valid, stream()), name)
             LAUNCH_COUNTS[_FAMILY_KEY.get(name, "dma")] += 1
@@ -289,7 +300,7 @@ def conv_forward(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, out=None, **
     a.Tin, a.Tout, a.P, a.K = Tin, Tout, P, K
     a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = stride, dil, -pad, 1, 0, 1, Tout, 0
     _common(a, bias=bias, **kw)
-    _launch_conv(a)
+    _launch_conv(a, wt=w)
     return out
 
 
@@ -361,7 +372,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         a.s, a.dj, a.off, a.os, a.oo, a.phases = 1, -1, 0, stride, -pad, stride
         a.Q = (Tin - 1 + pad) // stride + 1
     _common(a, **kw)
-    _launch_conv(a)
+    _launch_conv(a, wt=w)
     return out
 
 
@@ -461,7 +472,7 @@ def convT_forward(x, w, bias=None, stride=1, pad=0, out=None, **kw):
         a.s, a.dj, a.off, a.os, a.oo, a.phases = 1, -1, 0, stride, -pad, stride
         a.Q = (Tout - 1 + pad) // stride + 1
     _common(a, bias=bias, **kw)
-    _launch_conv(a)
+    _launch_conv(a, wt=w)
     return out
 
 
@@ -584,7 +595,7 @@ def convT_dgrad(dy, w, x_shape, stride=1, pad=0, out=None, **kw):
     a.Tin, a.Tout, a.P, a.K = Tout, Tin, P, K
     a.s, a.dj, a.off, a.os, a.oo, a.phases, a.Q, a.a_mode = stride, 1, -pad, 1, 0, 1, Tin, 0
     _common(a, **kw)
-    _launch_conv(a)
+    _launch_conv(a, wt=w)
     return out
 
 
@@ -998,6 +1009,9 @@ WEIGHT_EPOCH = [0]
 def invalidate_weights(lo=None, hi=None):
     """Parameters stored in [lo, hi) (all parameters when None) were modified behind torch's back."""
     WEIGHT_EPOCH[0] += 1
+    for e in _PARAM_REGIONS.values():
+        if lo is None or (lo < e["hi"] and e["lo"] < hi):
+            e["dirty"] = True
     if lo is None:
         _WN_CACHE.clear()
         return
@@ -1005,13 +1019,41 @@ def invalidate_weights(lo=None, hi=None):
         del _WN_CACHE[k]
 
 
+# Parameter regions: an optimizer that keeps its parameters in one flat buffer registers it (register_param_region).  Conv
+# weights that are used as they are (no weight norm: the encoders' attention / FFN / projection layers) then get the same
+# treatment as the weight-normed trees: their packed copies are cached until the region is written (invalidate_weights)
+# and re-made in ONE batched launch at the first use afterwards, instead of one pack launch per layer and use (110 launches of
+# ~8 us per bf16-mode step of the full model).
+_PARAM_REGIONS = {}
+_PARAM_REGIONS_ON = [__import__("os").environ.get("VCVITS_PARAM_REGIONS", "1") == "1"]
+
+
+def register_param_region(flat):
+    lo = flat.data_ptr()
+    hi = lo + 4 * flat.numel()
+    _PARAM_REGIONS[lo] = dict(lo=lo, hi=hi, packs={}, key=("region", lo, hi), shapes=(int(flat.numel()),), wbuf=flat, dirty=True)
+
+
+def unregister_param_region(flat):
+    _PARAM_REGIONS.pop(flat.data_ptr(), None)
+
+
 def _stable_entry(w_ptr):
-    """The cached weight-norm buffer (its cache entry) that contains address w_ptr, if any."""
+    """The cached weight-norm buffer (its cache entry) -- or the registered parameter region -- that contains address w_ptr,
+    if any."""
     if w_ptr is None:
         return None
     for e in _WN_CACHE.values():
         if e["lo"] <= w_ptr < e["hi"]:
             return e
+    if _PARAM_REGIONS_ON[0] and CAPTURING[0] is None:  # (a captured sequence must contain the launches that pack its weights)
+        for e in _PARAM_REGIONS.values():
+            if e["lo"] <= w_ptr < e["hi"]:
+                if e["dirty"]:
+                    e["dirty"] = False
+                    e["packs"].clear()
+                    _replay_packs(e["key"], e)
+                return e
     return None
 
 
@@ -1057,7 +1099,9 @@ def _replay_packs(key, ent):
     arena = torch.empty((total + 32 * len(todo),), device=dev, dtype=torch.float32)
     n = off = 0
     reg = []
-    for (woff, words, sig, fam), (abytes, flip) in todo:
+    for (woff, words, sig, fam), job in todo:
+        abytes, flip = job[0], job[1]
+        wver = job[2] if len(job) > 2 else 0
         a = VcvConvArgs.from_buffer_copy(abytes)
         if woff < 0 or woff + 4 * a.Mg * a.Cg * a.K > span:
             continue
@@ -1066,7 +1110,7 @@ def _replay_packs(key, ent):
             continue  # (the plan no longer takes this launch, e.g. a mode switch: it will pack lazily)
         view = arena[off:off + words]
         arr[n].w, arr[n].wp = a.w, view.data_ptr()
-        reg.append(((a.w, words, sig), view))
+        reg.append(((a.w, words, sig) if wver == 0 else (a.w, words, sig, wver), view))
         off += (words + 31) & ~31  # 128-byte aligned slices
         n += 1
     if n == 0:
