@@ -648,4 +648,8 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    # a stuck run can be asked where it is: SIGUSR1 writes every thread's Python stack to stderr (tools/run_profiles.sh)
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)
     main()
