@@ -306,6 +306,17 @@ int vcv_weight_norm_many_fwd(const void* items_dev, int n_items, int total_rows,
                              void* stream);
 int vcv_weight_norm_many_bwd(const void* items_dev, int n_items, int total_rows, const float* norm, void* stream);
 
+/* ---- spectral norm: torch.nn.utils.spectral_norm (dim 0, n_power_iterations 1, eps 1e-12), which the reference's
+ * discriminators use in place of weight norm under use_spectral_norm=True (discriminator.py:17,52;
+ * multi_scale_discriminator.py:13-19).  w, w_sn: [R, N] rows (R = output channels); u [R], v [N]: the layer's persistent
+ * vectors, UPDATED IN PLACE when `power_iteration` (training forward); sigma [1] = u . (W v); w_sn = w / sigma.
+ * work: R + N floats (fwd), 256 floats (bwd).  Backward: dw = (dw_sn - <dw_sn, w_sn> u v^T) / sigma with the u, v,
+ * sigma of that forward (copies: the next forward overwrites the vectors). ---- */
+int vcv_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, float* work, int R, int N,
+                          int power_iteration, float eps, void* stream);
+int vcv_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
+                          float* dw, float* work, int R, int N, void* stream);
+
 /* wt[c, m, K-1-k] = w[m, c, k]: lets the stride-1 data gradient of a conv run as a forward conv */
 int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, void* stream);
 

@@ -11,8 +11,15 @@ import torch
 from . import vits_oracle as O
 
 
+def _is_buffer(sd, k):
+    """The power-iteration vectors of a spectrally normed layer (buffers of torch.nn.utils.spectral_norm, not parameters):
+    weight_u, and weight_v where the layer carries weight_orig (weight_v of a weight-normed layer IS a parameter)."""
+    return k.endswith(".weight_u") or (k.endswith(".weight_v") and k[:-1] + "orig" in sd)
+
+
 def _leaf_copy(sd):
-    return {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    return {k: v.detach().clone().float().requires_grad_(v.is_floating_point() and not _is_buffer(sd, k))
+            for k, v in sd.items()}
 
 
 class CpuTrainer:
@@ -23,7 +30,8 @@ class CpuTrainer:
         self.vocoder_only = vocoder_only
         self.sd = _leaf_copy(module_state_dict)
         g_keys = [k for k in self.sd if k.startswith("net_g.") and self.sd[k].requires_grad]
-        d_keys = [k for k in self.sd if (k.startswith("net_period_d.") or k.startswith("net_scale_d."))]
+        d_keys = [k for k in self.sd if (k.startswith("net_period_d.") or k.startswith("net_scale_d."))
+                  and self.sd[k].requires_grad]
         t = hparams["train"]
         self.g_params = [self.sd[k] for k in g_keys]
         self.d_params = [self.sd[k] for k in d_keys]
@@ -90,8 +98,8 @@ class CpuTrainer:
             p.requires_grad_(True)
         self.opt_g.zero_grad()
         y_hat, y, y_mel, kl_args = self._generator_pass(batch_g)
-        _, gp, frp, fgp = O.mpd_forward(self.sd, "net_period_d", y, y_hat, self.periods)
-        _, gs, frs, fgs = O.msd_forward(self.sd, "net_scale_d", y, y_hat)
+        _, gp, frp, fgp = O.mpd_forward(self.sd, "net_period_d", y, y_hat, self.periods, training=True)
+        _, gs, frs, fgs = O.msd_forward(self.sd, "net_scale_d", y, y_hat, training=True)
         _, mel_hat = self._mel(y_hat.squeeze(1))
         loss_g = (O.generator_loss(gs) + O.feature_loss(frs, fgs)) + (O.generator_loss(gp) + O.feature_loss(frp, fgp)) \
             + torch.nn.functional.l1_loss(mel_hat, y_mel) * t["c_mel"]
@@ -108,8 +116,8 @@ class CpuTrainer:
         self.opt_d.zero_grad()
         with torch.no_grad():
             y_hat, y, _, _ = self._generator_pass(batch_d)
-        rp, gp, _, _ = O.mpd_forward(self.sd, "net_period_d", y, y_hat.detach(), self.periods)
-        rs, gs, _, _ = O.msd_forward(self.sd, "net_scale_d", y, y_hat.detach())
+        rp, gp, _, _ = O.mpd_forward(self.sd, "net_period_d", y, y_hat.detach(), self.periods, training=True)
+        rs, gs, _, _ = O.msd_forward(self.sd, "net_scale_d", y, y_hat.detach(), training=True)
         loss_d = O.discriminator_loss(rp, gp) + O.discriminator_loss(rs, gs)
         loss_d.backward()
         self.grads_d = {k: self.sd[k].grad.detach().clone() for k in self.sd

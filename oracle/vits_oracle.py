@@ -61,9 +61,29 @@ def slice_ids_from_uniform(u, x_lengths, segment_size):
     return (u * ids_str_max).to(dtype=torch.long)
 
 
-def _wn_weight(sd, prefix):
+def spectral_norm_weight(sd, prefix, training, eps=1e-12):
+    """Effective weight of a conv under torch.nn.utils.spectral_norm (the old hook form; dim 0, one power iteration,
+    eps 1e-12), which discriminator.py:17,52 use as norm_f when use_spectral_norm=True.  Restates the published
+    algorithm of torch's SpectralNorm.compute_weight: in a training forward  v <- normalize(W^T u),  u <- normalize(W v)
+    (both stored vectors updated in place, without gradient), then sigma = u . (W v) on copies of them and W / sigma;
+    an eval forward uses the stored vectors as they are."""
+    w, u, v = sd[prefix + ".weight_orig"], sd[prefix + ".weight_u"], sd[prefix + ".weight_v"]
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+        u, v = u.clone(), v.clone()
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w / sigma
+
+
+def _wn_weight(sd, prefix, training=False):
     """Effective weight of a (possibly weight-normed) conv: torch.nn.utils.weight_norm, dim=0
-    (modules.py:126,132,143; discriminator.py:16)."""
+    (modules.py:126,132,143; discriminator.py:16); spectral norm where the layer carries weight_orig (`training`
+    = the module's mode, which decides the power iteration)."""
+    if prefix + ".weight_orig" in sd:
+        return spectral_norm_weight(sd, prefix, training)
     if prefix + ".weight_v" in sd:
         v, g = sd[prefix + ".weight_v"], sd[prefix + ".weight_g"]
         dims = tuple(range(1, v.dim()))
@@ -300,21 +320,21 @@ DISC_S_LAYERS = [  # (stride, padding, groups)  vits/model/discriminators/discri
     (1, 7, 1), (4, 20, 4), (4, 20, 16), (4, 20, 64), (4, 20, 256), (1, 2, 1)]
 
 
-def disc_s_forward(sd, prefix, x):
-    """discriminator.py:63-74 (DiscriminatorS.forward)."""
+def disc_s_forward(sd, prefix, x, training=False):
+    """discriminator.py:63-74 (DiscriminatorS.forward).  `training` matters under spectral norm only."""
     fmap = []
     for i, (s, p, g) in enumerate(DISC_S_LAYERS):
-        x = F.conv1d(x, _wn_weight(sd, "%s.convs.%d" % (prefix, i)), _bias(sd, "%s.convs.%d" % (prefix, i)),
+        x = F.conv1d(x, _wn_weight(sd, "%s.convs.%d" % (prefix, i), training), _bias(sd, "%s.convs.%d" % (prefix, i)),
                      stride=s, padding=p, groups=g)
         x = F.leaky_relu(x, LRELU_SLOPE)
         fmap.append(x)
-    x = F.conv1d(x, _wn_weight(sd, prefix + ".conv_post"), _bias(sd, prefix + ".conv_post"), padding=1)
+    x = F.conv1d(x, _wn_weight(sd, prefix + ".conv_post", training), _bias(sd, prefix + ".conv_post"), padding=1)
     fmap.append(x)
     return torch.flatten(x, 1, -1), fmap
 
 
-def disc_p_forward(sd, prefix, x, period, kernel_size=5, stride=3):
-    """discriminator.py:27-46 (DiscriminatorP.forward)."""
+def disc_p_forward(sd, prefix, x, period, kernel_size=5, stride=3, training=False):
+    """discriminator.py:27-46 (DiscriminatorP.forward).  `training` matters under spectral norm only."""
     fmap = []
     b, c, t = x.shape
     if t % period != 0:
@@ -324,32 +344,32 @@ def disc_p_forward(sd, prefix, x, period, kernel_size=5, stride=3):
     x = x.view(b, c, t // period, period)
     for i in range(5):
         s = stride if i < 4 else 1
-        x = F.conv2d(x, _wn_weight(sd, "%s.convs.%d" % (prefix, i)), _bias(sd, "%s.convs.%d" % (prefix, i)),
+        x = F.conv2d(x, _wn_weight(sd, "%s.convs.%d" % (prefix, i), training), _bias(sd, "%s.convs.%d" % (prefix, i)),
                      stride=(s, 1), padding=(get_padding(kernel_size, 1), 0))
         x = F.leaky_relu(x, LRELU_SLOPE)
         fmap.append(x)
-    x = F.conv2d(x, _wn_weight(sd, prefix + ".conv_post"), _bias(sd, prefix + ".conv_post"), padding=(1, 0))
+    x = F.conv2d(x, _wn_weight(sd, prefix + ".conv_post", training), _bias(sd, prefix + ".conv_post"), padding=(1, 0))
     fmap.append(x)
     return torch.flatten(x, 1, -1), fmap
 
 
-def mpd_forward(sd, prefix, y, y_hat, periods):
+def mpd_forward(sd, prefix, y, y_hat, periods, training=False):
     """multi_period_discriminator.py:17-31: one DiscriminatorS followed by one DiscriminatorP per
-    period."""
+    period; d(y) then d(y_hat) -- two forwards, i.e. two power iterations per layer under spectral norm."""
     outs = ([], [], [], [])
     for i in range(len(periods) + 1):
         p = "%s.discriminators.%d" % (prefix, i)
         if i == 0:
-            r, fr = disc_s_forward(sd, p, y)
-            g, fg = disc_s_forward(sd, p, y_hat)
+            r, fr = disc_s_forward(sd, p, y, training)
+            g, fg = disc_s_forward(sd, p, y_hat, training)
         else:
-            r, fr = disc_p_forward(sd, p, y, periods[i - 1])
-            g, fg = disc_p_forward(sd, p, y_hat, periods[i - 1])
+            r, fr = disc_p_forward(sd, p, y, periods[i - 1], training=training)
+            g, fg = disc_p_forward(sd, p, y_hat, periods[i - 1], training=training)
         outs[0].append(r); outs[1].append(g); outs[2].append(fr); outs[3].append(fg)
     return outs
 
 
-def msd_forward(sd, prefix, y, y_hat):
+def msd_forward(sd, prefix, y, y_hat, training=False):
     """multi_scale_discriminator.py:27-42: 5 DiscriminatorS on progressively AvgPool1d(4,2,2)
     inputs."""
     outs = ([], [], [], [])
@@ -358,8 +378,8 @@ def msd_forward(sd, prefix, y, y_hat):
             y = F.avg_pool1d(y, 4, 2, 2)
             y_hat = F.avg_pool1d(y_hat, 4, 2, 2)
         p = "%s.discriminators.%d" % (prefix, i)
-        r, fr = disc_s_forward(sd, p, y)
-        g, fg = disc_s_forward(sd, p, y_hat)
+        r, fr = disc_s_forward(sd, p, y, training)
+        g, fg = disc_s_forward(sd, p, y_hat, training)
         outs[0].append(r); outs[2].append(fr); outs[1].append(g); outs[3].append(fg)
     return outs
 

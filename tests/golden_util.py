@@ -38,6 +38,13 @@ def fill_state_dict(keys_shapes, seed):
                 fan = 1
             t = rng_tensor(rng, shape, scale=max(fan, 1) ** -0.5)
         sd[key] = t
+    # spectral-normed layers (weight_orig + the power-iteration vectors weight_u / weight_v): unit vectors, as
+    # torch.nn.utils.spectral_norm keeps them
+    for key in list(sd):
+        if key.endswith(".weight_orig") or key == "weight_orig":
+            for leaf in ("weight_u", "weight_v"):
+                k = key[:-len("weight_orig")] + leaf
+                sd[k] = sd[k] / sd[k].norm()
     return sd
 
 

@@ -63,6 +63,33 @@ def test_vocoder_gan_batch(gpu):
          tol_grad=2e-2)
 
 
+def test_vocoder_gan_batch_spectral_norm(gpu):
+    """use_spectral_norm=True through a whole batch: the discriminators' power-iteration vectors advance with each of the
+    four forwards a batch runs them through (d(y), d(y_hat) in the generator step and again in the discriminator step),
+    losses and every gradient against the oracle trainer; the vectors after the batch are the oracle's."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import synthetic
+    from vcvits_amd.light.vcvits import VocoderGAN
+    torch.manual_seed(0)
+    cfg = small_cfg()
+    cfg["model"]["use_spectral_norm"] = True
+    module = VocoderGAN(**cfg)
+    assert "net_period_d.discriminators.1.convs.0.weight_orig" in module.state_dict()
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, [2, 3], vocoder_only=True)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    _run(module, trainer, synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3), gpu)
+    sd = module.state_dict()
+    n = 0
+    for k, v in trainer.sd.items():
+        if k.endswith(".weight_u") or (k.endswith(".weight_v") and k[:-1] + "orig" in trainer.sd):
+            assert (sd[k].cpu() - v).abs().max().item() <= 1e-4, k
+            n += 1
+    assert n == 2 * ((7 + 2 * 6) + 7)  # MPD: DiscS (7 convs) + two DiscP (6 each); MSD: its first DiscS only
+    _run(module, trainer, synthetic.vocoder_batch(2, 16, segment_size=4096, seed=4), gpu, tol_loss=1e-3,
+         tol_grad=2e-2)
+
+
 def test_full_vcvits_batch(gpu):
     from oracle.cpu_step import CpuTrainer
     from vcvits_amd import synthetic

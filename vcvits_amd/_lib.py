@@ -84,7 +84,7 @@ def lib():
 # every symbol include/vcvits_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "vcv_version", "vcv_conv_gemm", "vcv_conv_wgrad", "vcv_bias_grad",
-    "vcv_weight_norm_fwd", "vcv_weight_norm_bwd", "vcv_avg3", "vcv_scale", "vcv_mask_mul",
+    "vcv_weight_norm_fwd", "vcv_weight_norm_bwd", "vcv_spectral_norm_fwd", "vcv_spectral_norm_bwd", "vcv_avg3", "vcv_scale", "vcv_mask_mul",
     "vcv_reflect_pad_fwd", "vcv_reflect_pad_bwd", "vcv_avgpool4_fwd", "vcv_avgpool4_bwd",
     "vcv_loss_sum", "vcv_loss_grad", "vcv_adamw", "vcv_stft_mag_fwd", "vcv_stft_mag_bwd",
     "vcv_wn_gate_fwd", "vcv_wn_gate_bwd", "vcv_row_sum", "vcv_wn_res_skip_fwd", "vcv_wn_res_skip_bwd",
@@ -107,6 +107,8 @@ _ARGTYPES = {
     "vcv_bias_grad": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "vcv_weight_norm_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "vcv_weight_norm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vcv_spectral_norm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "vcv_spectral_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vcv_avg3": [_P, _P, _P, _P, _L, _P],
     "vcv_scale": [_P, _P, _F, _L, _P],
     "vcv_mask_mul": [_P, _P, _P, _I, _I, _I, _P],

@@ -11,6 +11,12 @@ import torch
 
 
 def run_pair(disc, y, y_hat):
+    if getattr(disc, "use_spectral_norm", False) and disc.training:
+        # every training forward advances the layers' power-iteration vectors, and d(y) and d(y_hat) are two forwards in
+        # the reference (multi_period_discriminator.py:22-28): the second divides by the sigma of the second iteration
+        out_r, fmap_r = disc(y)
+        out_g, fmap_g = disc(y_hat)
+        return out_r, out_g, fmap_r, fmap_g
     wants_wgrad = torch.is_grad_enabled() and any(p.requires_grad for p in disc.parameters())
     B = y.shape[0]
     if wants_wgrad or not (y_hat.requires_grad and torch.is_grad_enabled()):

@@ -13,15 +13,14 @@ from ..modules import Conv, LRELU_SLOPE, prepare_weight_norm
 class DiscriminatorP(nn.Module):
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
         super().__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("use_spectral_norm is false in both reference configs")
+        self.use_spectral_norm = sn = bool(use_spectral_norm)  # norm_f = spectral_norm instead of weight_norm (:17)
         self.period = period
         pad = get_padding(kernel_size, 1)
         chans = [1, 32, 128, 512, 1024, 1024]
         self.convs = nn.ModuleList([
             Conv(chans[i], chans[i + 1], kernel_size, stride=(stride if i < 4 else 1), padding=pad, weight_norm=True,
-                 two_d=True) for i in range(5)])
-        self.conv_post = Conv(1024, 1, 3, padding=1, weight_norm=True, two_d=True)
+                 two_d=True, spectral_norm=sn) for i in range(5)])
+        self.conv_post = Conv(1024, 1, 3, padding=1, weight_norm=True, two_d=True, spectral_norm=sn)
 
     def forward(self, x):
         prepare_weight_norm(self)
@@ -43,13 +42,12 @@ class DiscriminatorP(nn.Module):
 class DiscriminatorS(nn.Module):
     def __init__(self, use_spectral_norm=False):
         super().__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("use_spectral_norm is false in both reference configs")
+        self.use_spectral_norm = sn = bool(use_spectral_norm)  # (:52)
         cfg = [(1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 16), (256, 1024, 41, 4, 20, 64),
                (1024, 1024, 41, 4, 20, 256), (1024, 1024, 5, 1, 2, 1)]
-        self.convs = nn.ModuleList([Conv(ci, co, k, stride=s, padding=p, groups=g, weight_norm=True)
+        self.convs = nn.ModuleList([Conv(ci, co, k, stride=s, padding=p, groups=g, weight_norm=True, spectral_norm=sn)
                                     for ci, co, k, s, p, g in cfg])
-        self.conv_post = Conv(1024, 1, 3, padding=1, weight_norm=True)
+        self.conv_post = Conv(1024, 1, 3, padding=1, weight_norm=True, spectral_norm=sn)
 
     def forward(self, x):
         prepare_weight_norm(self)

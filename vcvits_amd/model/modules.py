@@ -93,14 +93,23 @@ class Conv(nn.Module):
     torch.nn.utils.weight_norm (same state_dict keys as the reference)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
-                 bias=True, weight_norm=False, two_d=False):
+                 bias=True, weight_norm=False, two_d=False, spectral_norm=False):
         super().__init__()
         self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
         shape = (out_channels, in_channels // groups, kernel_size) + ((1,) if two_d else ())
         w = torch.empty(shape)
         b = torch.empty(out_channels) if bias else None
         _default_conv_init(w, b)
-        self.is_wn = weight_norm
+        self.is_wn = weight_norm and not spectral_norm
+        self.is_sn = spectral_norm
+        if spectral_norm:
+            # torch.nn.utils.spectral_norm (old hook form, what discriminator.py:17,52 apply): parameters (bias,
+            # weight_orig), buffers weight_u [out] and weight_v [in/groups * k] = normalised N(0, 1) draws
+            self.bias = nn.Parameter(b) if bias else None
+            self.weight_orig = nn.Parameter(w)
+            self.register_buffer("weight_u", nn.functional.normalize(torch.randn(shape[0]), dim=0, eps=self.SN_EPS))
+            self.register_buffer("weight_v", nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=self.SN_EPS))
+            return
         # registration order follows torch: (weight, bias) for a plain conv, (bias, weight_g, weight_v)
         # after torch.nn.utils.weight_norm
         if weight_norm:
@@ -112,7 +121,12 @@ class Conv(nn.Module):
             self.weight = nn.Parameter(w)
             self.bias = nn.Parameter(b) if bias else None
 
+    SN_EPS = 1e-12  # torch.nn.utils.spectral_norm's default
+
     def effective_weight(self):
+        if self.is_sn:
+            # one power iteration per training forward, none in eval mode (the hook's do_power_iteration = module.training)
+            return ops.spectral_norm(self.weight_orig, self.weight_u, self.weight_v, self.training, self.SN_EPS)
         if not self.is_wn:
             return self.weight
         w = _take_prepared(self)

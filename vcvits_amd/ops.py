@@ -992,6 +992,45 @@ def weight_norm(v, g):
     return _WeightNormFn.apply(v, g)
 
 
+class _SpectralNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, u, v, power_iteration, eps):
+        w = _f32c(w)
+        if not (u.is_contiguous() and v.is_contiguous() and u.dtype == torch.float32 and v.dtype == torch.float32):
+            raise RuntimeError("spectral_norm: weight_u / weight_v must be contiguous fp32 buffers (updated in place)")
+        R = w.shape[0]
+        N = w.numel() // R
+        if u.numel() != R or v.numel() != N:
+            raise RuntimeError("spectral_norm: weight_u / weight_v do not match the weight's [%d, %d] matrix" % (R, N))
+        w_sn = torch.empty_like(w)
+        sigma = torch.empty((1,), device=w.device, dtype=torch.float32)
+        work = torch.empty((R + N,), device=w.device, dtype=torch.float32)
+        check(lib().vcv_spectral_norm_fwd(ptr(w), ptr(u), ptr(v), ptr(w_sn), ptr(sigma), ptr(work), R, N,
+                                          1 if power_iteration else 0, eps, stream()), "vcv_spectral_norm_fwd")
+        # the vectors sigma was formed from: the next training forward overwrites the buffers (torch clones them too)
+        ctx.save_for_backward(w_sn, u.clone() if power_iteration else u, v.clone() if power_iteration else v, sigma)
+        return w_sn
+
+    @staticmethod
+    def backward(ctx, dw_sn):
+        w_sn, u, v, sigma = ctx.saved_tensors
+        dw_sn = _f32c(dw_sn)
+        R = w_sn.shape[0]
+        N = w_sn.numel() // R
+        dw = torch.empty_like(w_sn)
+        work = torch.empty((256,), device=w_sn.device, dtype=torch.float32)
+        check(lib().vcv_spectral_norm_bwd(ptr(dw_sn), ptr(w_sn), ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(work), R, N,
+                                          stream()), "vcv_spectral_norm_bwd")
+        return dw, None, None, None, None
+
+
+def spectral_norm(w, u, v, power_iteration, eps=1e-12):
+    """w / sigma, sigma = u . (W v) over the [out_channels, rest] matrix of w (torch.nn.utils.spectral_norm, dim 0, one
+    power iteration; reference: discriminator.py:17,52 under use_spectral_norm=True).  With `power_iteration` (a training
+    forward) the buffers u, v are advanced IN PLACE first, as torch's forward pre-hook does."""
+    return _SpectralNormFn.apply(w, u, v, bool(power_iteration), float(eps))
+
+
 _WN_TABLES = {}
 # Cached results of _WeightNormManyFn per parameter set: {key: dict(versions, wbuf, norm, lo, hi, packs)}.  An
 # entry is valid until one of its parameters changes: in place through torch (version counters) or through an
