@@ -295,9 +295,11 @@ def resblock1_forward(sd, prefix, x, kernel_size, dilations=(1, 3, 5)):
 def generator_forward(sd, prefix, x, upsample_rates=(8, 8, 4, 2), upsample_kernel_sizes=(16, 16, 4, 4),
                       resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5),) * 3):
     """conv_pre k7 -> 4 x (leaky 0.1 -> weight-normed ConvTranspose1d ->
-    mean of 3 ResBlock1) -> leaky (default slope 0.01) -> conv_post k7 (no bias) -> tanh."""
+    mean of 3 ResBlock1) -> leaky (default slope 0.01) -> conv_post k7 (no bias) -> tanh.  conv_pre / conv_post are
+    read in whichever form the state_dict holds them (the original HiFi-GAN lineage weight-norms both and keeps
+    conv_post's bias; the VITS lineage does neither)."""
     nk = len(resblock_kernel_sizes)
-    x = F.conv1d(x, sd[prefix + ".conv_pre.weight"], sd[prefix + ".conv_pre.bias"], padding=3)
+    x = F.conv1d(x, _wn_weight(sd, prefix + ".conv_pre"), sd[prefix + ".conv_pre.bias"], padding=3)
     for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
         x = F.leaky_relu(x, LRELU_SLOPE)
         x = F.conv_transpose1d(x, _wn_weight(sd, "%s.ups.%d" % (prefix, i)), _bias(sd, "%s.ups.%d" % (prefix, i)),
@@ -309,7 +311,7 @@ def generator_forward(sd, prefix, x, upsample_rates=(8, 8, 4, 2), upsample_kerne
             xs = r if xs is None else xs + r
         x = xs / nk
     x = F.leaky_relu(x)
-    x = F.conv1d(x, sd[prefix + ".conv_post.weight"], None, padding=3)
+    x = F.conv1d(x, _wn_weight(sd, prefix + ".conv_post"), _bias(sd, prefix + ".conv_post"), padding=3)
     return torch.tanh(x)
 
 

@@ -13,12 +13,20 @@ from .modules import Conv, ConvT, LRELU_SLOPE
 
 
 class Generator(nn.Module):
+    """Defaults = the canonical VITS decoder (plain conv_pre, plain bias-free conv_post).  The original HiFi-GAN lineage
+    (jik876) weight-norms conv_pre / conv_post and keeps conv_post's bias; which of the two the hub model
+    "vtuber-plan/hifi-gan:v0.3.1" follows cannot be checked offline, so both load: the three
+    `conv_*` switches select the form, and `load_state_dict` switches the two layers to the form its keys show
+    (`conv_pre.weight_g`, `conv_post.weight_g`, `conv_post.bias`) before copying -- load weights before creating
+    optimizers, as the reference does (synthesizer_svc.py:59 builds the decoder with its weights)."""
+
     def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
-                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0, conv_pre_weight_norm=False,
+                 conv_post_weight_norm=False, conv_post_bias=False):
         super().__init__()
         self.num_kernels = len(resblock_kernel_sizes)
         self.num_upsamples = len(upsample_rates)
-        self.conv_pre = Conv(initial_channel, upsample_initial_channel, 7, padding=3)
+        self.conv_pre = Conv(initial_channel, upsample_initial_channel, 7, padding=3, weight_norm=conv_pre_weight_norm)
         block = modules.ResBlock1 if str(resblock) == "1" else modules.ResBlock2
         self.ups = nn.ModuleList()
         for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
@@ -30,11 +38,30 @@ class Generator(nn.Module):
             ch = upsample_initial_channel // (2 ** (i + 1))
             for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes):
                 self.resblocks.append(block(ch, k, tuple(d)))
-        self.conv_post = Conv(ch, 1, 7, padding=3, bias=False)
+        self.conv_post = Conv(ch, 1, 7, padding=3, bias=conv_post_bias, weight_norm=conv_post_weight_norm)
         if gin_channels != 0:
             self.cond = Conv(gin_channels, upsample_initial_channel, 1)
         for m in self.ups:
             m.weight_v.data.normal_(0.0, 0.01)
+        self._register_load_state_dict_pre_hook(self._match_lineage, with_module=True)
+
+    @staticmethod
+    def _match_lineage(self, state_dict, prefix, *_):
+        """Before a state_dict is copied in: give conv_pre / conv_post the form (weight norm, bias) its keys show."""
+        for name in ("conv_pre", "conv_post"):
+            k = prefix + name
+            if k + ".weight_g" not in state_dict and k + ".weight" not in state_dict:
+                continue  # (a partial state_dict without this layer: nothing to go by)
+            old = getattr(self, name)
+            wn = k + ".weight_g" in state_dict
+            bias = k + ".bias" in state_dict
+            if wn == old.is_wn and bias == (old.bias is not None):
+                continue
+            w = old.weight_v if old.is_wn else old.weight
+            new = Conv(w.shape[1], w.shape[0], w.shape[2], padding=old.padding, bias=bias, weight_norm=wn)
+            setattr(self, name, new.to(device=w.device, dtype=w.dtype))
+            for key in ("_wn_mods", "_wn_mods_skip", "_wn_mods_groups", "_wn_mods_skip_groups"):
+                self.__dict__.pop(key, None)  # prepare_weight_norm's cached layer list
 
     def _forward_bf16_activations(self, x, g):
         """Inference in bf16 mode: every conv <-> conv tensor between conv_pre and conv_post lives in 16 bits in HBM (the
@@ -65,7 +92,7 @@ class Generator(nn.Module):
         modules.prepare_weight_norm(self)
         if (ops.bf16_activations() and not torch.is_grad_enabled() and x.is_cuda and x.shape[-1] % 2 == 0
                 and x.shape[-1] >= 96 and isinstance(self.resblocks[0], modules.ResBlock1)
-                and self.conv_post.weight.shape[2] in (3, 5, 7)):
+                and (self.conv_post.weight_v if self.conv_post.is_wn else self.conv_post.weight).shape[2] in (3, 5, 7)):
             return self._forward_bf16_activations(x, g)
         x = self.conv_pre(x)
         if g is not None:
