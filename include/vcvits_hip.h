@@ -359,9 +359,11 @@ int vcv_loss_many_grad(const void* items_dev, int n_items, int total_blocks, flo
 int vcv_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
               float eps, float wd, int step, void* stream);
 
-/* ---- STFT magnitude sqrt(re^2+im^2+eps), n_fft = 2048 (mel_processing.py:54-96).
- * y: [B, T]; window: [2048]; twiddle: [1024] complex (cos, -sin)(2*pi*k/2048) interleaved;
- * mag/dmag: [B, 1025, F], F = (T + 2*pad - 2048)/hop + 1; reflect: 0 zero pad (torchaudio
+/* ---- STFT magnitude sqrt(re^2+im^2+eps) (mel_processing.py:54-96): n_fft = 2048 (both reference configs; the tuned
+ * kernels) or any other power of two in [64, 4096] (generic radix-2 kernels, stft_generic.hip).
+ * y: [B, T]; window: [n_fft] -- the analysis window already zero-padded (centred) to n_fft when win_length < n_fft, as
+ * torch.stft does; twiddle: [n_fft/2] complex (cos, -sin)(2*pi*k/n_fft) interleaved;
+ * mag/dmag: [B, n_fft/2+1, F], F = (T + 2*pad - n_fft)/hop + 1; reflect: 0 zero pad (torchaudio
  * spectrogram, :76-96), 1 reflect pad (:54-74).  bwd overwrites dy [B, T]. ---- */
 int vcv_stft_mag_fwd(const float* y, const float* window, const float* twiddle, float* mag, int B, int T,
                      int n_fft, int hop, int pad, int reflect, float eps, void* stream);

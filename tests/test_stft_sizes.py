@@ -1,0 +1,91 @@
+"""STFT sizes other than the reference configs' 2048 / 512 / 2048 (vits/mel_processing.py:54-96 take n_fft, hop_size and
+win_size as arguments; torch.stft pads a shorter window to n_fft).  Vectors: tests/golden/stft_sizes.npz, produced by the
+reference's spectrogram_torch (tools/make_goldens_stft_sizes.py).
+
+CPU: the oracle against those vectors.  GPU (-m gpu): mel_processing on the HIP kernels against them (n_fft = 2048 on the
+tuned kernels with a shorter window or another hop, every other size on the generic radix-2 kernels), the zero-pad variant
+and the input gradient against the oracle, the source-audio pipeline with win_length < n_fft."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load
+from oracle import vits_oracle as O
+
+
+def _sizes(g):
+    return [tuple(int(v) for v in row) for row in g["sizes"]]
+
+
+def close(name, a, b, tol, atol=1e-6):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert err <= tol * b.abs().max().item() + atol, "%s: abs err %.3e (scale %.3e)" % (name, err, b.abs().max().item())
+
+
+def test_oracle_vs_reference_vectors():
+    g = load("stft_sizes.npz")
+    y = torch.from_numpy(g["y"])
+    for n_fft, hop, win in _sizes(g):
+        close("%d/%d/%d" % (n_fft, hop, win), O.spectrogram(y, n_fft, hop, win, reflect=True), g["spec_%d_%d_%d" % (n_fft, hop, win)],
+              tol=2e-5)
+
+
+@pytest.mark.gpu
+def test_spectrogram_torch_at_other_sizes(gpu):
+    from vcvits_amd import mel_processing
+    g = load("stft_sizes.npz")
+    y = torch.from_numpy(g["y"]).to(gpu)
+    for n_fft, hop, win in _sizes(g):
+        spec = mel_processing.spectrogram_torch(y, n_fft, 22050, hop, win, center=False)
+        close("%d/%d/%d" % (n_fft, hop, win), spec, g["spec_%d_%d_%d" % (n_fft, hop, win)], tol=1e-5)  # north_star: 1e-5 on STFT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reflect", [True, False])
+def test_gradients_and_zero_pad_at_other_sizes(gpu, reflect):
+    from vcvits_amd import mel_processing
+    rng = np.random.default_rng(3)
+    fn = mel_processing.spectrogram_torch if reflect else mel_processing.spectrogram_torch_audio
+    for n_fft, hop, win, T in ((1024, 256, 1024, 4096), (512, 128, 400, 3000), (4096, 1024, 4096, 9000), (2048, 512, 1200, 6000),
+                               (128, 32, 128, 777)):
+        y = torch.from_numpy((rng.standard_normal((3, T)) * 0.3).astype(np.float32))
+        yc = y.clone().requires_grad_(True)
+        ref = O.spectrogram(yc, n_fft, hop, win, reflect=reflect)
+        r = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        (ref * r).sum().backward()
+        yg = y.to(gpu).requires_grad_(True)
+        out = fn(yg, n_fft, 22050, hop, win, center=False)
+        (out * r.to(gpu)).sum().backward()
+        tag = "%d/%d/%d %s" % (n_fft, hop, win, "reflect" if reflect else "zero")
+        close("spec " + tag, out, ref.detach(), tol=1e-5)
+        close("dy " + tag, yg.grad, yc.grad, tol=1e-4)
+    # mel of another size: the projection takes the bin count from the filterbank
+    mel = mel_processing.mel_spectrogram_torch(y.to(gpu), 1024, 80, 22050, 256, 1024, 0, None)
+    sp = O.spectrogram(y, 1024, 256, 1024, reflect=True)
+    ref = O.spec_to_mel(sp, torch.from_numpy(O.mel_filterbank(22050, 1024, 80, 0, None)))
+    close("mel 1024", mel, ref, tol=1e-4)
+
+
+@pytest.mark.gpu
+def test_unsupported_sizes_fail_loudly(gpu):
+    from vcvits_amd import mel_processing
+    y = torch.zeros(1, 4000, device=gpu)
+    with pytest.raises(NotImplementedError):
+        mel_processing.spectrogram_torch(y, 1000, 22050, 250, 1000)  # not a power of two
+    with pytest.raises(ValueError):
+        mel_processing.spectrogram_torch(y, 1024, 22050, 256, 2048)  # win_length > n_fft (torch.stft refuses it too)
+
+
+@pytest.mark.gpu
+def test_pipeline_with_shorter_window(gpu):
+    from vcvits_amd.model.pipeline import SpeechConversionAudioPipeline
+    rng = np.random.default_rng(9)
+    wav = torch.from_numpy((rng.standard_normal((2, 1, 16000)) * 0.2).astype(np.float32))
+    for win in (2048, 1600, 1024):
+        pipe = SpeechConversionAudioPipeline(sr=16000, n_fft=2048, n_mel=128, win_length=win, hop_length=512)
+        out = pipe(wav.to(gpu))
+        ref = O.audio_pipeline(wav, n_fft=2048, hop_length=512, win_length=win)
+        close("pipeline win %d" % win, out, ref, tol=1e-5, atol=2e-6)

@@ -90,6 +90,23 @@ def test_vocoder_gan_batch_spectral_norm(gpu):
          tol_grad=2e-2)
 
 
+def test_vocoder_gan_batch_filter_length_1024(gpu):
+    """A config with another STFT size (filter_length 1024, hop 256, win 1024: the mel loss of the generator step runs the
+    generic STFT kernels forward and backward, the decoder upsamples by 256): losses and every gradient vs the oracle."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import synthetic
+    from vcvits_amd.light.vcvits import VocoderGAN
+    torch.manual_seed(2)
+    cfg = small_cfg()
+    cfg["data"].update({"filter_length": 1024, "hop_length": 256, "win_length": 1024})
+    cfg["model"].update({"upsample_rates": [8, 8, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4]})
+    module = VocoderGAN(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, [2, 3], vocoder_only=True)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    _run(module, trainer, synthetic.vocoder_batch(2, 16, segment_size=4096, hop=256, seed=5), gpu)
+
+
 def test_full_vcvits_batch(gpu):
     from oracle.cpu_step import CpuTrainer
     from vcvits_amd import synthetic

@@ -732,12 +732,19 @@ static int launch_fwd_wave(const float* y, const float* window, const float* twi
   return vcv_check_launch();
 }
 
+// stft_generic.hip: any other power-of-two n_fft in [64, 4096]
+int stft_mag_fwd_generic_launch(const float* y, const float* window, const float* twiddle, float* mag, int B, int T, int n_fft,
+                                int hop, int pad, int reflect, float eps, hipStream_t st);
+int stft_mag_bwd_generic_launch(const float* y, const float* window, const float* twiddle, const float* dmag, float* dy, int B,
+                                int T, int n_fft, int hop, int pad, int reflect, float eps, hipStream_t st);
+
 extern "C" int vcv_stft_mag_fwd(const float* y, const float* window, const float* twiddle, float* mag,
                                 int B, int T, int n_fft, int hop, int pad, int reflect, float eps,
                                 void* stream) {
-  if (!y || !window || !twiddle || !mag || B <= 0 || T <= 0 || n_fft != N || hop <= 0 || pad < 0)
+  if (!y || !window || !twiddle || !mag || B <= 0 || T <= 0 || hop <= 0 || pad < 0)
     return VCV_EINVAL;
   if (reflect && pad > T - 1) return VCV_EINVAL;
+  if (n_fft != N) return stft_mag_fwd_generic_launch(y, window, twiddle, mag, B, T, n_fft, hop, pad, reflect, eps, (hipStream_t)stream);
   const int F = (T + 2 * pad - n_fft) / hop + 1;
   if (F <= 0) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -769,9 +776,11 @@ static int launch_bwd_own(const float* y, const float* window, const float* twid
 extern "C" int vcv_stft_mag_bwd(const float* y, const float* window, const float* twiddle,
                                 const float* dmag, float* dy, int B, int T, int n_fft, int hop, int pad,
                                 int reflect, float eps, void* stream) {
-  if (!y || !window || !twiddle || !dmag || !dy || B <= 0 || T <= 0 || n_fft != N || hop <= 0 || pad < 0)
+  if (!y || !window || !twiddle || !dmag || !dy || B <= 0 || T <= 0 || hop <= 0 || pad < 0)
     return VCV_EINVAL;
   if (reflect && pad > T - 1) return VCV_EINVAL;
+  if (n_fft != N)
+    return stft_mag_bwd_generic_launch(y, window, twiddle, dmag, dy, B, T, n_fft, hop, pad, reflect, eps, (hipStream_t)stream);
   const int F = (T + 2 * pad - n_fft) / hop + 1;
   if (F <= 0) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;

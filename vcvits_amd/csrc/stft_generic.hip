@@ -1,0 +1,148 @@
+// stft_generic.hip -- magnitude STFT forward / backward for any power-of-two n_fft in [64, 4096] other than the 2048 the two
+// reference configs use (stft.hip holds the kernels tuned for that size).  Reference: vits/mel_processing.py:54-96
+// (spectrogram_torch / spectrogram_torch_audio take n_fft, hop_size, win_size as arguments; torch.stft pads a shorter window
+// to n_fft, centred -- the `window` table handed in is already that padded window).
+//
+// One workgroup of 256 threads per FR consecutive frames of one row: a frame's windowed samples go into LDS in bit-reversed
+// order, log2(n_fft) radix-2 passes with the [n_fft/2] twiddle table (cos, -sin), magnitudes of the FR frames are staged in
+// LDS and written as FR consecutive floats per bin.  Backward: the frame's transform again, G_k = dmag_k X_k / mag_k on the
+// one-sided bins, the same transform on conj(G) (whose real part is the un-normalised inverse), times the window, added into
+// dy with fp32 atomics (frames overlap; dy is zeroed by the launcher).  A cold path: correct and coalesced, not tuned.
+#include "common.h"
+
+namespace {
+
+constexpr int GT = 256;  // threads per workgroup
+constexpr int FR = 4;    // frames per workgroup (forward)
+
+__device__ __forceinline__ int sample_index(int o, int T, int reflect) {
+  if (o >= 0 && o < T) return o;
+  if (!reflect) return -1;
+  return o < 0 ? -o : 2 * (T - 1) - o;  // (pad <= T - 1 checked by the launcher)
+}
+
+// in-place radix-2 decimation-in-time passes over buf[n_fft] (input in bit-reversed order, output in natural order)
+__device__ __forceinline__ void fft_passes(float2* buf, const float2* __restrict__ tw, int n_fft, int logn) {
+  for (int s = 1; s <= logn; ++s) {
+    const int half = 1 << (s - 1);
+    const int tstep = n_fft >> s;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_fft / 2; j += GT) {
+      const int k = j & (half - 1);
+      const int i0 = ((j >> (s - 1)) << s) + k;
+      const int i1 = i0 + half;
+      const float2 w = tw[k * tstep];
+      const float2 a = buf[i0], b = buf[i1];
+      const float2 t = make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
+      buf[i0] = make_float2(a.x + t.x, a.y + t.y);
+      buf[i1] = make_float2(a.x - t.x, a.y - t.y);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void load_frame(float2* buf, const float* __restrict__ yb, const float* __restrict__ window, int f,
+                                           int hop, int pad, int T, int reflect, int n_fft, int logn) {
+  for (int n = threadIdx.x; n < n_fft; n += GT) {
+    const int o = sample_index(f * hop + n - pad, T, reflect);
+    const float v = o >= 0 ? yb[o] * window[n] : 0.f;
+    buf[__brev((unsigned)n) >> (32 - logn)] = make_float2(v, 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(GT) stft_mag_fwd_generic_kernel(const float* __restrict__ y, const float* __restrict__ window,
+                                                                 const float2* __restrict__ tw, float* __restrict__ mag, int T,
+                                                                 int F, int hop, int pad, int reflect, float eps, int n_fft,
+                                                                 int logn) {
+  extern __shared__ float2 smem[];
+  float2* buf = smem;                                  // [n_fft]
+  float* outs = reinterpret_cast<float*>(smem + n_fft);  // [n_fft/2 + 1][FR]
+  const int nbin = n_fft / 2 + 1;
+  const int b = blockIdx.y, f0 = blockIdx.x * FR;
+  const float* yb = y + (size_t)b * T;
+  const int nf = min(FR, F - f0);
+  for (int i = 0; i < nf; ++i) {
+    __syncthreads();
+    load_frame(buf, yb, window, f0 + i, hop, pad, T, reflect, n_fft, logn);
+    fft_passes(buf, tw, n_fft, logn);
+    for (int k = threadIdx.x; k < nbin; k += GT) {
+      const float2 x = buf[k];
+      outs[k * FR + i] = sqrtf(x.x * x.x + x.y * x.y + eps);
+    }
+  }
+  __syncthreads();
+  float* mb = mag + (size_t)b * nbin * F + f0;
+  for (int e = threadIdx.x; e < nbin * FR; e += GT) {
+    const int k = e / FR, i = e % FR;
+    if (i < nf) mb[(size_t)k * F + i] = outs[e];
+  }
+}
+
+__global__ void __launch_bounds__(GT) stft_mag_bwd_generic_kernel(const float* __restrict__ y, const float* __restrict__ window,
+                                                                 const float2* __restrict__ tw, const float* __restrict__ dmag,
+                                                                 float* __restrict__ dy, int T, int F, int hop, int pad,
+                                                                 int reflect, float eps, int n_fft, int logn) {
+  extern __shared__ float2 smem[];
+  float2* buf = smem;
+  const int nbin = n_fft / 2 + 1;
+  const int b = blockIdx.y, f = blockIdx.x;
+  const float* yb = y + (size_t)b * T;
+  load_frame(buf, yb, window, f, hop, pad, T, reflect, n_fft, logn);
+  fft_passes(buf, tw, n_fft, logn);
+  // G_k = dmag_k * X_k / mag_k for the one-sided bins (<= 4096 / 2 / 256 + 1 = 9 per thread), then conj(G) back into the
+  // buffer in bit-reversed order, zeros above the Nyquist bin
+  float2 g[9];
+  const float* db = dmag + (size_t)b * nbin * F + f;
+  for (int r = 0; r < 9; ++r) {
+    const int k = threadIdx.x + GT * r;
+    g[r] = make_float2(0.f, 0.f);
+    if (k < nbin) {
+      const float2 x = buf[k];
+      const float sc = db[(size_t)k * F] / sqrtf(x.x * x.x + x.y * x.y + eps);
+      g[r] = make_float2(x.x * sc, -x.y * sc);
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < n_fft; n += GT) buf[n] = make_float2(0.f, 0.f);
+  __syncthreads();
+  for (int r = 0; r < 9; ++r) {
+    const int k = threadIdx.x + GT * r;
+    if (k < nbin) buf[__brev((unsigned)k) >> (32 - logn)] = g[r];
+  }
+  fft_passes(buf, tw, n_fft, logn);
+  float* dyb = dy + (size_t)b * T;
+  for (int n = threadIdx.x; n < n_fft; n += GT) {
+    const int o = sample_index(f * hop + n - pad, T, reflect);
+    if (o >= 0) unsafeAtomicAdd(dyb + o, buf[n].x * window[n]);
+  }
+}
+
+}  // namespace
+
+// called by vcv_stft_mag_fwd / vcv_stft_mag_bwd (stft.hip) for n_fft != 2048
+int stft_mag_fwd_generic_launch(const float* y, const float* window, const float* twiddle, float* mag, int B, int T, int n_fft, int hop,
+                             int pad, int reflect, float eps, hipStream_t st) {
+  if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1))) return VCV_EINVAL;
+  const int F = (T + 2 * pad - n_fft) / hop + 1;
+  if (F <= 0) return VCV_EINVAL;
+  const int logn = 31 - __builtin_clz((unsigned)n_fft);
+  const size_t lds = sizeof(float2) * (size_t)n_fft + sizeof(float) * (size_t)(n_fft / 2 + 1) * FR;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)stft_mag_fwd_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  hipLaunchKernelGGL(stft_mag_fwd_generic_kernel, dim3(vcv_cdiv(F, FR), B), dim3(GT), lds, st, y, window, (const float2*)twiddle, mag,
+                     T, F, hop, pad, reflect, eps, n_fft, logn);
+  return vcv_check_launch();
+}
+
+int stft_mag_bwd_generic_launch(const float* y, const float* window, const float* twiddle, const float* dmag, float* dy, int B, int T,
+                             int n_fft, int hop, int pad, int reflect, float eps, hipStream_t st) {
+  if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1))) return VCV_EINVAL;
+  const int F = (T + 2 * pad - n_fft) / hop + 1;
+  if (F <= 0) return VCV_EINVAL;
+  const int logn = 31 - __builtin_clz((unsigned)n_fft);
+  if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * T, st) != hipSuccess) return VCV_EHIP;
+  hipLaunchKernelGGL(stft_mag_bwd_generic_kernel, dim3(F, B), dim3(GT), sizeof(float2) * (size_t)n_fft, st, y, window,
+                     (const float2*)twiddle, dmag, dy, T, F, hop, pad, reflect, eps, n_fft, logn);
+  return vcv_check_launch();
+}

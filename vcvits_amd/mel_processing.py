@@ -69,12 +69,10 @@ def _mel_matrix(n_fft, num_mels, sampling_rate, fmin, fmax, dtype, device):
 
 
 def _spec(y, n_fft, hop_size, win_size, reflect):
-    if win_size != n_fft:
-        raise NotImplementedError("win_length == n_fft in both reference configs")
     _range_warn(y)
     lead = y.shape[:-1]
     y2 = y.reshape(-1, y.shape[-1])
-    mag = ops.stft_mag(y2, n_fft, hop_size, int((n_fft - hop_size) / 2), reflect, 1e-6)
+    mag = ops.stft_mag(y2, n_fft, hop_size, int((n_fft - hop_size) / 2), reflect, 1e-6, win_length=win_size)
     return mag.reshape(lead + mag.shape[-2:])
 
 
