@@ -491,7 +491,8 @@ int vcv_prof_dump(const char* path);
 /* ---- source-audio front end (vits/model/pipeline.py:24-28,59-70):
  * complex STFT (torchaudio Spectrogram(power=None, pad, center=False)) and inverse STFT
  * (torchaudio InverseSpectrogram = torch.istft, Hann window, center=True trims n_fft/2 per side).
- * spec: complex64 [B, 1025, F] interleaved (re, im); ola: workspace [B, 2048 + hop*(F-1)] ---- */
+ * n_fft = 2048 (tuned kernels) or any power of two in [64, 4096]; window / twiddle tables as for vcv_stft_mag_fwd.
+ * spec: complex64 [B, n_fft/2+1, F] interleaved (re, im); ola: workspace [B, n_fft + hop*(F-1)] ---- */
 int vcv_stft_complex_fwd(const float* y, const float* window, const float* twiddle, float* out, int B, int T,
                          int n_fft, int hop, int pad, int reflect, void* stream);
 int vcv_istft(const float* spec, const float* window, const float* twiddle, float* ola, float* out, int B, int F,

@@ -4,7 +4,7 @@ reference's spectrogram_torch (tools/make_goldens_stft_sizes.py).
 
 CPU: the oracle against those vectors.  GPU (-m gpu): mel_processing on the HIP kernels against them (n_fft = 2048 on the
 tuned kernels with a shorter window or another hop, every other size on the generic radix-2 kernels), the zero-pad variant
-and the input gradient against the oracle, the source-audio pipeline with win_length < n_fft."""
+and the input gradient against the oracle, the source-audio pipeline (complex STFT -> inverse STFT) at the same sizes."""
 import numpy as np
 import pytest
 import torch
@@ -80,12 +80,25 @@ def test_unsupported_sizes_fail_loudly(gpu):
 
 
 @pytest.mark.gpu
-def test_pipeline_with_shorter_window(gpu):
+def test_pipeline_at_other_sizes(gpu):
+    """vits/model/pipeline.py:11-70 (its own constructor defaults are n_fft 1024 / win 1024 / hop 256): complex STFT ->
+    inverse STFT at the tuned size with a shorter window, and at other sizes on the generic kernels."""
+    from vcvits_amd import ops
     from vcvits_amd.model.pipeline import SpeechConversionAudioPipeline
     rng = np.random.default_rng(9)
     wav = torch.from_numpy((rng.standard_normal((2, 1, 16000)) * 0.2).astype(np.float32))
-    for win in (2048, 1600, 1024):
-        pipe = SpeechConversionAudioPipeline(sr=16000, n_fft=2048, n_mel=128, win_length=win, hop_length=512)
+    for n_fft, hop, win in ((2048, 512, 2048), (2048, 512, 1600), (2048, 512, 1024), (1024, 256, 1024), (512, 128, 400),
+                            (4096, 1024, 4096), (256, 64, 256)):
+        pipe = SpeechConversionAudioPipeline(sr=16000, n_fft=n_fft, n_mel=128, win_length=win, hop_length=hop)
         out = pipe(wav.to(gpu))
-        ref = O.audio_pipeline(wav, n_fft=2048, hop_length=512, win_length=win)
-        close("pipeline win %d" % win, out, ref, tol=1e-5, atol=2e-6)
+        ref = O.audio_pipeline(wav, n_fft=n_fft, hop_length=hop, win_length=win)
+        close("pipeline %d/%d/%d" % (n_fft, hop, win), out, ref, tol=1e-5, atol=2e-6)
+        # the complex spectrum itself (torch.stft on the zero-padded signal)
+        pad = (n_fft - hop) // 2
+        spec = ops.stft_complex(wav[:, 0].to(gpu), n_fft, hop, pad, reflect=False, win_length=win)
+        yp = torch.nn.functional.pad(wav[:, 0], (pad, pad))
+        sref = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False,
+                          return_complex=True)
+        close("stft %d/%d/%d" % (n_fft, hop, win), torch.view_as_real(spec), torch.view_as_real(sref), tol=1e-5)
+    default = SpeechConversionAudioPipeline()  # the reference's own defaults construct and run
+    assert default(wav.to(gpu)).shape == wav.shape

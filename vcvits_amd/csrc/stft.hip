@@ -658,7 +658,7 @@ istft_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ wind
 
 // stage 2: divide by the window envelope sum_f w^2[i - f*hop] and trim `trim` samples on the left (center=True)
 __global__ void istft_norm_kernel(const float* __restrict__ ola, const float* __restrict__ window,
-                                  float* __restrict__ out, int F, int hop, int L, int trim, int Tout, size_t n) {
+                                  float* __restrict__ out, int F, int hop, int L, int trim, int Tout, size_t n, int n_fft) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   const int t = (int)(idx % Tout);
@@ -667,7 +667,7 @@ __global__ void istft_norm_kernel(const float* __restrict__ ola, const float* __
   float env = 0.f;
   int f_hi = i / hop;
   if (f_hi > F - 1) f_hi = F - 1;
-  for (int f = f_hi; f >= 0 && i - f * hop < N; --f) {
+  for (int f = f_hi; f >= 0 && i - f * hop < n_fft; --f) {
     const float w = window[i - f * hop];
     env += w * w;
   }
@@ -676,10 +676,16 @@ __global__ void istft_norm_kernel(const float* __restrict__ ola, const float* __
 
 }  // namespace
 
+int stft_complex_fwd_generic_launch(const float* y, const float* window, const float* twiddle, float* out, int B, int T, int n_fft,
+                                    int hop, int pad, int reflect, hipStream_t st);
+int istft_ola_generic_launch(const float* spec, const float* window, const float* twiddle, float* ola, int B, int F, int n_fft,
+                             int hop, int L, hipStream_t st);
+
 extern "C" int vcv_stft_complex_fwd(const float* y, const float* window, const float* twiddle, float* out, int B,
                                     int T, int n_fft, int hop, int pad, int reflect, void* stream) {
-  if (!y || !window || !twiddle || !out || B <= 0 || T <= 0 || n_fft != N || hop <= 0 || pad < 0) return VCV_EINVAL;
+  if (!y || !window || !twiddle || !out || B <= 0 || T <= 0 || hop <= 0 || pad < 0) return VCV_EINVAL;
   if (reflect && pad > T - 1) return VCV_EINVAL;
+  if (n_fft != N) return stft_complex_fwd_generic_launch(y, window, twiddle, out, B, T, n_fft, hop, pad, reflect, (hipStream_t)stream);
   const int F = (T + 2 * pad - n_fft) / hop + 1;
   if (F <= 0) return VCV_EINVAL;
   hipLaunchKernelGGL(stft_complex_fwd_kernel, dim3(F, B), dim3(NT), 0, (hipStream_t)stream, y, window,
@@ -691,18 +697,24 @@ extern "C" int vcv_stft_complex_fwd(const float* y, const float* window, const f
 // Tout = hop*(F-1) when center (n_fft/2 trimmed on both sides), else the full overlap-add length
 extern "C" int vcv_istft(const float* spec, const float* window, const float* twiddle, float* ola, float* out,
                          int B, int F, int n_fft, int hop, int center, void* stream) {
-  if (!spec || !window || !twiddle || !ola || !out || B <= 0 || F <= 0 || n_fft != N || hop <= 0) return VCV_EINVAL;
+  if (!spec || !window || !twiddle || !ola || !out || B <= 0 || F <= 0 || hop <= 0) return VCV_EINVAL;
+  if (n_fft != N && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int L = n_fft + hop * (F - 1);
   const int trim = center ? n_fft / 2 : 0;
   const int Tout = center ? hop * (F - 1) : L;
   if (Tout <= 0) return VCV_EINVAL;
   if (hipMemsetAsync(ola, 0, sizeof(float) * (size_t)B * L, st) != hipSuccess) return VCV_EHIP;
-  hipLaunchKernelGGL(istft_ola_kernel, dim3(F, B), dim3(NT), 0, st, (const float2*)spec, window,
-                     (const float2*)twiddle, ola, F, hop, L);
+  if (n_fft == N) {
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(F, B), dim3(NT), 0, st, (const float2*)spec, window,
+                       (const float2*)twiddle, ola, F, hop, L);
+  } else {
+    const int rc = istft_ola_generic_launch(spec, window, twiddle, ola, B, F, n_fft, hop, L, st);
+    if (rc != VCV_OK) return rc;
+  }
   const size_t n = (size_t)B * Tout;
   hipLaunchKernelGGL(istft_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ola, window, out, F, hop,
-                     L, trim, Tout, n);
+                     L, trim, Tout, n, n_fft);
   return vcv_check_launch();
 }
 

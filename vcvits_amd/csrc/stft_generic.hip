@@ -1,4 +1,4 @@
-// stft_generic.hip -- magnitude STFT forward / backward for any power-of-two n_fft in [64, 4096] other than the 2048 the two
+// stft_generic.hip -- magnitude STFT forward / backward, complex STFT and inverse STFT for any power-of-two n_fft in [64, 4096] other than the 2048 the two
 // reference configs use (stft.hip holds the kernels tuned for that size).  Reference: vits/mel_processing.py:54-96
 // (spectrogram_torch / spectrogram_torch_audio take n_fft, hop_size, win_size as arguments; torch.stft pads a shorter window
 // to n_fft, centred -- the `window` table handed in is already that padded window).
@@ -117,7 +117,69 @@ __global__ void __launch_bounds__(GT) stft_mag_bwd_generic_kernel(const float* _
   }
 }
 
+// complex spectrum of one frame per workgroup: out [B, n_fft/2+1, F] complex (the source-audio pipeline's Spectrogram)
+__global__ void __launch_bounds__(GT) stft_complex_fwd_generic_kernel(const float* __restrict__ y, const float* __restrict__ window,
+                                                                     const float2* __restrict__ tw, float2* __restrict__ out,
+                                                                     int T, int F, int hop, int pad, int reflect, int n_fft,
+                                                                     int logn) {
+  extern __shared__ float2 smem[];
+  float2* buf = smem;
+  const int nbin = n_fft / 2 + 1;
+  const int b = blockIdx.y, f = blockIdx.x;
+  load_frame(buf, y + (size_t)b * T, window, f, hop, pad, T, reflect, n_fft, logn);
+  fft_passes(buf, tw, n_fft, logn);
+  float2* ob = out + (size_t)b * nbin * F + f;
+  for (int k = threadIdx.x; k < nbin; k += GT) ob[(size_t)k * F] = buf[k];
+}
+
+// inverse STFT, stage 1 (torch.istft): conjugate-symmetric extension of the one-sided frame (imaginary parts of DC / Nyquist
+// ignored), inverse transform = Re FFT(conj V) / n_fft, times the window, overlap-added into ola with fp32 atomics
+__global__ void __launch_bounds__(GT) istft_ola_generic_kernel(const float2* __restrict__ spec, const float* __restrict__ window,
+                                                              const float2* __restrict__ tw, float* __restrict__ ola, int F,
+                                                              int hop, int L, int n_fft, int logn) {
+  extern __shared__ float2 smem[];
+  float2* buf = smem;
+  const int nbin = n_fft / 2 + 1, half = n_fft / 2;
+  const int b = blockIdx.y, f = blockIdx.x;
+  const float2* sb = spec + (size_t)b * nbin * F + f;
+  for (int k = threadIdx.x; k < n_fft; k += GT) {
+    float2 v;
+    if (k <= half) {
+      v = sb[(size_t)k * F];
+      v.y = (k == 0 || k == half) ? 0.f : -v.y;  // conj(V_k)
+    } else {
+      v = sb[(size_t)(n_fft - k) * F];           // V_k = conj(V_{n-k}), so conj(V_k) = V_{n-k}
+    }
+    buf[__brev((unsigned)k) >> (32 - logn)] = v;
+  }
+  fft_passes(buf, tw, n_fft, logn);
+  float* ob = ola + (size_t)b * L + (size_t)f * hop;
+  const float inv = 1.f / (float)n_fft;
+  for (int n = threadIdx.x; n < n_fft; n += GT) unsafeAtomicAdd(ob + n, buf[n].x * inv * window[n]);
+}
+
 }  // namespace
+
+int stft_complex_fwd_generic_launch(const float* y, const float* window, const float* twiddle, float* out, int B, int T, int n_fft,
+                                    int hop, int pad, int reflect, hipStream_t st) {
+  if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1))) return VCV_EINVAL;
+  const int F = (T + 2 * pad - n_fft) / hop + 1;
+  if (F <= 0) return VCV_EINVAL;
+  const int logn = 31 - __builtin_clz((unsigned)n_fft);
+  hipLaunchKernelGGL(stft_complex_fwd_generic_kernel, dim3(F, B), dim3(GT), sizeof(float2) * (size_t)n_fft, st, y, window,
+                     (const float2*)twiddle, (float2*)out, T, F, hop, pad, reflect, n_fft, logn);
+  return vcv_check_launch();
+}
+
+// stage 1 of vcv_istft for n_fft != 2048 (ola zeroed by the caller; stage 2 = stft.hip's istft_norm_kernel)
+int istft_ola_generic_launch(const float* spec, const float* window, const float* twiddle, float* ola, int B, int F, int n_fft,
+                             int hop, int L, hipStream_t st) {
+  if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1))) return VCV_EINVAL;
+  const int logn = 31 - __builtin_clz((unsigned)n_fft);
+  hipLaunchKernelGGL(istft_ola_generic_kernel, dim3(F, B), dim3(GT), sizeof(float2) * (size_t)n_fft, st, (const float2*)spec, window,
+                     (const float2*)twiddle, ola, F, hop, L, n_fft, logn);
+  return vcv_check_launch();
+}
 
 // called by vcv_stft_mag_fwd / vcv_stft_mag_bwd (stft.hip) for n_fft != 2048
 int stft_mag_fwd_generic_launch(const float* y, const float* window, const float* twiddle, float* mag, int B, int T, int n_fft, int hop,

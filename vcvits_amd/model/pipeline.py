@@ -14,9 +14,8 @@ from .. import ops
 class SpeechConversionAudioPipeline(nn.Module):
     def __init__(self, sr=16000, n_fft=1024, n_mel=128, win_length=1024, hop_length=256):
         super().__init__()
-        # (the complex STFT / iSTFT kernels behind forward() are built for n_fft = 2048, both reference configs, with any
-        # win_length <= n_fft; another n_fft constructs -- a step fed precomputed features never runs this module -- and
-        # raises NotImplementedError from ops.stft_complex when called)
+        # (n_fft = 2048, both reference configs: the tuned kernels; any other power of two in [64, 4096]: the generic ones;
+        # win_length <= n_fft either way.  Anything else raises NotImplementedError from ops.stft_complex when called)
         self.source_sampling_rate = sr
         self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
         self.pad = int((n_fft - hop_length) / 2)

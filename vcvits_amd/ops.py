@@ -1516,13 +1516,17 @@ def _stft_consts(device, n_fft, win_length=None):
     return _stft_tables[key]
 
 
+def _check_n_fft(n_fft):
+    if n_fft != 2048 and (n_fft < 64 or n_fft > 4096 or n_fft & (n_fft - 1)):
+        raise NotImplementedError("STFT kernels: n_fft = a power of two in [64, 4096] (both reference configs: 2048)")
+
+
 class _StftMagFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, n_fft, hop, pad, reflect, eps, win_length=None):
         y = _f32c(y)
         B, T = y.shape
-        if n_fft != 2048 and (n_fft < 64 or n_fft > 4096 or n_fft & (n_fft - 1)):
-            raise NotImplementedError("STFT kernels: n_fft = a power of two in [64, 4096] (both reference configs: 2048)")
+        _check_n_fft(n_fft)
         win, tw = _stft_consts(y.device, n_fft, win_length)
         F_ = (T + 2 * pad - n_fft) // hop + 1
         mag = torch.empty((B, n_fft // 2 + 1, F_), device=y.device, dtype=torch.float32)
@@ -1557,8 +1561,7 @@ def stft_complex(y, n_fft=2048, hop=512, pad=768, reflect=False, win_length=None
     source pipeline under inference_mode, vcvits.py:61-62)."""
     y = _f32c(y.detach())
     B, T = y.shape
-    if n_fft != 2048:
-        raise NotImplementedError("complex STFT / iSTFT kernels: n_fft = 2048 (the source-audio pipeline of both reference configs)")
+    _check_n_fft(n_fft)
     win, tw = _stft_consts(y.device, n_fft, win_length)
     F_ = (T + 2 * pad - n_fft) // hop + 1
     out = torch.empty((B, n_fft // 2 + 1, F_, 2), device=y.device, dtype=torch.float32)
@@ -1571,8 +1574,7 @@ def istft(spec, n_fft=2048, hop=512, center=True, win_length=None):
     """Inverse STFT of complex64 [B, n_fft/2+1, F] -> [B, hop*(F-1)] (torch.istft, Hann window of win_length <= n_fft)."""
     s = torch.view_as_real(spec.detach()).contiguous()
     B, _, F_, _ = s.shape
-    if n_fft != 2048:
-        raise NotImplementedError("complex STFT / iSTFT kernels: n_fft = 2048 (the source-audio pipeline of both reference configs)")
+    _check_n_fft(n_fft)
     win, tw = _stft_consts(s.device, n_fft, win_length)
     L = n_fft + hop * (F_ - 1)
     ola = torch.empty((B, L), device=s.device, dtype=torch.float32)
