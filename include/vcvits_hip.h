@@ -360,7 +360,8 @@ int vcv_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
               float eps, float wd, int step, void* stream);
 
 /* ---- STFT magnitude sqrt(re^2+im^2+eps) (mel_processing.py:54-96): n_fft = 2048 (both reference configs; the tuned
- * kernels) or any other power of two in [64, 4096] (generic radix-2 kernels, stft_generic.hip).
+ * kernels), any other power of two in [64, 4096] (generic radix-2 kernels) or any other even size in [16, 4096] (direct DFT;
+ * stft_generic.hip).
  * y: [B, T]; window: [n_fft] -- the analysis window already zero-padded (centred) to n_fft when win_length < n_fft, as
  * torch.stft does; twiddle: [n_fft/2] complex (cos, -sin)(2*pi*k/n_fft) interleaved;
  * mag/dmag: [B, n_fft/2+1, F], F = (T + 2*pad - n_fft)/hop + 1; reflect: 0 zero pad (torchaudio
@@ -491,7 +492,7 @@ int vcv_prof_dump(const char* path);
 /* ---- source-audio front end (vits/model/pipeline.py:24-28,59-70):
  * complex STFT (torchaudio Spectrogram(power=None, pad, center=False)) and inverse STFT
  * (torchaudio InverseSpectrogram = torch.istft, Hann window, center=True trims n_fft/2 per side).
- * n_fft = 2048 (tuned kernels) or any power of two in [64, 4096]; window / twiddle tables as for vcv_stft_mag_fwd.
+ * n_fft = 2048 (tuned kernels) or any even size in [16, 4096]; window / twiddle tables as for vcv_stft_mag_fwd.
  * spec: complex64 [B, n_fft/2+1, F] interleaved (re, im); ola: workspace [B, n_fft + hop*(F-1)] ---- */
 int vcv_stft_complex_fwd(const float* y, const float* window, const float* twiddle, float* out, int B, int T,
                          int n_fft, int hop, int pad, int reflect, void* stream);

@@ -3,7 +3,8 @@ win_size as arguments; torch.stft pads a shorter window to n_fft).  Vectors: tes
 reference's spectrogram_torch (tools/make_goldens_stft_sizes.py).
 
 CPU: the oracle against those vectors.  GPU (-m gpu): mel_processing on the HIP kernels against them (n_fft = 2048 on the
-tuned kernels with a shorter window or another hop, every other size on the generic radix-2 kernels), the zero-pad variant
+tuned kernels with a shorter window or another hop, other powers of two on the generic radix-2 kernels, other even sizes
+on the direct DFT), the zero-pad variant
 and the input gradient against the oracle, the source-audio pipeline (complex STFT -> inverse STFT) at the same sizes."""
 import numpy as np
 import pytest
@@ -50,7 +51,7 @@ def test_gradients_and_zero_pad_at_other_sizes(gpu, reflect):
     rng = np.random.default_rng(3)
     fn = mel_processing.spectrogram_torch if reflect else mel_processing.spectrogram_torch_audio
     for n_fft, hop, win, T in ((1024, 256, 1024, 4096), (512, 128, 400, 3000), (4096, 1024, 4096, 9000), (2048, 512, 1200, 6000),
-                               (128, 32, 128, 777)):
+                               (128, 32, 128, 777), (1280, 320, 1280, 5000), (400, 160, 320, 2000), (3000, 750, 3000, 8000)):
         y = torch.from_numpy((rng.standard_normal((3, T)) * 0.3).astype(np.float32))
         yc = y.clone().requires_grad_(True)
         ref = O.spectrogram(yc, n_fft, hop, win, reflect=reflect)
@@ -74,7 +75,9 @@ def test_unsupported_sizes_fail_loudly(gpu):
     from vcvits_amd import mel_processing
     y = torch.zeros(1, 4000, device=gpu)
     with pytest.raises(NotImplementedError):
-        mel_processing.spectrogram_torch(y, 1000, 22050, 250, 1000)  # not a power of two
+        mel_processing.spectrogram_torch(y, 1001, 22050, 250, 1001)  # odd
+    with pytest.raises(NotImplementedError):
+        mel_processing.spectrogram_torch(y, 8192, 22050, 2048, 8192)  # beyond 4096
     with pytest.raises(ValueError):
         mel_processing.spectrogram_torch(y, 1024, 22050, 256, 2048)  # win_length > n_fft (torch.stft refuses it too)
 
@@ -88,7 +91,7 @@ def test_pipeline_at_other_sizes(gpu):
     rng = np.random.default_rng(9)
     wav = torch.from_numpy((rng.standard_normal((2, 1, 16000)) * 0.2).astype(np.float32))
     for n_fft, hop, win in ((2048, 512, 2048), (2048, 512, 1600), (2048, 512, 1024), (1024, 256, 1024), (512, 128, 400),
-                            (4096, 1024, 4096), (256, 64, 256)):
+                            (4096, 1024, 4096), (256, 64, 256), (1280, 320, 1280), (400, 100, 400), (3000, 750, 2400)):
         pipe = SpeechConversionAudioPipeline(sr=16000, n_fft=n_fft, n_mel=128, win_length=win, hop_length=hop)
         out = pipe(wav.to(gpu))
         ref = O.audio_pipeline(wav, n_fft=n_fft, hop_length=hop, win_length=win)

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from make_goldens import O, close, rmel, rng_tensor, save  # noqa: E402
 
 SIZES = [(1024, 256, 1024), (512, 128, 512), (4096, 1024, 4096), (256, 64, 200), (1024, 256, 800), (2048, 512, 1200),
-         (2048, 300, 2048), (64, 16, 64)]
+         (2048, 300, 2048), (64, 16, 64), (1280, 320, 1280), (400, 160, 400), (48, 12, 48)]
 
 
 def main():

@@ -698,7 +698,7 @@ extern "C" int vcv_stft_complex_fwd(const float* y, const float* window, const f
 extern "C" int vcv_istft(const float* spec, const float* window, const float* twiddle, float* ola, float* out,
                          int B, int F, int n_fft, int hop, int center, void* stream) {
   if (!spec || !window || !twiddle || !ola || !out || B <= 0 || F <= 0 || hop <= 0) return VCV_EINVAL;
-  if (n_fft != N && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return VCV_EINVAL;
+  if (n_fft != N && (n_fft < 16 || n_fft > 4096 || (n_fft & 1))) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int L = n_fft + hop * (F - 1);
   const int trim = center ? n_fft / 2 : 0;

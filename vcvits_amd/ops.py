@@ -1517,8 +1517,8 @@ def _stft_consts(device, n_fft, win_length=None):
 
 
 def _check_n_fft(n_fft):
-    if n_fft != 2048 and (n_fft < 64 or n_fft > 4096 or n_fft & (n_fft - 1)):
-        raise NotImplementedError("STFT kernels: n_fft = a power of two in [64, 4096] (both reference configs: 2048)")
+    if n_fft < 16 or n_fft > 4096 or n_fft & 1:
+        raise NotImplementedError("STFT kernels: even n_fft in [16, 4096] (both reference configs: 2048)")
 
 
 class _StftMagFn(torch.autograd.Function):
@@ -1552,7 +1552,7 @@ class _StftMagFn(torch.autograd.Function):
 def stft_mag(y, n_fft=2048, hop=512, pad=768, reflect=False, eps=1e-6, win_length=None):
     """sqrt(|STFT|^2 + eps) of y [B, T] -> [B, n_fft/2+1, frames] (Hann window of win_length <= n_fft, center=False).
     n_fft = 2048 runs the kernels tuned for the reference configs; any other power of two in [64, 4096] the generic
-    radix-2 kernels (stft_generic.hip)."""
+    radix-2 kernels, any other even size in [16, 4096] a direct DFT (stft_generic.hip)."""
     return _StftMagFn.apply(y, n_fft, hop, pad, reflect, eps, win_length)
 
 
