@@ -323,6 +323,10 @@ int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C, int K, vo
 /* out = dy * act'(y) for tf in {DLEAKY, DRELU, DTANH, DLOGCLAMP}: one pass that the data-, weight- and
  * bias-gradient kernels of a fused conv+activation then share */
 int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream);
+/* out = (dy + add) * act'(y); add may be NULL (= vcv_act_grad).  `add`: a second gradient of the same tensor -- the
+ * feature-matching loss's gradient of a recorded discriminator feature map (vcvits.py:119 loss_fm over fmaps of
+ * discriminator.py:38-45) -- summed in this pass instead of in one of its own */
+int vcv_act_grad_add(const float* dy, const float* add, const float* y, float* out, int tf, float slope, int64_t n, void* stream);
 /* the same pass over [B, C, T] tensors that also collects the bias gradient: dbias[c] += sum_{b, t} out[b, c, t] */
 int vcv_act_grad_bias(const float* dy, const float* y, float* out, float* dbias, int B, int C, int T, int tf, float slope,
                       void* stream);

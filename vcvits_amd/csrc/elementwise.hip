@@ -3,6 +3,7 @@
 // All are streaming kernels: coalesced reads of [B, C, T] rows, one pass, wavefront (64-lane)
 // shuffles for the reductions.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -128,6 +129,30 @@ __global__ void act_grad_kernel(const float* __restrict__ dy, const float* __res
                                 int tf, float slope, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = vcv_tf(dy[i], tf, y, i, slope);
+}
+
+// the same with 16-byte accesses and an optional second gradient added first: out = (dy + add) * act'(y).  `add` is the
+// gradient a recorded feature map received from the feature-matching loss (ops._TapFn): summed here instead of in a pass of
+// its own over the pass-through gradient
+template <bool ADD>
+__global__ void act_grad4_kernel(const float4* __restrict__ dy, const float4* __restrict__ add, const float4* __restrict__ y,
+                                 float4* __restrict__ out, int tf, float slope, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 d = dy[i];
+  const float4 a = y[i];
+  if (ADD) {
+    const float4 e = add[i];
+    d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+  }
+  out[i] = make_float4(vcv_tf_val(d.x, tf, a.x, slope), vcv_tf_val(d.y, tf, a.y, slope), vcv_tf_val(d.z, tf, a.z, slope),
+                       vcv_tf_val(d.w, tf, a.w, slope));
+}
+
+__global__ void act_grad_add_kernel(const float* __restrict__ dy, const float* __restrict__ add, const float* __restrict__ y,
+                                    float* __restrict__ out, int tf, float slope, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vcv_tf_val(dy[i] + add[i], tf, y[i], slope);
 }
 
 // act_grad over [B, C, T] rows that also collects db[c] += sum_{b, t} out[b, c, t]: work units are 1024-float pieces of
@@ -394,10 +419,29 @@ extern "C" int vcv_weight_flip_transpose(const float* w, float* wt, int M, int C
   return vcv_check_launch();
 }
 
-extern "C" int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream) {
+extern "C" int vcv_act_grad_add(const float* dy, const float* add, const float* y, float* out, int tf, float slope, int64_t n,
+                                void* stream) {
   if (!dy || !y || !out || n <= 0 || tf < VCV_TF_DLEAKY) return VCV_EINVAL;
-  hipLaunchKernelGGL(act_grad_kernel, grid1d(n), dim3(256), 0, ST, dy, y, out, tf, slope, (size_t)n);
+  const bool vec = (n & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out | (uintptr_t)add) & 15) == 0;
+  static const bool scalar_only = getenv("VCVITS_ACT_GRAD_SCALAR") != nullptr;  // (A/B switch)
+  if (vec && !scalar_only) {
+    const size_t n4 = (size_t)n / 4;
+    if (add)
+      hipLaunchKernelGGL(act_grad4_kernel<true>, grid1d(n4), dim3(256), 0, ST, (const float4*)dy, (const float4*)add, (const float4*)y,
+                         (float4*)out, tf, slope, n4);
+    else
+      hipLaunchKernelGGL(act_grad4_kernel<false>, grid1d(n4), dim3(256), 0, ST, (const float4*)dy, (const float4*)nullptr,
+                         (const float4*)y, (float4*)out, tf, slope, n4);
+  } else if (add) {
+    hipLaunchKernelGGL(act_grad_add_kernel, grid1d(n), dim3(256), 0, ST, dy, add, y, out, tf, slope, (size_t)n);
+  } else {
+    hipLaunchKernelGGL(act_grad_kernel, grid1d(n), dim3(256), 0, ST, dy, y, out, tf, slope, (size_t)n);
+  }
   return vcv_check_launch();
+}
+
+extern "C" int vcv_act_grad(const float* dy, const float* y, float* out, int tf, float slope, int64_t n, void* stream) {
+  return vcv_act_grad_add(dy, nullptr, y, out, tf, slope, n, stream);
 }
 
 extern "C" int vcv_act_grad_bias(const float* dy, const float* y, float* out, float* dbias, int B, int C, int T, int tf,

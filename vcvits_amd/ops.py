@@ -708,24 +708,35 @@ class _TapFn(torch.autograd.Function):
     grad_batch_start promises its consumers."""
 
     @staticmethod
-    def forward(ctx, x, b0):
+    def forward(ctx, x, b0, producer=None):
         ctx.b0 = b0
+        ctx.producer = producer  # the conv node that made x, when its backward can take the trailing gradient itself
         return x.view(x.shape), x[b0:]
 
     @staticmethod
     def backward(ctx, g_pass, g_tail):
         b0 = ctx.b0
         if g_pass is None and g_tail is None:
-            return None, None
+            return None, None, None
         if g_pass is None:
             g_pass = torch.empty((b0 + g_tail.shape[0],) + tuple(g_tail.shape[1:]), device=g_tail.device, dtype=g_tail.dtype)
             g_pass[b0:].copy_(g_tail)
-            return g_pass, None
+            return g_pass, None, None
         if g_tail is not None:
+            prod = ctx.producer
+            if (_TAP_FUSE[0] and prod is not None and prod.tap_add is None and g_tail.dtype == torch.float32
+                    and g_tail.is_contiguous() and g_pass.dtype == torch.float32):
+                # x's producer is the next node of this backward pass: its activation-derivative pass reads g_pass anyway
+                # and sums g_tail into it there (vcv_act_grad_add) -- no read-modify-write pass over g_pass here
+                prod.tap_add = (g_tail, b0)
+                return g_pass, None, None
             if not g_pass.is_contiguous():
                 g_pass = g_pass.contiguous()
             g_pass[b0:].add_(g_tail)
-        return g_pass, None
+        return g_pass, None, None
+
+
+_TAP_FUSE = [__import__("os").environ.get("VCVITS_TAP_FUSE", "1") == "1"]  # (A/B switch)
 
 
 def fmap_tap(x):
@@ -734,7 +745,9 @@ def fmap_tap(x):
     node with the pass-through; otherwise it is x itself."""
     b0 = _GRAD_B0[0]
     if b0 > 0 and x.requires_grad and torch.is_grad_enabled() and b0 < x.shape[0]:
-        xp, tail = _TapFn.apply(x, b0)
+        fn = x.grad_fn
+        producer = fn if (fn is not None and getattr(fn, "tap_ok", False)) else None
+        xp, tail = _TapFn.apply(x, b0, producer)
         return xp, FmapTap(x.detach()[:b0], tail)
     return x, x
 
@@ -785,6 +798,10 @@ class _ConvFn(torch.autograd.Function):
         ctx.w_sink, ctx.b_sink = _sink(w), _sink(bias)
         ctx.w_tmp = w.requires_grad and not w.is_leaf  # its gradient is an intermediate of this backward pass
         ctx.b0 = _GRAD_B0[0] if not (w.requires_grad or (bias is not None and bias.requires_grad)) else 0
+        # (fmap_tap) this node's backward starts with a plain activation-derivative pass over its output gradient: a second
+        # gradient of the output (the feature-matching loss's) can be summed inside that pass -- _TapFn leaves it in tap_add
+        ctx.tap_ok = out_act != ACT_NONE and not (bias is not None and bias.requires_grad and not ctx.bt)
+        ctx.tap_add = None
         ctx.save_for_backward(x, w, y if out_act != ACT_NONE else None)
         return y
 
@@ -799,6 +816,9 @@ class _ConvFn(torch.autograd.Function):
         if ctx.link is not None and ctx.link[1] == "dst":
             link_dres, ctx.link[0].dres = ctx.link[0].dres, None
         dtf = _ACT_TO_DTF[out_act]
+        if ctx.tap_add is not None and (dtf == TF_NONE or (ctx.has_bias and ctx.needs_input_grad[2] and not ctx.bt)):
+            tap, ctx.tap_add = ctx.tap_add, None  # (not the plain activation-derivative branch after all: add it here)
+            dy[tap[1]:].add_(tap[0])
         dx = dw = db = dres = None
         db_done = None  # the bias gradient, once some launch has produced it
         w3 = w.view(w.shape[0], w.shape[1], w.shape[2])
@@ -814,8 +834,15 @@ class _ConvFn(torch.autograd.Function):
                                               dy.numel() // (dy.shape[0] * dy.shape[1]), dtf, slope, stream()),
                       "vcv_act_grad_bias")
             else:
-                check(lib().vcv_act_grad(ptr(dy[b0:]), ptr(y[b0:]), ptr(dye[b0:]), dtf, slope, dy[b0:].numel(), stream()),
-                      "vcv_act_grad")
+                tap, ctx.tap_add = ctx.tap_add, None
+                tb0 = tap[1] if tap is not None else dy.shape[0]
+                if b0 < tb0:
+                    check(lib().vcv_act_grad(ptr(dy[b0:tb0]), ptr(y[b0:tb0]), ptr(dye[b0:tb0]), dtf, slope, dy[b0:tb0].numel(),
+                                             stream()), "vcv_act_grad")
+                if tap is not None:  # (the recorded half's second gradient, summed in the same pass)
+                    lo = max(b0, tb0)
+                    check(lib().vcv_act_grad_add(ptr(dy[lo:]), ptr(tap[0][lo - tb0:]), ptr(y[lo:]), ptr(dye[lo:]), dtf, slope,
+                                                 dy[lo:].numel(), stream()), "vcv_act_grad_add")
             dy, y, dtf = dye, None, TF_NONE
         if ctx.bt:
             # x was saved in the folded layout; fold dy the same way, unfold dx
