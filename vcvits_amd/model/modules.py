@@ -7,6 +7,7 @@ from .. import ops
 from .._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH
 
 LRELU_SLOPE = 0.1  # vits/model/modules.py:16
+_WN_LINK = __import__("os").environ.get("VCVITS_WN_LINK", "1") == "1"  # (A/B switch: WN residual-gradient hand-off)
 
 
 def _default_conv_init(weight, bias):
@@ -209,12 +210,14 @@ class WN(nn.Module):
         output = None
         H = self.hidden_channels
         for i in range(self.n_layers):
-            x_in = self.in_layers[i](x)
+            # x feeds this layer's conv and its residual add: the two gradients are summed in the conv's data-gradient launch
+            link = ops.ResGradLink() if (_WN_LINK and i < self.n_layers - 1 and x.requires_grad and torch.is_grad_enabled()) else None
+            x_in = self.in_layers[i](x, link=(link, "dst") if link else None)
             acts = ops.wn_gate(x_in, g, i * 2 * H)
             acts = ops.dropout(acts, self.p_dropout, self.training)
             rs = self.res_skip_layers[i](acts)
             if i < self.n_layers - 1:
-                x, output = ops.wn_res_skip(x, output, rs, mask2, False)
+                x, output = ops.wn_res_skip(x, output, rs, mask2, False, link=link)
             else:
                 output = ops.wn_res_skip(x, output, rs, mask2, True)
         return ops.mask_mul(output, mask2)

@@ -1699,7 +1699,8 @@ def wn_gate(xin, g, goff):
 
 class _WnResSkipFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, out, rs, mask, last):
+    def forward(ctx, x, out, rs, mask, last, link=None):
+        ctx.link = link
         x, out, rs, mask = _f32c(x), _f32c(out), _f32c(rs), _f32c(mask)
         B, H, T = x.shape
         on = torch.empty_like(x)
@@ -1717,7 +1718,7 @@ class _WnResSkipFn(torch.autograd.Function):
         (mask,) = ctx.saved_tensors
         if ctx.last:
             don = _f32c(grads[0])
-            return None, (don if ctx.has_out else None), don, None, None
+            return None, (don if ctx.has_out else None), don, None, None, None
         dxn, don = _f32c(grads[0]), _f32c(grads[1])
         ref = dxn if dxn is not None else don
         B, H, T = ref.shape
@@ -1725,12 +1726,19 @@ class _WnResSkipFn(torch.autograd.Function):
         dx = torch.empty_like(ref)
         check(lib().vcv_wn_res_skip_bwd(ptr(dxn), ptr(don), ptr(mask), ptr(drs), ptr(dx), B, H, T, stream()),
               "vcv_wn_res_skip_bwd")
-        return dx, (don if ctx.has_out else None), drs, None, None
+        if ctx.link is not None:
+            # x's other consumer is this layer's dilated conv, whose backward runs later in this pass (it is upstream of
+            # `rs`): its data-gradient launch adds dx in its epilogue (ResGradLink), autograd sees one gradient for x
+            if ctx.link.dres is not None:
+                raise RuntimeError("ResGradLink: a residual gradient of an earlier backward pass was never consumed")
+            ctx.link.dres, dx = dx, None
+        return dx, (don if ctx.has_out else None), drs, None, None, None
 
 
-def wn_res_skip(x, out, rs, mask, last):
-    """(x_new, out_new) for a middle layer, out_new for the last one (modules.py:168-174)."""
-    return _WnResSkipFn.apply(x, out, rs, mask, last)
+def wn_res_skip(x, out, rs, mask, last, link=None):
+    """(x_new, out_new) for a middle layer, out_new for the last one (modules.py:168-174).  link: a ResGradLink shared
+    with the conv1d call that also consumes x (link=(obj, "dst")): x's residual-path gradient is handed to that conv."""
+    return _WnResSkipFn.apply(x, out, rs, mask, last, link)
 
 
 class _SplitSampleFn(torch.autograd.Function):
