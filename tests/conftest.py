@@ -20,3 +20,19 @@ def gpu():
     from vcvits_amd import _lib
     _lib.lib()  # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _quiesce_gpu_between_tests(request):
+    """GPU tests build and drop modules, optimizers and captured HIP graphs by the hundred in one process: let every test's
+    device work finish and its objects (graphs and their memory pools included) be collected at a point where nothing is
+    in flight, instead of whenever the garbage collector gets to them under a later test's launches."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()

@@ -2,11 +2,33 @@
 reference runs that pass eagerly under torch.no_grad(): vits/light/vcvits.py:119,153).  The replayed pass must be the
 eager pass: same losses step for step from identical state; fresh dropout masks on every replay."""
 import copy
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# The whole-step graphs (graphed.GraphedStep) are EXPERIMENTAL and off by default: DESIGN.md section 5(iv) records an
+# unresolved race (a GPU memory fault when replays and eager passes interleave at full width).  Their tests therefore run
+# in a child pytest process -- a fault there must not take the session (and every test after it) down; the parent test
+# fails with the child's output instead.
+IN_CHILD = os.environ.get("VCVITS_STEP_GRAPH_TESTS_CHILD") == "1"
+step_graph = pytest.mark.skipif(not IN_CHILD, reason="runs inside test_step_graph_tests_in_child_process")
+
+
+def test_step_graph_tests_in_child_process(gpu):
+    if IN_CHILD:
+        pytest.skip("this is the child")
+    env = dict(os.environ, VCVITS_STEP_GRAPH_TESTS_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "graphed_step or captured_backward"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    assert "4 passed" in out, out[-1500:]
 
 
 def _cfg(p_dropout):
@@ -103,6 +125,7 @@ def test_graph_replays_draw_fresh_dropout_masks(gpu):
             assert not torch.equal(outs[i][0], outs[j][0]) and not torch.equal(outs[i][1], outs[j][1]), (i, j)
 
 
+@step_graph
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_graphed_step_equals_eager(gpu, dtype):
     """zero_grad + forward + backward of each optimizer index replayed from a HIP graph (graphed.GraphedStep) against the
@@ -152,6 +175,7 @@ def test_graphed_step_equals_eager(gpu, dtype):
     assert losses[True][0] != losses[True][-1]  # the parameters moved
 
 
+@step_graph
 def test_graphed_step_vocoder_workload(gpu):
     """The benchmark's module (VocoderGAN, BASELINE configs[1]) at reduced width: graph steps equal eager steps."""
     from vcvits_amd import configs, synthetic
@@ -188,6 +212,7 @@ def test_graphed_step_vocoder_workload(gpu):
         assert abs(g0 - g1) <= 2e-5 * abs(g0) and abs(d0 - d1) <= 2e-5 * abs(d0), (res[False], res[True])
 
 
+@step_graph
 def test_captured_backward_regenerates_the_replays_dropout_mask(gpu):
     """Inside a captured pass the attention backward (and vcv_dropout's) must regenerate the mask of ITS replay: the
     device-side seed offset read by the forward.  A replay with offset k equals the eager pass run with host seed S + k."""
@@ -221,8 +246,15 @@ def test_captured_backward_regenerates_the_replays_dropout_mask(gpu):
         graph = torch.cuda.CUDAGraph()
         L.vcv_set_seed_offset_ptr(off.data_ptr())
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
-            outs = run()
+        from vcvits_amd.light import graphed
+        gc_was_on = graphed._no_gc_during_capture()  # (no collection of an earlier test's graphs inside this capture)
+        try:
+            with torch.cuda.graph(graph):
+                outs = run()
+        finally:
+            if gc_was_on:
+                import gc
+                gc.enable()
         L.vcv_set_seed_offset_ptr(None)
         baked = list(seeds)
         assert len(baked) == 2, baked  # attention, dropout

@@ -18,6 +18,8 @@ What makes the captured sequence valid on replay:
 Any failure while capturing disables the graph for that callable (eager from then on)."""
 import os
 
+import gc
+
 import torch
 
 from .. import ops
@@ -74,9 +76,10 @@ class GraphedNoGrad:
         graph = torch.cuda.CUDAGraph()
         ops.CAPTURING[0] = keep
         L.vcv_set_seed_offset_ptr(seed.data_ptr())
+        gc_was_on = _no_gc_during_capture()
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_ERROR_MODE):
                 out = self.fn(static)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 -- whatever the capture tripped over: stay eager
@@ -89,11 +92,30 @@ class GraphedNoGrad:
         finally:
             L.vcv_set_seed_offset_ptr(None)
             ops.CAPTURING[0] = None
+            if gc_was_on:
+                gc.enable()
         # derived weights created while capturing hold no data yet (a capture records, it does not run)
         ops.invalidate_weights()
         ent = self.entries[key] = {"graph": graph, "inputs": static, "outputs": out, "seed": seed, "keep": keep}
         return ent
 
+
+
+def _no_gc_during_capture():
+    """Collect garbage NOW and keep the cyclic collector off until the capture is over (returns whether it was on).  A
+    collection that starts inside a capture can reach an earlier module's HIP graph (modules sit in reference cycles, so
+    their graphs die in the collector, not at `del`), and destroying a graph while a stream is capturing is an error raised
+    in a destructor: the process aborts (seen one full-suite run in eight: many modules with graphs in one process)."""
+    gc.collect()
+    was_on = gc.isenabled()
+    gc.disable()
+    return was_on
+
+
+# Capture with the thread-local error mode: under the default ("global") any other thread's event query during the capture is
+# an error that kills the process -- and in a data-parallel run torch's RCCL watchdog thread polls the events of the gradient
+# all-reduces it is still retiring at about that time.  Only the capturing thread's own calls are policed.
+CAPTURE_ERROR_MODE = __import__("os").environ.get("VCVITS_CAPTURE_ERROR_MODE", "thread_local")
 
 
 def set_step_enabled(on):
@@ -172,9 +194,10 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         ops.CAPTURING[0] = keep
         L.vcv_set_seed_offset_ptr(seed.data_ptr())
+        gc_was_on = _no_gc_during_capture()
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_ERROR_MODE):
                 opt.zero_grad()
                 loss = self.module.training_step(static, 0, idx)
                 loss.backward()
@@ -189,6 +212,8 @@ class GraphedStep:
         finally:
             L.vcv_set_seed_offset_ptr(None)
             ops.CAPTURING[0] = None
+            if gc_was_on:
+                gc.enable()
         ops.invalidate_weights()  # derived weights created while capturing hold no data (a capture records, it does not run)
         ent = self.entries[key] = {"graph": graph, "inputs": static, "loss": loss.detach(), "seed": seed, "keep": keep,
                                    "touched": bytes(opt._touched), "logged": dict(self.module.logged)}
