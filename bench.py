@@ -400,15 +400,32 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     PEVERY = 4
     psteps = (steps + PEVERY - 1) // PEVERY if prof else 0
     calls0 = _lib.CALLS[0]
+    bg = module.__dict__.get("_batch_graph") if module is not None else None
+    replays0 = bg.replays if bg is not None else 0
+    t_replay = t_eager = 0.0
+    n_replay = n_eager = 0
+    c0 = time.thread_time()
     t0 = time.perf_counter()
     for i in range(steps):
         if prof:
             L.vcv_prof_pause(0 if i % PEVERY == 0 else 1)
+        ts = time.perf_counter()
         run()
+        te = time.perf_counter() - ts
+        if prof and i % PEVERY == 0:  # (the profiled steps run eagerly: per-launch events are not capturable)
+            t_eager, n_eager = t_eager + te, n_eager + 1
+        else:
+            t_replay, n_replay = t_replay + te, n_replay + 1
     t_issue = time.perf_counter() - t0  # host time to ISSUE the timed steps (no device wait inside a step)
+    c_issue = time.thread_time() - c0   # ... and the CPU time this thread spent doing it
     sync()
     dt = time.perf_counter() - t0
     calls = (_lib.CALLS[0] - calls0) / max(steps, 1)
+    bg = module.__dict__.get("_batch_graph") if module is not None else None
+    host = {"issue_ms": 1e3 * t_issue / max(steps, 1), "cpu_ms": 1e3 * c_issue / max(steps, 1),
+            "graph_replays": (bg.replays - replays0) if bg is not None else 0,
+            "issue_ms_unprofiled_step": round(1e3 * t_replay / n_replay, 2) if n_replay else None,
+            "issue_ms_profiled_eager_step": round(1e3 * t_eager / n_eager, 2) if n_eager else None}
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -472,7 +489,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     if f32_split is not None:
         ops.set_f32_split(True, terms=6)
     torch.cuda.empty_cache()
-    return {"arith": arith, "dt": dt, "roof": roof, "host_issue_ms": 1e3 * t_issue / max(steps, 1), "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
+    return {"arith": arith, "dt": dt, "roof": roof, "host_issue_ms": 1e3 * t_issue / max(steps, 1), "host": host, "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
             "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world}
 
 
@@ -516,9 +533,22 @@ def make_line(r):
                             "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                             "utterances_per_s": round(utt_s, 3), "algorithmic_gflop_per_utterance": round(gfl, 1),
                             "algorithmic_tflops": round(utt_s * gfl / 1e3, 2),
+                            # the figure counts the reference's work (4 generator forwards-equivalents + 9 D); the
+                            # discriminator step's no-grad generator pass here is decoder-side only (posterior encoder ->
+                            # slice -> decoder: what y_hat depends on), so the EXECUTED flops of a full-model step are lower
+                            **({"algorithmic_gflop_note": "reference semantics (SURVEY 8d: 4 G + 9 D1); the D-step's no-grad "
+                                "generator pass skips the content encoder and the flow (dead work for y_hat.detach()), "
+                                "executed GFLOP per utterance are lower by that pass's enc_p + flow share"}
+                               if workload == "full" else {}),
                             # host side of a step: time this process needed to ISSUE one step's launches (the step is
                             # GPU-bound while this stays below ms_per_step) and the library launcher calls it made
                             "host_issue_ms_per_step": round(r["host_issue_ms"], 2),
+                            "host_cpu_ms_per_step": round(r["host"]["cpu_ms"], 2),
+                            # a training batch whose shapes repeat is ONE HIP-graph replay (vcvits_amd/light/graphed.py); the
+                            # steps that carry per-launch events (every fourth) run the eager loop -- the two kinds apart:
+                            "hip_graph_replays_in_timed_steps": r["host"]["graph_replays"],
+                            "host_issue_ms_graph_replay_step": r["host"]["issue_ms_unprofiled_step"],
+                            "host_issue_ms_profiled_eager_step": r["host"]["issue_ms_profiled_eager_step"],
                             "library_launcher_calls_per_step": round(r["calls"], 1),
                             "arithmetic": (r["arith"] if dtype == "f32" else
                                            "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},
@@ -534,6 +564,8 @@ def short(line):
             "workload": line["config"]["workload"], "per_gpu_batch": line["config"]["per_gpu_batch"],
             "algorithmic_tflops": line["config"]["algorithmic_tflops"],
             "host_issue_ms_per_step": line["config"]["host_issue_ms_per_step"],
+            "host_issue_ms_graph_replay_step": line["config"].get("host_issue_ms_graph_replay_step"),
+            "hip_graph_replays_in_timed_steps": line["config"].get("hip_graph_replays_in_timed_steps"),
             "library_launcher_calls_per_step": line["config"]["library_launcher_calls_per_step"],
             "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "frac", "traffic", "traffic_source",
                                                   "avg_launch_us", "launches_per_step", "share_of_step_time",

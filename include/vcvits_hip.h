@@ -184,6 +184,10 @@ int vcv_conv_x3_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
 int vcv_conv_pk_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
 int vcv_conv_bf16_pack_job(const VcvConvArgs* args, int flip, VcvPackJob* out);
 int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* stream);
+/* The same launches without the host -> device copy of the job table: `jobs` is finalised in place (order, block0) and the
+ * caller copies it into `table_dev` itself before the launches first execute (launch sequences recorded into a HIP graph:
+ * no copy node that re-reads host memory at every replay). */
+int vcv_pack_many_prepared(VcvPackJob* jobs, int n, void* table_dev, void* stream);
 /* Host table -> device on `stream`; inside a stream capture the copy is replayed from `src`, which the caller keeps alive
  * and unchanged for the life of the graph (the python layer's device tables of a captured pass). */
 int vcv_upload_table(void* dst, const void* src, int64_t bytes, void* stream);
@@ -359,9 +363,24 @@ int vcv_loss_many_sum(const void* items_dev, int n_items, int total_blocks, floa
 int vcv_loss_many_grad(const void* items_dev, int n_items, int total_blocks, float target, int mode,
                        const float* gout, float* dabuf, void* stream);
 
+/* ---- embedding rows laid out [B, C, T] (content_encoder.py:58-60: emb_pitch(pitch).transpose(1, -1); synthesizer_svc.py:77:
+ * emb_g(sid).unsqueeze(-1) with T = 1) and the table gradient.  idx: int64 [B, T]; W: [rows, C]; y / dy: [B, C, T].
+ * An index outside [0, rows) reads as a zero row.  The gradient is one workgroup per table row, positions summed in ascending
+ * order: no atomics, no sort, no host read-back (torch's embedding_dense_backward sorts with thrust and reads the segment
+ * count back -- not capturable into a HIP graph on this stack); accumulate: dW += instead of dW =. */
+int vcv_embedding_t_fwd(const void* idx, const float* W, float* y, int B, int T, int C, int rows, void* stream);
+int vcv_embedding_t_bwd(const void* idx, const float* dy, float* dW, int B, int T, int C, int rows, int accumulate, void* stream);
+
 /* ---- torch.optim.AdamW step over a flat buffer (vcvits.py:247-257) ---- */
 int vcv_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
               float eps, float wd, int step, void* stream);
+/* The same step with the per-step scalars in device memory: hyper_dev -> {fp32 learning rate, int32 step delta}; the step
+ * count of the bias corrections is step_base + delta.  For an optimizer step recorded into a HIP graph (arguments are
+ * baked at capture; the host refreshes the 8-byte record before each replay). */
+/* dst[0..n) = the first n <= 4 of (w0..w3), passed as kernel arguments (the record above: fp32 bits of lr, step delta). */
+int vcv_set_words(void* dst, int n, int w0, int w1, int w2, int w3, void* stream);
+int vcv_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps, float wd,
+                  const void* hyper_dev, int step_base, void* stream);
 
 /* ---- STFT magnitude sqrt(re^2+im^2+eps) (mel_processing.py:54-96): n_fft = 2048 (both reference configs; the tuned
  * kernels), any other power of two in [64, 4096] (generic radix-2 kernels) or any other even size in [16, 4096] (direct DFT;

@@ -4,6 +4,11 @@ shapes bench.py times must be the shapes a test has checked:
     arithmetic, one whole G step + D step against the CPU oracle AT B = 32 (losses and every parameter gradient); (b) in
     bf16 mode (the timed arithmetic), batch row b of the B = 32 pass against the B = 1 pass of row b -- forward outputs and
     the parameter gradients of a probe loss on that row -- plus the bf16 step's losses against the fp32 oracle's;
+  * BASELINE configs[3] -- configs/48k_base.json (128 channels, d_k = 32, 12 periods) at the per-GPU batch 16 x 384 frames in
+    bf16 mode: the same rows-against-single-runs check, and the timed step's losses against the fp32 CPU oracle on the same
+    16 utterances (the 8-rank run itself needs the node);
+  * BASELINE configs[1] -- the headline: base widths, B = 16, fp32, HiFi-GAN generator + MPD + MSD step (VocoderGAN): one
+    whole G step + D step against the CPU oracle at B = 16 (losses and every parameter gradient);
   * BASELINE configs[4] -- 48 kHz inference at B = 64 x 938 frames in bf16 mode: rows of the batch against their B = 1 runs
     and against the fp32 oracle (waveform RMS <= 1e-3, north_star).
 Reference: vits/light/vcvits.py:54-183 (training_step), vits/model/synthesizers/synthesizer_svc.py:70-109."""
@@ -18,7 +23,6 @@ from golden_util import close_kinked, fill_state_dict, keys_shapes_of, record_st
 
 pytestmark = pytest.mark.gpu
 
-ROWS = (3, 29)
 
 
 def _rel_l2(a, b):
@@ -113,18 +117,21 @@ def _disc_probe(module, y, y_hat, row, seed):
     return [t.detach().clone() for t in outs], grads
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_config2_batch_rows_equal_single_runs(gpu, dtype):
-    """configs[2] (B = 32 x 384 frames): row b of the batched pass == the B = 1 pass of row b, forward and backward; in the
-    bf16 arithmetic bench.py times (differences: fp32 summation order, then 2^-9 wherever a rounding flips) and in fp32."""
+@pytest.mark.parametrize("config,B,dtype", [("base", 32, "f32"), ("base", 32, "bf16"), ("48k", 16, "bf16")])
+def test_config2_batch_rows_equal_single_runs(gpu, config, B, dtype):
+    """configs[2] (base widths, B = 32 x 384 frames) and configs[3] (48k widths, 12 periods, per-GPU B = 16 x 384 frames): row b of
+    the batched pass == the B = 1 pass of row b, forward and backward; in the bf16 arithmetic bench.py times (differences: fp32
+    summation order, then 2^-9 wherever a rounding flips) and, for configs[2], in fp32."""
     from vcvits_amd import configs, ops
     from vcvits_amd.light.vcvits import VCVITS
     torch.manual_seed(3)
-    cfg = configs.base()
+    cfg = configs.base() if config == "base" else configs.base_48k()
     cfg["model"]["p_dropout"] = 0.0
     module = VCVITS(**cfg).to(gpu)
+    ROWS = (3, 29) if B == 32 else (3, 13)
+    cfgtag = "cfg2" if config == "base" else "cfg3"
     # plain autograd accumulation (no optimizer: no gradient sinks, parameters keep their own .grad)
-    batch = _full_batch(cfg, 32, seed=78, dev=gpu)
+    batch = _full_batch(cfg, B, seed=78, dev=gpu)
     tol_out, tol_grad = (2e-5, 5e-4) if dtype == "f32" else (1e-2, 4e-2)
     ops.set_compute_dtype(dtype)
     try:
@@ -141,7 +148,7 @@ def test_config2_batch_rows_equal_single_runs(gpu, dtype):
             o1, g1, y1, yh1 = _generator_probe(module, _sub(batch, row), 0, R)
             for k in o32:
                 e = _rel_l2(o32[k], o1[k])
-                record_stats("rows", "cfg2/%s/gen/%s" % (dtype, k), rel_l2=e)
+                record_stats("rows", "%s/%s/gen/%s" % (cfgtag, dtype, k), rel_l2=e)
                 assert e <= tol_out, (dtype, row, k, e)
             num = den = 0.0
             for n in g32:
@@ -151,7 +158,7 @@ def test_config2_batch_rows_equal_single_runs(gpu, dtype):
                 num += (g32[n].double() - g1[n].double()).pow(2).sum().item()
                 den += g1[n].double().pow(2).sum().item()
             e = (num / den) ** 0.5
-            record_stats("rows", "cfg2/%s/gen/grads" % dtype, rel_l2=e)
+            record_stats("rows", "%s/%s/gen/grads" % (cfgtag, dtype), rel_l2=e)
             assert e <= tol_grad, (dtype, row, "net_g gradients", e)
             # discriminators: stacked (y, y_hat) of the B = 32 pass, probe on row b
             d32, gd32 = _disc_probe(module, y32, yh32, row, seed=9)
@@ -166,12 +173,12 @@ def test_config2_batch_rows_equal_single_runs(gpu, dtype):
                 num += (gd32[n].double() - gd1[n].double()).pow(2).sum().item()
                 den += gd1[n].double().pow(2).sum().item()
             e = (num / den) ** 0.5
-            record_stats("rows", "cfg2/%s/disc/grads" % dtype, rel_l2=e)
+            record_stats("rows", "%s/%s/disc/grads" % (cfgtag, dtype), rel_l2=e)
             # (fp32: the two passes sum in different orders, so a few of the ~1e7 leaky-ReLU pre-activations of a row land
             # on different sides of zero -- golden_util.close_kinked; observed 5.4e-4)
             assert e <= (2e-3 if dtype == "f32" else tol_grad), (dtype, row, "discriminator gradients", e)
         if dtype == "bf16":
-            assert ops.LAUNCH_COUNTS["bf16"] - before["bf16"] > 500 and ops.LAUNCH_COUNTS["wgrad_bf16"] - before["wgrad_bf16"] > 100
+            assert ops.LAUNCH_COUNTS["bf16"] - before["bf16"] > 400 and ops.LAUNCH_COUNTS["wgrad_bf16"] - before["wgrad_bf16"] > 100
     finally:
         ops.set_compute_dtype("f32")
 
@@ -199,6 +206,71 @@ def test_config2_bf16_step_losses_B32(gpu):
         ops.set_compute_dtype("f32")
     for a, b, n in zip((out["g"], out["d"]), (lg, ld), ("loss_g", "loss_d")):
         assert abs(float(a) - float(b)) <= 2e-3 * abs(float(b)) + 1e-5, (n, float(a), float(b))
+
+
+def test_config3_bf16_step_losses_B16(gpu):
+    """The timed configs[3] step itself on one rank (48k widths, 12 periods, bf16 mode, per-GPU B = 16 x 384 frames): losses
+    within the bf16 bound (2e-3) of the fp32 CPU oracle run on the same 16 utterances."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import configs, ops
+    from vcvits_amd.light.vcvits import VCVITS
+    torch.manual_seed(6)
+    cfg = configs.base_48k()
+    cfg["model"]["p_dropout"] = 0.0
+    periods = list(cfg["model"]["multi_period_discriminator_periods"])
+    assert len(periods) == 12
+    module = VCVITS(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=False)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    batch = _full_batch(cfg, 16, seed=81)
+    torch.set_num_threads(16)
+    lg, ld = trainer.batch(batch)
+    ops.set_compute_dtype("bf16")
+    try:
+        before = dict(ops.LAUNCH_COUNTS)
+        out = module.fit_batch({k: v.to(gpu) for k, v in batch.items()})
+        assert ops.LAUNCH_COUNTS["bf16"] - before["bf16"] > 400 and ops.LAUNCH_COUNTS["wgrad_bf16"] - before["wgrad_bf16"] > 100
+    finally:
+        ops.set_compute_dtype("f32")
+    for a, b, n in zip((out["g"], out["d"]), (lg, ld), ("loss_g", "loss_d")):
+        record_stats("step", "cfg3/bf16/%s" % n, rel=abs(float(a) - float(b)) / abs(float(b)))
+        assert abs(float(a) - float(b)) <= 2e-3 * abs(float(b)) + 1e-5, (n, float(a), float(b))
+
+
+def test_config1_vocoder_step_B16_vs_oracle_f32(gpu):
+    """The HEADLINE shape (BASELINE configs[1]: base widths, B = 16, fp32, generator + MPD(8 periods + S) + MSD + STFT / mel-L1):
+    one whole G step + D step against the CPU oracle at B = 16 -- losses and every parameter gradient of both optimizers."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import configs, synthetic
+    from vcvits_amd.light.vcvits import DEFAULT_PERIODS, VocoderGAN
+    torch.manual_seed(7)
+    cfg = configs.base()
+    module = VocoderGAN(**cfg)
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, DEFAULT_PERIODS, vocoder_only=True)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    batch = synthetic.vocoder_batch(16, cfg["model"]["inter_channels"], seed=1234)
+    torch.set_num_threads(16)
+    lg, ld = trainer.batch(batch)
+    names = {id(p): n for n, p in module.named_parameters()}
+    grads = {}
+
+    def probe(idx, opt):
+        for p in opt.params:
+            grads[names[id(p)]] = p.grad.detach().cpu().clone()
+
+    out = module.fit_batch({k: v.to(gpu) for k, v in batch.items()}, after_backward=probe)
+    for a, b, n in zip((out["g"], out["d"]), (lg, ld), ("loss_g", "loss_d")):
+        assert abs(float(a) - float(b)) <= 2e-4 * abs(float(b)) + 1e-5, (n, float(a), float(b))
+    ref = dict(trainer.grads_g)
+    ref.update(trainer.grads_d)
+    assert len(ref) > 300 and set(ref) <= set(grads), sorted(set(ref) - set(grads))[:5]
+    tops = {}
+    for kk, v in ref.items():
+        tops[kk.split(".")[0]] = max(tops.get(kk.split(".")[0], 0.0), float(v.abs().max()))
+    for k, b in ref.items():
+        close_kinked("cfg1-B16/" + k, grads[k], b, tol=5e-4, floor=2e-6 * tops[k.split(".")[0]])
 
 
 def test_config4_inference_B64_rows(gpu):

@@ -176,3 +176,40 @@ def test_adamw(gpu):
         opt.step()
         ops.adamw_step(pg, g.to(gpu), m, v, 2e-4, (0.8, 0.99), 1e-9, 0.01, step)
     _cmp("adamw", pg, pr.detach(), tol=1e-6)
+
+
+@pytest.mark.parametrize("B,T,C,rows", [(16, 204, 128, 512), (32, 204, 256, 512), (3, 37, 40, 9), (64, 1, 256, 512)])
+def test_embedding_t_forward_and_table_gradient(gpu, B, T, C, rows):
+    """ops.embedding_t == F.embedding(idx, W).transpose(1, -1) (content_encoder.py:58-60; emb_g(sid).unsqueeze(-1) at T = 1),
+    forward and the table gradient (one workgroup per row, fixed summation order: bit-reproducible), with and without a
+    gradient sink; at sizes on both sides of torch's 3072-index switch to its sort-based backward."""
+    import torch.nn.functional as F
+    from vcvits_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    W = torch.randn(rows, C, generator=g).to(gpu).requires_grad_(True)
+    idx = torch.randint(0, rows, (B, T), generator=g).to(gpu)
+    r = torch.randn(B, C, T, generator=g).to(gpu)
+    y = ops.embedding_t(idx, W)
+    ref = F.embedding(idx.cpu(), W.detach().cpu()).transpose(1, -1)
+    assert torch.equal(y.detach().cpu(), ref)
+    (y * r).sum().backward()
+    Wc = W.detach().cpu().double().requires_grad_(True)
+    (F.embedding(idx.cpu(), Wc).transpose(1, -1) * r.cpu().double()).sum().backward()
+    err = (W.grad.cpu().double() - Wc.grad).abs().max().item()
+    assert err <= 1e-5 * Wc.grad.abs().max().item() + 1e-6, err
+    g1 = W.grad.clone()
+    W.grad = None
+    (ops.embedding_t(idx, W) * r).sum().backward()
+    assert torch.equal(g1, W.grad)  # fixed order: bit for bit
+    # gradient sink: added onto the registered view, autograd receives nothing
+    sink = torch.ones(rows, C, device=gpu)
+    ops.register_grad_sink(W, sink)
+    try:
+        W.grad = None
+        (ops.embedding_t(idx, W) * r).sum().backward()
+        assert W.grad is None and torch.allclose(sink - 1.0, g1, rtol=1e-5, atol=1e-5)
+    finally:
+        ops.unregister_grad_sink(W)
+    if T == 1:
+        y1 = ops.embedding_t(idx[:, 0], W)
+        assert torch.equal(y1, y.detach())

@@ -11,10 +11,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# The whole-step graphs (graphed.GraphedStep) are EXPERIMENTAL and off by default: DESIGN.md section 5(iv) records an
-# unresolved race (a GPU memory fault when replays and eager passes interleave at full width).  Their tests therefore run
-# in a child pytest process -- a fault there must not take the session (and every test after it) down; the parent test
-# fails with the child's output instead.
+# The whole-batch graphs (graphed.GraphedBatch: both optimizer passes and their AdamW steps as one HIP graph) are the default
+# path of fit_batch.  These tests still run in a child pytest process: a GPU fault in a graph replay kills the process, and
+# it must not take the session (and every test after it) down; the parent test fails with the child's output instead.
 IN_CHILD = os.environ.get("VCVITS_STEP_GRAPH_TESTS_CHILD") == "1"
 step_graph = pytest.mark.skipif(not IN_CHILD, reason="runs inside test_step_graph_tests_in_child_process")
 
@@ -24,11 +23,11 @@ def test_step_graph_tests_in_child_process(gpu):
         pytest.skip("this is the child")
     env = dict(os.environ, VCVITS_STEP_GRAPH_TESTS_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "graphed_step or captured_backward"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                        "-k", "graphed_step or captured_backward or graphed_batch"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
-    assert "4 passed" in out, out[-1500:]
+    assert "7 passed" in out, out[-1500:]
 
 
 def _cfg(p_dropout):
@@ -128,8 +127,9 @@ def test_graph_replays_draw_fresh_dropout_masks(gpu):
 @step_graph
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_graphed_step_equals_eager(gpu, dtype):
-    """zero_grad + forward + backward of each optimizer index replayed from a HIP graph (graphed.GraphedStep) against the
-    eager loop: same losses step for step from identical state, both indices captured, the optimizer still steps."""
+    """The whole batch (both optimizer passes and their AdamW steps) replayed from ONE HIP graph (graphed.GraphedBatch)
+    against the eager loop: same losses step for step from identical state, the recorded optimizer steps move the
+    parameters as the eager ones do."""
     from vcvits_amd import ops
     from vcvits_amd.light import graphed
     from vcvits_amd.light.vcvits import VCVITS
@@ -155,14 +155,15 @@ def test_graphed_step_equals_eager(gpu, dtype):
             losses[mode] = ls
             params[mode] = (mod.optim_g.flat.clone(), mod.optim_d.flat.clone())
             if mode:
-                sg = mod.__dict__["_step_graph"]
-                assert not sg.failed and sg.replays >= 8, (sg.failed, sg.replays)  # two batch shapes x two indices, then replays
+                sg = mod.__dict__["_batch_graph"]
+                assert not sg.failed and sg.replays >= 7 and sg.captures == 1, (sg.failed, sg.replays, sg.captures)
+                assert mod.optim_g.step_count == 9 and mod.optim_d.step_count == 9
             else:
-                assert "_step_graph" not in mod.__dict__ or mod.__dict__["_step_graph"].replays == 0
+                assert "_batch_graph" not in mod.__dict__ or mod.__dict__["_batch_graph"].replays == 0
             mod.optim_g.close()
             mod.optim_d.close()
     finally:
-        graphed.set_step_enabled(False)
+        graphed.set_step_enabled(True)
         ops.set_compute_dtype("f32")
     tol = 2e-5 if dtype == "f32" else 2e-3  # (weight-gradient atomics / split orders move the parameters in the last bits)
     for (g0, d0), (g1, d1) in zip(losses[False], losses[True]):
@@ -202,14 +203,107 @@ def test_graphed_step_vocoder_workload(gpu):
                 ls.append((float(out["g"]), float(out["d"])))
             res[mode] = ls
             if mode:
-                sg = mod.__dict__["_step_graph"]
-                assert not sg.failed and sg.replays >= 8, (sg.failed, sg.replays)
+                sg = mod.__dict__["_batch_graph"]
+                assert not sg.failed and sg.replays >= 5, (sg.failed, sg.replays)
             mod.optim_g.close()
             mod.optim_d.close()
     finally:
-        graphed.set_step_enabled(False)
+        graphed.set_step_enabled(True)
     for (g0, d0), (g1, d1) in zip(res[False], res[True]):
         assert abs(g0 - g1) <= 2e-5 * abs(g0) and abs(d0 - d1) <= 2e-5 * abs(d0), (res[False], res[True])
+
+
+@step_graph
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graphed_batch_interleaved_with_eager_batches(gpu, dtype):
+    """Replays and eager batches interleaved (what bench.py's sampled profiler steps do, and what variable-length data
+    does): the mixed loop's losses equal the all-eager loop's step for step.  Round 4's step graphs took a GPU memory
+    fault in exactly this pattern at full width."""
+    from vcvits_amd import ops
+    from vcvits_amd.light import graphed
+    from vcvits_amd.light.vcvits import VCVITS
+    cfg = _cfg(0.0)
+    torch.manual_seed(11)
+    sd = copy.deepcopy(VCVITS(**cfg).state_dict())
+    batches = _batches(cfg, 2, gpu, with_draws=True)
+    odd = {k: (v[:3].contiguous() if v.dim() > 0 and v.shape[0] == 4 else v) for k, v in batches[0].items()}  # another shape
+    losses = {}
+    ops.set_compute_dtype(dtype)
+    try:
+        for mode in ("eager", "mixed"):
+            torch.manual_seed(12)
+            mod = VCVITS(**cfg)
+            mod.load_state_dict(sd)
+            mod = mod.to(gpu)
+            mod.configure_optimizers()
+            ls = []
+            for i in range(14):
+                b = odd if i in (6, 11) else batches[i % 2]
+                graphed.set_step_enabled(mode == "mixed" and i % 4 != 1)  # every fourth batch of the mixed loop is eager
+                out = mod.fit_batch(b)
+                ls.append((float(out["g"]), float(out["d"])))
+            losses[mode] = ls
+            if mode == "mixed":
+                sg = mod.__dict__["_batch_graph"]
+                assert not sg.failed and sg.replays >= 5, (sg.failed, sg.replays)
+            assert mod.optim_g.step_count == 14 and mod.optim_d.step_count == 14
+            mod.optim_g.close()
+            mod.optim_d.close()
+    finally:
+        graphed.set_step_enabled(True)
+        ops.set_compute_dtype("f32")
+    tol = 5e-5 if dtype == "f32" else 4e-3
+    for (g0, d0), (g1, d1) in zip(losses["eager"], losses["mixed"]):
+        assert abs(g0 - g1) <= tol * abs(g0) and abs(d0 - d1) <= tol * abs(d0), (losses["eager"], losses["mixed"])
+
+
+@step_graph
+def test_graphed_batch_follows_a_learning_rate_change_and_a_rebuilt_optimizer(gpu):
+    """The recorded AdamW steps read the learning rate from device memory (a scheduler step between replays takes effect)
+    and a rebuilt optimizer (new flat buffers) never replays a graph recorded for the old storage."""
+    from vcvits_amd import configs, synthetic
+    from vcvits_amd.light import graphed
+    from vcvits_amd.light.vcvits import VocoderGAN
+    cfg = configs.base()
+    cfg["model"].update({"inter_channels": 16, "upsample_initial_channel": 32, "multi_period_discriminator_periods": [2, 3]})
+    cfg["data"]["n_mel_channels"] = 40
+    cfg["train"]["segment_size"] = 4096
+    cfg["train"]["lr_decay"] = 0.5
+    torch.manual_seed(5)
+    sd = copy.deepcopy(VocoderGAN(**cfg).state_dict())
+    batch = {k: v.to(gpu) for k, v in synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3).items()}
+    res = {}
+    try:
+        for mode in (False, True):
+            graphed.set_step_enabled(mode)
+            mod = VocoderGAN(**cfg)
+            mod.load_state_dict(sd)
+            mod = mod.to(gpu)
+            mod.configure_optimizers()
+            ls = []
+            for i in range(12):
+                if i in (5, 6):
+                    mod.on_epoch_end()  # ExponentialLR: the second call halves the rate
+                if i == 9:
+                    st = (mod.optim_g.state_dict(), mod.optim_d.state_dict())
+                    mod.configure_optimizers()  # new flat buffers; moments restored, parameters carried over
+                    mod.optim_g.load_state_dict(st[0])
+                    mod.optim_d.load_state_dict(st[1])
+                out = mod.fit_batch(batch)
+                ls.append((float(out["g"]), float(out["d"])))
+            res[mode] = (ls, mod.optim_g.flat.clone(), mod.optim_g.lr)
+            if mode:
+                sg = mod.__dict__["_batch_graph"]
+                assert not sg.failed and sg.replays >= 1, (sg.failed, sg.replays)
+            mod.optim_g.close()
+            mod.optim_d.close()
+    finally:
+        graphed.set_step_enabled(True)
+    assert res[False][2] == res[True][2] and res[True][2] < float(cfg["train"]["learning_rate"])
+    for (g0, d0), (g1, d1) in zip(res[False][0], res[True][0]):
+        assert abs(g0 - g1) <= 5e-5 * abs(g0) and abs(d0 - d1) <= 5e-5 * abs(d0), (res[False][0], res[True][0])
+    lr = float(cfg["train"]["learning_rate"])
+    assert float((res[False][1] - res[True][1]).abs().max()) <= 2.5 * lr * 12 + 1e-4 * float(res[False][1].abs().max())
 
 
 @step_graph

@@ -96,7 +96,7 @@ EXPORTS = [
     "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16", "vcv_act_grad_bias", "vcv_conv_pk_plan", "vcv_conv_pk_run",
     "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_rel_attn_bwd2", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause", "vcv_conv_x3_pack_job", "vcv_conv_pk_pack_job", "vcv_conv_bf16_pack_job", "vcv_pack_many", "vcv_upload_table",
     "vcv_conv_bf16io_plan", "vcv_conv_bf16io_run", "vcv_cast_f32_x16", "vcv_cast_x16_f32", "vcv_conv_m1_x16_fwd",
-    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr",
+    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_bwd",
 ]
 
 
@@ -199,6 +199,11 @@ _ARGTYPES = {
     "vcv_conv_bf16_pack_job": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(VcvPackJob)],
     "vcv_pack_many": [ctypes.POINTER(VcvPackJob), _I, _P, _P],
     "vcv_upload_table": [_P, _P, _L, _P],
+    "vcv_pack_many_prepared": [ctypes.POINTER(VcvPackJob), _I, _P, _P],
+    "vcv_embedding_t_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vcv_embedding_t_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vcv_set_words": [_P, _I, _I, _I, _I, _I, _P],
+    "vcv_adamw_dev": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _I, _P],
     "vcv_conv_bf16io_plan": [ctypes.POINTER(VcvConvArgs), _I, ctypes.POINTER(ctypes.c_int64)],
     "vcv_conv_bf16io_run": [ctypes.POINTER(VcvConvArgs), _P, _P, _I, _I, _P],
     "vcv_prof_active": [],
@@ -210,6 +215,124 @@ _ARGTYPES = {
 }
 
 
+class Capture:
+    """State of ONE launch sequence being recorded into a HIP graph (light/graphed.py sets CAPTURE[0] for its duration).
+
+    What a recorded launch bakes is an ADDRESS.  The sequence is valid on replay only while everything behind those
+    addresses is still there, so this object makes that true by construction instead of by convention:
+      * `keep`     -- objects that must live as long as the graph (device tables, host arrays);
+      * `tables`   -- device tables whose contents are known while recording and never change between replays (they hold
+                      addresses of the graph's own tensors).  They are NOT uploaded by a recorded copy node -- a node
+                      that re-reads pageable host memory at every replay -- but once, eagerly, right after the capture
+                      (`flush`).  That only works for memory NO recorded launch ever writes: a block of the graph's pool
+                      is re-written at every replay by whichever earlier tensor of the sequence lived in it before the
+                      table did (the first version of this scheme took tables from the pool and faulted on its first
+                      replay for exactly that reason).  So tables are cut from `table_arena`, allocated before the capture
+                      begins, outside the pool; when it is full the caller falls back to a recorded copy node;
+      * `external` -- every tensor handed to a launcher (`ptr`) whose storage was allocated BEFORE the capture began, i.e.
+                      outside the graph's private pool (parameters, optimizer buffers, cached constant tables, ...).  The
+                      graph holds a reference to each, so none of them can be freed -- and its address recycled -- under
+                      the graph, whatever the eager code does with its caches afterwards.
+    VCVITS_CHECK_PTRS=1 prints every distinct external tensor with the call site that handed it over (the audit the
+    round-4 memory fault called for: an address baked into a captured launch that no longer exists)."""
+    _next_id = [1]
+
+    TABLE_BYTES = int(float(os.environ.get("VCVITS_GRAPH_TABLE_MB", "16")) * (1 << 20))
+
+    def __init__(self, device=None):
+        self.id = Capture._next_id[0]
+        Capture._next_id[0] += 1
+        self.keep, self.pending, self.external = [], [], {}
+        self.table_arena, self.table_off = None, 0
+        if device is not None and torch.cuda.is_available():
+            self.table_arena = torch.zeros(self.TABLE_BYTES, device=device, dtype=torch.uint8)
+        self.log = os.environ.get("VCVITS_CHECK_PTRS", "0") == "1"
+        self._starts, self._ends = [], []
+        if device is not None and torch.cuda.is_available():
+            segs = sorted((s["address"], s["address"] + s["total_size"]) for s in torch.cuda.memory_snapshot()
+                          if s.get("device", 0) == (device.index if device.index is not None else torch.cuda.current_device()))
+            self._starts = [a for a, _ in segs]
+            self._ends = [b for _, b in segs]
+
+    # (list protocol of the round-4 `keep` list: ops appends host arrays / tables to the capture)
+    def append(self, obj):
+        self.keep.append(obj)
+
+    def extend(self, objs):
+        self.keep.extend(objs)
+
+    def is_external(self, addr):
+        import bisect
+        i = bisect.bisect_right(self._starts, addr) - 1
+        return i >= 0 and addr < self._ends[i]
+
+    def note(self, t):
+        a = t.data_ptr()
+        if a in self.external or not self.is_external(a):
+            return
+        self.external[a] = t
+        if self.log:
+            import sys
+            import traceback
+            fr = [f for f in traceback.extract_stack(limit=12)[:-2] if "torch/" not in f.filename][-4:]
+            sys.stderr.write("vcvits_amd[capture %d]: external tensor %s %s @0x%x  <- %s\n" % (
+                self.id, tuple(t.shape), str(t.dtype).replace("torch.", ""), a,
+                " <- ".join("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in reversed(fr))))
+
+    def table(self, host_bytes, dtype, shape):
+        """A device tensor (`dtype`, `shape`) cut from the table arena that will hold `host_bytes` (a contiguous numpy array
+        or a ctypes array) whenever the graph runs -- or None when the arena is full (caller: recorded copy node)."""
+        import numpy as np
+        n = host_bytes.nbytes if isinstance(host_bytes, np.ndarray) else ctypes.sizeof(host_bytes)
+        need = 1
+        for d in shape:
+            need *= int(d)
+        need *= torch.empty((), dtype=dtype).element_size()
+        if self.table_arena is None or need < n or self.table_off + need > self.table_arena.numel():
+            return None
+        view = self.table_arena[self.table_off:self.table_off + need].view(dtype).view(tuple(shape))
+        self.pending.append((view, host_bytes))
+        self.table_off = (self.table_off + need + 255) & ~255
+        return view
+
+    def check_tables(self):
+        """VCVITS_CHECK_PTRS: every 8-byte word of the pending device tables that looks like a device address must lie
+        inside a live allocator segment (the graph's pool included)."""
+        import bisect
+        import sys
+        import numpy as np
+        segs = sorted((s["address"], s["address"] + s["total_size"]) for s in torch.cuda.memory_snapshot())
+        starts = [a for a, _ in segs]
+        lo, hi = (segs[0][0], segs[-1][1]) if segs else (0, 0)
+        bad = 0
+        for ti, (dev_tensor, host) in enumerate(self.pending):
+            raw = np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host.reshape(-1).view(np.uint8)
+            words = raw[:raw.size // 8 * 8].view(np.int64)
+            for wi, w in enumerate(words.tolist()):
+                if w < (1 << 40) or w >= (1 << 48):
+                    continue  # (not an address: a count, an offset, packed ints)
+                i = bisect.bisect_right(starts, w) - 1
+                if not (i >= 0 and w < segs[i][1]):
+                    bad += 1
+                    sys.stderr.write("vcvits_amd[capture %d]: table %d (%s, %d bytes) word %d = 0x%x is outside every live "
+                                     "segment [0x%x, 0x%x)\n" % (self.id, ti, tuple(dev_tensor.shape), raw.size, wi, w, lo, hi))
+        sys.stderr.write("vcvits_amd[capture %d]: %d device tables checked, %d stray addresses\n" % (self.id, len(self.pending), bad))
+
+    def flush(self):
+        import numpy as np
+        if self.log:
+            self.check_tables()
+        for dev_tensor, host in self.pending:
+            src = np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host.reshape(-1).view(np.uint8)
+            dst = dev_tensor.reshape(-1).view(torch.uint8)
+            dst[:src.size].copy_(torch.from_numpy(src.copy()))
+        self.pending = []
+
+
+# the capture in progress on this process's launch thread (None: eager)
+CAPTURE = [None]
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int, contiguous, on GPU."""
     if t is None:
@@ -218,6 +341,8 @@ def ptr(t):
         raise RuntimeError("vcvits_amd: tensor is not on the GPU; the HIP path has no CPU fallback")
     if not t.is_contiguous():
         raise RuntimeError("vcvits_amd: non-contiguous tensor passed to a HIP launcher")
+    if CAPTURE[0] is not None:
+        CAPTURE[0].note(t)
     return ctypes.c_void_p(t.data_ptr())
 
 

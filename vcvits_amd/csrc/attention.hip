@@ -1372,7 +1372,7 @@ extern "C" int vcv_rel_attn_bwd2(const float* q, const float* k, const float* v,
     return vcv_check_launch();
   }
   const size_t ne = sizeof(float) * (2 * w + 1) * dk;
-  if (hipMemsetAsync(dembk, 0, ne, st) != hipSuccess || hipMemsetAsync(dembv, 0, ne, st) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dembk, ne, st) != hipSuccess || vcv_zero_async(dembv, ne, st) != hipSuccess) return VCV_EHIP;
   const size_t lds = lds_bytes(a.TP);
   auto rows = bf16 ? rel_attn_bwd_rows_kernel<true> : rel_attn_bwd_rows_kernel<false>;
   auto cols = bf16 ? rel_attn_bwd_cols_kernel<true> : rel_attn_bwd_cols_kernel<false>;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "vcvits_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,6 +49,23 @@ static inline int vcv_check_launch() {
 }
 
 static inline int vcv_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Zero `bytes` (a multiple of 4) at p on `stream` with a KERNEL.  The launchers used hipMemsetAsync; inside a stream capture
+// that records a memset NODE, and VCVITS_ZERO_MEMSET=1 keeps it (A/B: light/graphed.py's replays).
+static __global__ void vcv_zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = 0u;
+}
+static inline hipError_t vcv_zero_async(void* p, size_t bytes, hipStream_t st) {
+  static const bool use_memset = [] { const char* e = getenv("VCVITS_ZERO_MEMSET"); return e && e[0] == '1'; }();
+  if (use_memset || (bytes & 3) || ((uintptr_t)p & 3)) return hipMemsetAsync(p, 0, bytes, st);
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(vcv_zero_words_kernel, dim3(blocks), dim3(256), 0, st, (uint32_t*)p, n);
+  return hipGetLastError();
+}
 
 extern "C" int vcv_get_deterministic(void);  // version.hip
 extern "C" const void* vcv_get_seed_offset_ptr(void);  // version.hip

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) pack_many_kernel(const VcvPackJob* __rest
 
 // jobs: host array of n jobs with w / wp / the layout fields set (vcv_conv_*_pack_job) -- block0 is filled here;
 // table_dev: device scratch of n * sizeof(VcvPackJob) bytes.  One launch packs them all.
-extern "C" int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* stream) {
+static int pack_many_impl(VcvPackJob* jobs, int n, void* table_dev, void* stream, bool upload) {
   if (!jobs || n <= 0 || !table_dev) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   static const bool no_tile = getenv("VCVITS_PACK_NO_TILE") != nullptr;
@@ -244,12 +244,24 @@ extern "C" int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* str
     blocks += (jobs[i].total + 255) / 256;
   }
   if (blocks >= (1ll << 31) || blocks_t >= (1ll << 31)) return VCV_EINVAL;
-  if (hipMemcpyAsync(table_dev, jobs, sizeof(VcvPackJob) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) return VCV_EHIP;
+  if (upload && hipMemcpyAsync(table_dev, jobs, sizeof(VcvPackJob) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) return VCV_EHIP;
   if (nt > 0)
     hipLaunchKernelGGL(pack_x3_tile_kernel, dim3((unsigned)blocks_t), dim3(256), lds_max, st, (const VcvPackJob*)table_dev, nt);
   if (n > nt)
     hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const VcvPackJob*)table_dev + nt, n - nt);
   return vcv_check_launch();
+}
+
+extern "C" int vcv_pack_many(VcvPackJob* jobs, int n, void* table_dev, void* stream) {
+  return pack_many_impl(jobs, n, table_dev, stream, true);
+}
+
+// The same launches WITHOUT the host -> device copy of the job table: `jobs` is finalised in place (order, block0) and the
+// caller uploads it into `table_dev` itself before the launches first EXECUTE.  For launch sequences recorded into a HIP
+// graph: the table's contents never change between replays, so the graph holds no copy node that re-reads host memory
+// (light/graphed.py uploads every table of a captured pass once, eagerly, right after the capture).
+extern "C" int vcv_pack_many_prepared(VcvPackJob* jobs, int n, void* table_dev, void* stream) {
+  return pack_many_impl(jobs, n, table_dev, stream, false);
 }
 
 // Host table -> device on `stream` (hipMemcpyAsync).  Inside a stream capture this becomes a memcpy node that reads `src`

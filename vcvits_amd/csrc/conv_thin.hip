@@ -491,7 +491,7 @@ extern "C" int vcv_linear_t1_fwd(const float* x, const float* w, const float* bi
 extern "C" int vcv_linear_t1_dgrad(const float* dy, const float* w, float* dx, int B, int C, int M, void* stream) {
   if (!dy || !w || !dx || B <= 0 || B > T1_BMAX || C <= 0 || M <= 0) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * C, st) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dx, sizeof(float) * (size_t)B * C, st) != hipSuccess) return VCV_EHIP;
   const int nct = vcv_cdiv(C, 256);
   int msplit = 512 / nct;
   if (msplit > M / 16) msplit = M / 16;

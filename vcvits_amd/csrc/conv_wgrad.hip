@@ -474,7 +474,7 @@ extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, in
   long long nseg = (1024 + C - 1) / C;
   if (nseg > units / 8) nseg = units / 8;
   if (nseg < 1 || vcv_get_deterministic()) nseg = 1;
-  if (nseg > 1 && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
+  if (nseg > 1 && !accumulate && vcv_zero_async(dbias, sizeof(float) * C, st) != hipSuccess) return VCV_EHIP;
   if (T % 4 == 0)
     hipLaunchKernelGGL(bias_grad_kernel<true>, dim3(C, (unsigned)nseg), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf,
                        slope, (int)nseg, accumulate);

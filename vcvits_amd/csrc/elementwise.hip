@@ -364,6 +364,39 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
+// The same step with the two per-step scalars read from device memory: hyper = {lr (fp32 bits), step delta (int32)}.  A
+// launch recorded into a HIP graph bakes its arguments, so the learning rate and the step count (bias corrections) of a
+// replayed optimizer step come from this 8-byte record, which the host refreshes before each replay (light/graphed.py).
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, size_t n, float b1, float b2, float eps, float wd,
+                                 const int* __restrict__ hyper, int step_base) {
+  __shared__ float s_h[3];
+  if (threadIdx.x == 0) {
+    const int step = step_base + hyper[1];
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    s_h[0] = __int_as_float(hyper[0]);
+    s_h[1] = (float)bc1;
+    s_h[2] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float lr = s_h[0], bc1 = s_h[1], bc2_sqrt = s_h[2];
+  const float gi = g[i];
+  float pi = p[i] * (1.f - lr * wd);
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+__global__ void set_words_kernel(int* __restrict__ dst, int n, int w0, int w1, int w2, int w3) {
+  const int w[4] = {w0, w1, w2, w3};
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = w[threadIdx.x];
+}
+
 // wt[c, m, K-1-k] = w[m, c, k]: the stride-1 data gradient of a conv is a forward conv with these weights
 __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C,
                                              int K, size_t n) {
@@ -536,6 +569,22 @@ extern "C" int vcv_loss_many_grad(const void* items_dev, int n_items, int total_
   if (!items_dev || !gout || !dabuf || n_items <= 0 || total_blocks <= 0) return VCV_EINVAL;
   hipLaunchKernelGGL(loss_many_grad_kernel, dim3(total_blocks), dim3(256), 0, ST, (const LossItem*)items_dev, n_items,
                      total_blocks, target, mode, gout, dabuf);
+  return vcv_check_launch();
+}
+
+// dst[0..n) = the first n of (w0, w1, w2, w3), n <= 4: a few host scalars into device memory as kernel ARGUMENTS (copied
+// at launch time: no host buffer that a later call could overwrite while the copy is still queued).
+extern "C" int vcv_set_words(void* dst, int n, int w0, int w1, int w2, int w3, void* stream) {
+  if (!dst || n <= 0 || n > 4) return VCV_EINVAL;
+  hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(64), 0, ST, (int*)dst, n, w0, w1, w2, w3);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps,
+                             float wd, const void* hyper_dev, int step_base, void* stream) {
+  if (!p || !g || !m || !v || !hyper_dev || n <= 0 || step_base <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(adamw_dev_kernel, grid1d(n), dim3(256), 0, ST, p, g, m, v, (size_t)n, b1, b2, eps, wd,
+                     (const int*)hyper_dev, step_base);
   return vcv_check_launch();
 }
 

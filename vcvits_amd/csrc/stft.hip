@@ -704,7 +704,7 @@ extern "C" int vcv_istft(const float* spec, const float* window, const float* tw
   const int trim = center ? n_fft / 2 : 0;
   const int Tout = center ? hop * (F - 1) : L;
   if (Tout <= 0) return VCV_EINVAL;
-  if (hipMemsetAsync(ola, 0, sizeof(float) * (size_t)B * L, st) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(ola, sizeof(float) * (size_t)B * L, st) != hipSuccess) return VCV_EHIP;
   if (n_fft == N) {
     hipLaunchKernelGGL(istft_ola_kernel, dim3(F, B), dim3(NT), 0, st, (const float2*)spec, window,
                        (const float2*)twiddle, ola, F, hop, L);
@@ -803,7 +803,7 @@ extern "C" int vcv_stft_mag_bwd(const float* y, const float* window, const float
     if ((long long)B * F <= 2048 && tail_fits(2)) return launch_bwd_own<4, 2>(y, window, twiddle, dmag, dy, B, T, F, hop, pad, eps, st);
     if (tail_fits(8)) return launch_bwd_own<2, 8>(y, window, twiddle, dmag, dy, B, T, F, hop, pad, eps, st);
   }
-  if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * T, st) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dy, sizeof(float) * (size_t)B * T, st) != hipSuccess) return VCV_EHIP;
   hipLaunchKernelGGL(stft_mag_bwd_kernel<false>, dim3(vcv_cdiv(F, NF), B), dim3(NT), 0, st, y,
                      window, (const float2*)twiddle, dmag, dy, T, F, hop, pad, reflect, eps);
   return vcv_check_launch();

@@ -349,7 +349,7 @@ int stft_mag_bwd_generic_launch(const float* y, const float* window, const float
   if (F <= 0) return VCV_EINVAL;
   const bool dft = n_fft < 64 || (n_fft & (n_fft - 1));
   if (dft ? !dft_size(n_fft) : n_fft > 4096) return VCV_EINVAL;
-  if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * T, st) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dy, sizeof(float) * (size_t)B * T, st) != hipSuccess) return VCV_EHIP;
   if (dft) {
     hipLaunchKernelGGL(stft_dft_bwd_kernel, dim3(F, B), dim3(GT), dft_lds_bytes(n_fft), st, y, window, (const float2*)twiddle, dmag,
                        dy, T, F, hop, pad, reflect, eps, n_fft);

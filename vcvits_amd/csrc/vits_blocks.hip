@@ -581,6 +581,78 @@ __global__ void slice_bwd_kernel(const float* __restrict__ dy, const int64_t* __
   if (t >= 0 && t < T) dx[bc * T + t] = dy[i];
 }
 
+// ---- embedding rows as [B, C, T] (content_encoder.py:58-60: emb_pitch(pitch).transpose(1, -1); synthesizer_svc.py:77:
+// emb_g(sid).unsqueeze(-1)) and the table gradient ------------------------------------------------------------------------
+// y[b, c, t] = W[idx[b, t], c]: the rows of a 32-frame tile are read along c (coalesced), transposed through LDS and written
+// along t (coalesced).  An index outside [0, rows) gives a zero column.
+__global__ __launch_bounds__(256) void embedding_t_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ W,
+                                                              float* __restrict__ y, int T, int C, int rows) {
+  extern __shared__ float tile[];  // [32][C + 1]
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;
+  const int nt = min(32, T - t0);
+  const int ld = C + 1;
+  for (int e = threadIdx.x; e < nt * C; e += 256) {
+    const int tt = e / C, c = e - tt * C;
+    const long long r = idx[(size_t)b * T + t0 + tt];
+    tile[tt * ld + c] = (r >= 0 && r < rows) ? W[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * C; e += 256) {
+    const int c = e / nt, tt = e - c * nt;
+    y[((size_t)b * C + c) * T + t0 + tt] = tile[tt * ld + c];
+  }
+}
+
+// dW[r, c] (+)= sum over the positions n = b T + t with idx[n] == r of dy[b, c, t], positions in ascending order: ONE
+// workgroup owns row r, so there are no atomics and the sum order is fixed (torch's embedding_dense_backward sorts the
+// indices with thrust and reads the segment count back to the host -- a sync inside the step, and on this ROCm build not
+// capturable into a HIP graph: the replayed partition kernel faulted).  The table is small (512 x 128..256): every workgroup
+// scans the N <= ~10^4 indices from L2 and gathers its ~N / rows matching columns.
+__global__ __launch_bounds__(256) void embedding_t_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy,
+                                                              float* __restrict__ dW, int N, int T, int C, int accumulate) {
+  __shared__ int list[256];
+  __shared__ int wcount[4];
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int MAXC = 4;  // channels per thread: C <= 1024
+  float acc[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+  for (int base = 0; base < N; base += 256) {
+    const int n = base + (int)threadIdx.x;
+    const bool hit = n < N && idx[n] == (long long)r;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) off += wcount[w];
+      total += wcount[w];
+    }
+    if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = n;
+    __syncthreads();
+    for (int k = 0; k < total; ++k) {
+      const int nn = list[k];
+      const int b = nn / T, t = nn - b * T;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const int c = (int)threadIdx.x + 256 * j;
+        if (c < C) acc[j] += dy[((size_t)b * C + c) * T + t];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = (int)threadIdx.x + 256 * j;
+    if (c < C) {
+      float* p = dW + (size_t)r * C + c;
+      *p = accumulate ? *p + acc[j] : acc[j];
+    }
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -773,8 +845,8 @@ extern "C" int vcv_layernorm_c_bwd(const float* x, const float* y, const float* 
     hipLaunchKernelGGL(layernorm_c_bwd_reduce_kernel, dim3(vcv_cdiv(2 * C, 256)), dim3(256), 0, ST, (const float*)scratch, dgamma, dbeta, C, nwg);
     return vcv_check_launch();
   }
-  if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, ST) != hipSuccess) return VCV_EHIP;
-  if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dgamma, sizeof(float) * C, ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dbeta, sizeof(float) * C, ST) != hipSuccess) return VCV_EHIP;
   hipLaunchKernelGGL(layernorm_c_bwd_kernel, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, mean, rstd,
                      dout, dx, dgamma, dbeta, C, T);
   return vcv_check_launch();
@@ -813,8 +885,8 @@ extern "C" int vcv_rel_softmax_bwd(const float* P, const float* Pd, float* dP, c
   if (!P || !Pd || !dP || !dO || !q || !embk || !embv || !mask || !dSt || !dqband || !dembk || !dembv || 2 * w + 1 > 32)
     return VCV_EINVAL;
   const size_t ne = sizeof(float) * (2 * w + 1) * dk;
-  if (hipMemsetAsync(dembk, 0, ne, ST) != hipSuccess) return VCV_EHIP;
-  if (hipMemsetAsync(dembv, 0, ne, ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dembk, ne, ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dembv, ne, ST) != hipSuccess) return VCV_EHIP;
   if (2 * w + 1 > RS_NRMAX || dk > 64 * RS_DD) return VCV_EINVAL;
   hipLaunchKernelGGL(rel_softmax_bwd_kernel, dim3(vcv_cdiv(T, RS_ROWS), B * H), dim3(64), 0, ST, P, Pd, dP, dO, q, embk, embv, mask, dSt,
                      dqband, dembk, dembv, H, dk, T, w, qscale);
@@ -825,7 +897,7 @@ extern "C" int vcv_kl_fwd(const float* zp, const float* lq, const float* mp, con
                           float* out2, int B, int C, int T, void* stream) {
   const size_t n = (size_t)B * C * T;
   if (!zp || !lq || !mp || !lp || !mask || !out2 || n == 0) return VCV_EINVAL;
-  if (hipMemsetAsync(out2, 0, 2 * sizeof(float), ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(out2, 2 * sizeof(float), ST) != hipSuccess) return VCV_EHIP;
   size_t nb = (n + 2047) / 2048;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(kl_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, ST, zp, lq, mp, lp, mask, out2, C, T, n);
@@ -855,7 +927,7 @@ extern "C" int vcv_nearest_fwd(const float* x, float* y, int R, int Tin, int Tou
 extern "C" int vcv_nearest_bwd(const float* dy, float* dx, int R, int Tin, int Tout, void* stream) {
   const size_t n = (size_t)R * Tout;
   if (!dy || !dx || n == 0 || Tin <= 0) return VCV_EINVAL;
-  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)R * Tin, ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dx, sizeof(float) * (size_t)R * Tin, ST) != hipSuccess) return VCV_EHIP;
   hipLaunchKernelGGL(nearest_bwd_kernel, g1(n), dim3(256), 0, ST, dy, dx, Tin, Tout, n);
   return vcv_check_launch();
 }
@@ -872,7 +944,22 @@ extern "C" int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float
                              void* stream) {
   const size_t n = (size_t)B * C * S;
   if (!dy || !ids || !dx || n == 0) return VCV_EINVAL;
-  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * C * T, ST) != hipSuccess) return VCV_EHIP;
+  if (vcv_zero_async(dx, sizeof(float) * (size_t)B * C * T, ST) != hipSuccess) return VCV_EHIP;
   hipLaunchKernelGGL(slice_bwd_kernel, g1(n), dim3(256), 0, ST, dy, ids, mul, dx, C, T, S, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_embedding_t_fwd(const void* idx, const float* W, float* y, int B, int T, int C, int rows, void* stream) {
+  if (!idx || !W || !y || B <= 0 || T <= 0 || C <= 0 || rows <= 0) return VCV_EINVAL;
+  const size_t lds = sizeof(float) * 32 * (size_t)(C + 1);
+  if (lds > 64 * 1024) return VCV_EINVAL;
+  hipLaunchKernelGGL(embedding_t_fwd_kernel, dim3(vcv_cdiv(T, 32), B), dim3(256), lds, ST, (const long long*)idx, W, y, T, C, rows);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_embedding_t_bwd(const void* idx, const float* dy, float* dW, int B, int T, int C, int rows, int accumulate,
+                                   void* stream) {
+  if (!idx || !dy || !dW || B <= 0 || T <= 0 || C <= 0 || C > 1024 || rows <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(embedding_t_bwd_kernel, dim3(rows), dim3(256), 0, ST, (const long long*)idx, dy, dW, B * T, T, C, accumulate);
   return vcv_check_launch();
 }

@@ -1,59 +1,207 @@
-"""HIP-graph replay of a no-grad pass.
+"""HIP-graph replay of the training batch.
 
-The discriminator step of the reference re-runs the whole generator forward under `torch.no_grad()` and keeps only
-`y_hat.detach()` (vits/light/vcvits.py:119,153).  That pass is ~300 launcher calls whose shapes, addresses and order do
-not change from step to step, and at bf16 speeds the step is bound by the host issuing them (bench.py:
-`host_issue_ms_per_step`), so it is captured once into a HIP graph (torch.cuda.CUDAGraph: the library's launches go to the
-capturing stream like torch's own) and replayed: one host call instead of ~300.
+The reference's loop (vits/light/vcvits.py:54-183 under Lightning's automatic optimisation) issues, per batch, one generator
+pass and one discriminator pass eagerly: here that is ~1,000-1,800 launcher calls through Python autograd per batch whose
+shapes, addresses and order repeat from batch to batch, and every configuration was bound -- or within 20 % of being bound
+-- by the host issuing them (bench.py: `host_issue_ms_per_step`).  So once a batch shape repeats the WHOLE batch
 
-What makes the captured sequence valid on replay:
-  * inputs are copied into static buffers, outputs are the capture's own tensors (valid until the next replay);
-  * every buffer the sequence allocates comes from the graph's private pool, so the addresses baked into device tables
-    (weight-norm records, packed-weight jobs) stay the same; host arrays a captured copy reads from are kept alive;
-  * derived-weight caches are bypassed while capturing (ops.CAPTURING): the graph always re-normalises and re-packs the
-    weights it uses, whatever the cache state was at capture time;
-  * dropout: the host seed is baked into the kernel arguments, so the kernels add a device-side counter that is bumped
-    before each replay (vcv_set_seed_offset_ptr) -- fresh masks every step; torch's own generators are graph-safe;
-  * the per-launch profiler must be idle (its events are not capturable): while it records, the pass runs eagerly.
-Any failure while capturing disables the graph for that callable (eager from then on)."""
-import os
+    zero_grad(G) -> training_step(batch, 0) -> backward -> [gradient all-reduces] -> AdamW(G)
+ -> zero_grad(D) -> training_step(batch, 1) -> backward -> [gradient all-reduces] -> AdamW(D)
 
+is recorded into ONE HIP graph (`GraphedBatch`) and replayed: one host call per batch.  `GraphedNoGrad` is the same
+machinery for a no-grad callable (the discriminator step's generator pass of the eager loop).
+
+What a recorded launch bakes is an address, and what makes the recorded sequence valid on replay is that everything behind
+the addresses is still there and means the same.  That is enforced by construction (`_lib.Capture`), not by convention:
+
+  * inputs are copied into static buffers; outputs / losses are the capture's own tensors (valid until the next replay);
+  * every buffer the sequence allocates comes from the graph's private pool, and the sequence re-makes, at every replay,
+    everything it derives from the parameters (weight norm, packed weights): caches filled by eager passes are not
+    consulted while recording, entries made by the capture are (the discriminators' weights are normalised and packed
+    once per recorded batch, as in the eager loop);
+  * device tables (weight-norm records, pack jobs, loss items) are written ONCE, eagerly, right after the capture --
+    their contents are addresses of the graph's own tensors -- and are held by the graph.  Round 4 recorded copy nodes that
+    re-read pageable host memory at every replay instead;
+  * every tensor from OUTSIDE the pool that any launcher was handed while recording (parameters, flat gradient / moment
+    buffers, cached constant tables) is held by the graph, so its address cannot be recycled under it whatever the eager
+    code does with its caches later (VCVITS_CHECK_PTRS=1 lists them with their call sites);
+  * the weight-gradient arena of a recorded batch is its own (eager passes between replays cannot move or resize it) and
+    is left all-zero by the recorded sequence itself;
+  * per-step scalars are not baked: the optimizer's learning rate and step count (bias corrections) are read from an
+    8-byte device record refreshed before each replay (vcv_adamw_dev), dropout kernels add a device-side counter bumped
+    per replay to their baked host seed (vcv_set_seed_offset_ptr) -- fresh masks every step, the backward kernels of a
+    replay regenerate the masks of their own forward;
+  * host-side effects of a pass that later code reads are re-applied after each replay: per-parameter step counts, the
+    "received a gradient" flags, `module.logged`, derived-weight invalidation;
+  * ONE stream: `VCVITS.fit_batch` runs the eager batches, the capture and the replays on the module's own (non-null)
+    stream, and the optimizers' gradient hooks are registered under it, so the AccumulateGrad nodes of the parameters live
+    on the stream the capture records: the recorded graph is a linear chain.  Round 4 warmed up on the legacy null stream
+    and captured on a side stream: every autograd accumulation (LayerNorm / embedding / relative-position parameters: the
+    ones without a gradient sink) then forked the graph onto the null stream -- not a capturable stream -- and replays of
+    the full model raced (wrong losses from the third replay on, a GPU memory fault once eager batches were interleaved);
+  * data parallel: the bucket all-reduces the post-accumulate hooks launch while recording are part of the graph (RCCL
+    collectives are capturable; torch forks its communication stream off the capturing stream and `wait()` joins it), so
+    a replayed backward overlaps its all-reduces exactly as the eager one does.  Recording starts only after the
+    used-parameter set was frozen (FlatAdamW static mode: no host-side flag exchange left in the step);
+  * the key of a graph holds the batch shapes, the arithmetic switches and the parameter-storage epoch
+    (ops.GRAPH_EPOCH: a rebuilt optimizer, a replaced layer) -- a graph recorded for other storage is never replayed;
+    entries are LRU-bounded (`MAX_ENTRIES`) and an evicted graph releases its pool;
+  * the per-launch profiler and the dropout trace of the tests force the eager pass (their events / lists are not
+    capturable); any failure while recording disables the graph for that object (eager from then on).
+"""
 import gc
+import os
+import sys
+from collections import OrderedDict
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from .._lib import lib
 
 ENABLED = [os.environ.get("VCVITS_GRAPHS", "1") == "1"]
-# the forward + backward pass of each optimizer index as a graph too (GraphedStep below): EXPERIMENTAL, off unless
-# VCVITS_STEP_GRAPHS=1 / set_step_enabled(True) -- see the class docstring for what was measured and what is unresolved
-STEP_ENABLED = [os.environ.get("VCVITS_STEP_GRAPHS", "0") == "1"]
+# the whole batch (both optimizer passes and their AdamW steps) as one graph: on by default (VCVITS_BATCH_GRAPHS=0 keeps
+# the eager loop with the graphed no-grad generator pass)
+BATCH_ENABLED = [os.environ.get("VCVITS_BATCH_GRAPHS", os.environ.get("VCVITS_STEP_GRAPHS", "1")) == "1"]
+MAX_ENTRIES = int(os.environ.get("VCVITS_GRAPH_ENTRIES", "4"))  # graphs kept per object (distinct batch shapes), LRU
+MAX_COUNTED = 256  # distinct shapes whose repeat counts are remembered
+
+# Capture with the thread-local error mode: under the default ("global") any other thread's event query during the capture is
+# an error that kills the process -- and in a data-parallel run torch's RCCL watchdog thread polls the events of the gradient
+# all-reduces it is still retiring at about that time.  Only the capturing thread's own calls are policed.
+CAPTURE_ERROR_MODE = os.environ.get("VCVITS_CAPTURE_ERROR_MODE", "thread_local")
 
 
 def set_enabled(on):
     ENABLED[0] = bool(on)
 
 
-class GraphedNoGrad:
-    def __init__(self, fn, warmup=1):
-        self.fn, self.warmup = fn, int(warmup)
-        self.entries, self.counts = {}, {}
-        self.failed = False
-        self.replays = 0
+def set_batch_enabled(on):
+    BATCH_ENABLED[0] = bool(on)
 
-    def _key(self, batch, extra):
-        return tuple((k, tuple(v.shape), str(v.dtype), str(v.device)) for k, v in sorted(batch.items())) + tuple(extra)
+
+set_step_enabled = set_batch_enabled  # (round-4 name)
+
+
+def _no_gc_during_capture():
+    """Collect garbage NOW and keep the cyclic collector off until the capture is over (returns whether it was on).  A
+    collection that starts inside a capture can reach an earlier module's HIP graph (modules sit in reference cycles, so
+    their graphs die in the collector, not at `del`), and destroying a graph while a stream is capturing is an error raised
+    in a destructor: the process aborts (seen one full-suite run in eight: many modules with graphs in one process)."""
+    gc.collect()
+    was_on = gc.isenabled()
+    gc.disable()
+    return was_on
+
+
+def _shape_key(batch):
+    return tuple((k, tuple(v.shape), str(v.dtype), str(v.device)) for k, v in sorted(batch.items()))
+
+
+class _Recorder:
+    """Shared by GraphedNoGrad / GraphedBatch: repeat counting, the LRU of recorded graphs and the capture itself."""
+
+    what = "sequence"
+
+    def __init__(self, warmup):
+        self.warmup = int(warmup)
+        self.entries, self.counts = OrderedDict(), OrderedDict()
+        self.failed = False
+        self.replays = self.captures = 0
+
+    def _lookup(self, key):
+        """The entry of `key` (moved to the young end), or None after counting one more sighting; True when the key has now
+        been seen more than `warmup` times and should be recorded."""
+        ent = self.entries.get(key)
+        if ent is not None:
+            self.entries.move_to_end(key)
+            return ent, False
+        n = self.counts[key] = self.counts.get(key, 0) + 1
+        self.counts.move_to_end(key)
+        while len(self.counts) > MAX_COUNTED:
+            self.counts.popitem(last=False)
+        return None, n > self.warmup
+
+    def _store(self, key, ent):
+        self.entries[key] = ent
+        self.counts.pop(key, None)
+        while len(self.entries) > max(1, MAX_ENTRIES):
+            _k, old = self.entries.popitem(last=False)
+            self._release(old)
+
+    @staticmethod
+    def _release(ent):
+        g = ent.pop("graph", None)
+        ent.clear()
+        del g  # (the CUDAGraph object owns the private pool: destroying it releases the pool's memory)
+
+    def drop(self):
+        """Forget every recorded graph (parameter storage moved, module rebuilt)."""
+        while self.entries:
+            _k, old = self.entries.popitem(last=False)
+            self._release(old)
+        self.counts.clear()
+
+    def _record(self, dev, body):
+        """Run `body(cap)` under a stream capture; returns (graph, cap, result) or None after a failure."""
+        L = lib()
+        torch.cuda.synchronize()
+        gc_was_on = _no_gc_during_capture()
+        torch.cuda.empty_cache()  # (torch's capture entry does the same: done first so the segment snapshot below is final)
+        cap = _lib.Capture(dev)
+        seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        graph = torch.cuda.CUDAGraph()
+        ops.CAPTURING[0] = cap
+        L.vcv_set_seed_offset_ptr(seed.data_ptr())
+        # record ON the stream the caller is already working on when that is a real stream (VCVITS.fit_batch runs everything
+        # on the module's own stream): autograd's AccumulateGrad nodes run on the stream they were CREATED on, and a node
+        # created on another stream forks the recorded graph -- onto the legacy null stream when the eager warm-up ran there,
+        # which a capture must never touch (torch warns "may break CUDA graph capture"; on this stack the capture went
+        # through and the replays raced: round 4's memory fault).  On the null stream torch's side capture stream is used.
+        cur = torch.cuda.current_stream(dev)
+        cap_stream = cur if cur.cuda_stream != 0 else None
+        try:
+            with torch.cuda.graph(graph, stream=cap_stream, capture_error_mode=CAPTURE_ERROR_MODE):
+                out = body(cap)
+            torch.cuda.synchronize()
+            cap.flush()  # device tables of the recorded launches: written once, before the first replay
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- whatever the capture tripped over: stay eager
+            self.failed = True
+            sys.stderr.write("vcvits_amd: HIP-graph capture of the %s failed (%s: %s); running eagerly\n"
+                             % (self.what, type(e).__name__, str(e)[:300]))
+            return None
+        finally:
+            L.vcv_set_seed_offset_ptr(None)
+            ops.CAPTURING[0] = None
+            # derived weights made while recording hold no data yet (a capture records, it does not run) and belong to the graph
+            ops.invalidate_weights()
+            if gc_was_on:
+                gc.enable()
+        self.captures += 1
+        if cap.log:
+            sys.stderr.write("vcvits_amd[capture %d]: %s recorded; %d external tensors held, %d device tables\n"
+                             % (cap.id, self.what, len(cap.external), len(cap.keep)))
+        return graph, cap, seed, out
+
+
+class GraphedNoGrad(_Recorder):
+    """fn(batch) under torch.no_grad(), replayed from a HIP graph once `batch`'s shapes have been seen `warmup` + 1 times."""
+
+    what = "no-grad generator pass"
+
+    def __init__(self, fn, warmup=1):
+        super().__init__(warmup)
+        self.fn = fn
 
     def __call__(self, batch, extra=()):
         if (not ENABLED[0] or self.failed or not torch.cuda.is_available() or torch.is_grad_enabled()
                 or lib().vcv_prof_active() or ops.DROPOUT_TRACE[0] is not None or ops.CAPTURING[0] is not None):
-            return self.fn(batch)  # (inside another capture -- GraphedStep -- the pass is part of that graph)
-        key = self._key(batch, extra)
-        ent = self.entries.get(key)
+            return self.fn(batch)  # (inside another capture -- GraphedBatch -- the pass is part of that graph)
+        key = _shape_key(batch) + tuple(extra) + (ops.GRAPH_EPOCH[0],)
+        ent, record = self._lookup(key)
         if ent is None:
-            n = self.counts[key] = self.counts.get(key, 0) + 1
-            if n <= self.warmup:
+            if not record:
                 # eager warm-up: plans, device tables and allocator pools exist before the capture (one pass: the capture --
                 # tens of milliseconds -- then falls into a run's warm-up steps, not into its steady state)
                 return self.fn(batch)
@@ -68,153 +216,146 @@ class GraphedNoGrad:
         return ent["outputs"]
 
     def _capture(self, key, batch):
-        L = lib()
         dev = next(iter(batch.values())).device
         static = {k: v.clone() for k, v in batch.items()}
-        seed = torch.zeros(1, dtype=torch.int64, device=dev)
-        keep = []
-        graph = torch.cuda.CUDAGraph()
-        ops.CAPTURING[0] = keep
-        L.vcv_set_seed_offset_ptr(seed.data_ptr())
-        gc_was_on = _no_gc_during_capture()
-        try:
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_ERROR_MODE):
-                out = self.fn(static)
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001 -- whatever the capture tripped over: stay eager
-            self.failed = True
-            import sys
-            sys.stderr.write("vcvits_amd: HIP-graph capture of the no-grad generator pass failed (%s: %s); running eagerly\n"
-                             % (type(e).__name__, str(e)[:200]))
-            ops.invalidate_weights()
+        rec = self._record(dev, lambda cap: self.fn(static))
+        if rec is None:
             return None
-        finally:
-            L.vcv_set_seed_offset_ptr(None)
-            ops.CAPTURING[0] = None
-            if gc_was_on:
-                gc.enable()
-        # derived weights created while capturing hold no data yet (a capture records, it does not run)
-        ops.invalidate_weights()
-        ent = self.entries[key] = {"graph": graph, "inputs": static, "outputs": out, "seed": seed, "keep": keep}
+        graph, cap, seed, out = rec
+        ent = {"graph": graph, "inputs": static, "outputs": out, "seed": seed, "cap": cap}
+        self._store(key, ent)
         return ent
 
 
+class GraphedBatch(_Recorder):
+    """One batch of the training loop -- both optimizer passes and their AdamW steps -- as ONE HIP graph (module docstring).
 
-def _no_gc_during_capture():
-    """Collect garbage NOW and keep the cyclic collector off until the capture is over (returns whether it was on).  A
-    collection that starts inside a capture can reach an earlier module's HIP graph (modules sit in reference cycles, so
-    their graphs die in the collector, not at `del`), and destroying a graph while a stream is capturing is an error raised
-    in a destructor: the process aborts (seen one full-suite run in eight: many modules with graphs in one process)."""
-    gc.collect()
-    was_on = gc.isenabled()
-    gc.disable()
-    return was_on
+    `run(batch, extra)` returns {"g": loss, "d": loss} (static tensors, valid until the next replay) or None: the caller runs
+    the batch eagerly (shapes not seen often enough yet, profiler / dropout trace active, graphs switched off, capture
+    failed).  Eager batches may be interleaved with replays freely: a replay depends on nothing an eager batch can move."""
 
-
-# Capture with the thread-local error mode: under the default ("global") any other thread's event query during the capture is
-# an error that kills the process -- and in a data-parallel run torch's RCCL watchdog thread polls the events of the gradient
-# all-reduces it is still retiring at about that time.  Only the capturing thread's own calls are policed.
-CAPTURE_ERROR_MODE = __import__("os").environ.get("VCVITS_CAPTURE_ERROR_MODE", "thread_local")
-
-
-def set_step_enabled(on):
-    STEP_ENABLED[0] = bool(on)
-
-
-class GraphedStep:
-    """`zero_grad -> training_step(batch, idx) -> backward` of one optimizer index as ONE HIP graph (the optimizer's own
-    step stays eager: two launches whose scalar arguments -- learning rate, bias corrections -- change per step).
-
-    The reference's loop issues this pass eagerly (vits/light/vcvits.py:55-183 under Lightning's automatic optimisation);
-    here it is ~450 (generator index) / ~500 (discriminator index) launcher calls through autograd per step whose shapes,
-    addresses and order repeat, and every bf16-mode configuration is bound by the host issuing them (and the fp32 one is
-    within 20 %: a loaded host turns it host-bound).  Same validity rules as GraphedNoGrad above, plus:
-      * the backward pass runs inside the capture (torch's autograd engine keeps the capturing stream current for its
-        worker thread; the library's launches take the stream from torch per call);
-      * host-side effects of the pass that the optimizer reads are re-applied after each replay: the "received a gradient"
-        flags the post-accumulate hooks set (FlatAdamW._touched) -- hooks do not fire in a replay;
-      * the weight-gradient arena (ops._ARENA) is sized by the eager warm-up passes, so the capture neither grows nor moves
-        it; its re-zeroing is part of the captured zero_grad;
-      * dropout in a backward kernel (attention, vcv_dropout's mask regeneration) reads the same device-side seed offset as
-        its forward: one bump per replay covers both;
-      * single-process only: with a process group the gradient hooks launch collectives -- that pass stays eager.
-    Any failure while capturing disables the graph for that index (eager from then on).
-
-    State at the end of round 4 (why it is off by default): tests/test_graphed_gpu.py -- losses step for step and the
-    parameters after nine steps equal the eager loop's at reduced width (full model, f32 and bf16 mode; the benchmark's
-    vocoder module), and a captured backward regenerates the dropout mask of its own replay.  bench.py with it on: host issue
-    time per step 57 -> 25 ms (fp32 vocoder workload), 65 -> 46 ms (48k full model, one rank), but throughput -1 % on the
-    GPU-bound workloads (235.4-239.5 vs 236-241.8 utterances/s: eager steps normalise and pack the discriminators' weights
-    once per batch and reuse them in the second optimizer index; each graph has to make its own) and +1 % on the 48k one.
-    UNRESOLVED: the base-width full model at B = 32 takes a GPU memory fault when eager passes (the profiler's sampled
-    steps) are interleaved with replays; without interleaving it runs (372 utterances/s).  Until that is understood the eager
-    loop is the product path."""
+    what = "training batch"
 
     def __init__(self, module, warmup=2):
-        self.module, self.warmup = module, int(warmup)
-        self.entries, self.counts = {}, {}
-        self.failed = False
-        self.replays = 0
+        super().__init__(warmup)
+        self.module = module
 
-    def applicable(self, opt):
-        return (ENABLED[0] and STEP_ENABLED[0] and not self.failed and torch.cuda.is_available() and torch.is_grad_enabled()
-                and self.module.training and not getattr(opt, "_ddp", False) and opt.grad.is_cuda
-                and not lib().vcv_prof_active() and ops.DROPOUT_TRACE[0] is None and ops.CAPTURING[0] is None)
+    def applicable(self):
+        m = self.module
+        og, od = m.optim_g, m.optim_d
+        if not (ENABLED[0] and BATCH_ENABLED[0] and not self.failed and torch.cuda.is_available() and torch.is_grad_enabled()
+                and m.training and og is not None and od is not None and og.grad.is_cuda
+                and not lib().vcv_prof_active() and ops.DROPOUT_TRACE[0] is None and ops.CAPTURING[0] is None):
+            return False
+        for o in (og, od):
+            # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step)
+            if getattr(o, "_ddp", False) and o._static_set is None:
+                return False
+        return True
 
-    def run(self, idx, opt, batch, extra=()):
-        """The loss of the pass (a static tensor, valid until the next replay), or None: the caller runs the pass eagerly."""
-        if not self.applicable(opt):
+    def run(self, batch, extra=()):
+        if not self.applicable():
             return None
-        key = (idx,) + tuple((k, tuple(v.shape), str(v.dtype), str(v.device)) for k, v in sorted(batch.items())) + tuple(extra)
-        ent = self.entries.get(key)
+        m = self.module
+        key = _shape_key(batch) + tuple(extra) + (ops.GRAPH_EPOCH[0], id(m.optim_g), id(m.optim_d))
+        ent, record = self._lookup(key)
         if ent is None:
-            n = self.counts[key] = self.counts.get(key, 0) + 1
-            if n <= self.warmup:
+            if not record:
                 return None
-            ent = self._capture(key, idx, opt, batch)
+            ent = self._capture(key, batch)
             if ent is None:
                 return None
+        # the per-step scalars of the two recorded AdamW steps
+        deltas = []
+        for opt, ranges in ((m.optim_g, ent["ranges_g"]), (m.optim_d, ent["ranges_d"])):
+            ds = {opt._pstep[i] + 1 - st for i, st in ranges}
+            if len(ds) > 1:
+                # eager batches in between stepped a different parameter set: the recorded runs' relative step counts no
+                # longer hold -- forget this graph (it is recorded again when the shape repeats)
+                self._release(self.entries.pop(key))
+                return None
+            deltas.append(ds.pop() if ds else 0)
+        for opt, d in zip((m.optim_g, m.optim_d), deltas):
+            glr = opt.param_groups[0]["lr"]
+            if glr != opt.lr:  # (an external scheduler wrote the group's rate: FlatAdamW.step does the same)
+                opt.lr = float(glr)
+            if opt.hyper is not None:
+                ops.set_hyper(opt.hyper, opt.lr, d)
         for k, v in batch.items():
             ent["inputs"][k].copy_(v)
         ent["seed"].add_(1)
         ent["graph"].replay()
-        opt._synced = False
-        opt._touched[:] = ent["touched"]
-        self.module.logged = ent["logged"]
+        # host-side effects of the two passes
+        for opt, touched, idx in ((m.optim_g, ent["touched_g"], ent["idx_g"]), (m.optim_d, ent["touched_d"], ent["idx_d"])):
+            ps = opt._pstep
+            for i in idx:
+                ps[i] += 1
+            opt.step_count += 1
+            opt._touched[:] = touched
+            opt._synced = True
+        ops.invalidate_weights()  # the recorded AdamW steps wrote the parameters
+        m.logged = ent["logged"]
         self.replays += 1
-        return ent["loss"]
+        return ent["losses"]
 
-    def _capture(self, key, idx, opt, batch):
-        L = lib()
-        dev = opt.grad.device
+    def _capture(self, key, batch):
+        m = self.module
+        og, od = m.optim_g, m.optim_d
+        dev = og.grad.device
         static = {k: v.clone() for k, v in batch.items()}
-        seed = torch.zeros(1, dtype=torch.int64, device=dev)
-        keep = []
-        graph = torch.cuda.CUDAGraph()
-        ops.CAPTURING[0] = keep
-        L.vcv_set_seed_offset_ptr(seed.data_ptr())
-        gc_was_on = _no_gc_during_capture()
-        try:
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_ERROR_MODE):
-                opt.zero_grad()
-                loss = self.module.training_step(static, 0, idx)
-                loss.backward()
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001 -- whatever the capture tripped over: stay eager
-            self.failed = True
-            import sys
-            sys.stderr.write("vcvits_amd: HIP-graph capture of the optimizer-%d pass failed (%s: %s); running eagerly\n"
-                             % (idx, type(e).__name__, str(e)[:300]))
-            ops.invalidate_weights()
+        # the recorded batch's own weight-gradient arena: as large as the eager one has grown to, zero now and left zero by
+        # the recorded sequence (every reset zeroes what the pass before it used; the last reset is recorded explicitly)
+        eager_buf = ops._ARENA.get("buf")
+        n_arena = max(int(eager_buf.numel()) if eager_buf is not None else 0, 1 << 20)
+        arena = {"buf": torch.zeros((n_arena,), device=dev, dtype=torch.float32), "off": 0, "need": 0, "on": True}
+        for o in (og, od):  # the {lr, step delta} records of the two recorded AdamW steps: allocated (and kept) outside the pool
+            if o.hyper is None:
+                o.hyper = torch.zeros(2, device=dev, dtype=torch.int32)
+        skip_adamw = os.environ.get("VCVITS_DBG_NO_ADAMW", "0") == "1"
+        state = {}
+
+        def body(cap):
+            losses = {}
+            old_arena = ops.arena_swap(arena)
+            try:
+                for idx, opt in ((0, og), (1, od)):
+                    m._toggle(idx)
+                    opt.zero_grad()
+                    loss = m.training_step(static, 0, idx)
+                    loss.backward()
+                    if skip_adamw:  # (debug A/B: the recorded batch without its optimizer steps)
+                        opt.finish_grad_sync()
+                        opt.captured_ranges = []
+                    else:
+                        opt.step()  # (finish_grad_sync inside: the all-reduce joins are part of the graph)
+                    losses["g" if idx == 0 else "d"] = loss.detach()
+                    state["touched_%s" % ("g" if idx == 0 else "d")] = bytes(opt._touched)
+                    state["ranges_%s" % ("g" if idx == 0 else "d")] = list(opt.captured_ranges or [])
+                ops.wgrad_arena_reset()
+                if ops._ARENA.get("buf") is not arena["buf"]:
+                    cap.append(ops._ARENA.get("buf"))  # (grown while recording: allocated in the graph's pool, zeroed by it)
+            finally:
+                ops.arena_swap(old_arena)
+                for p in og.params:
+                    p.requires_grad_(True)
+                for p in od.params:
+                    p.requires_grad_(True)
+            return losses
+
+        # the recorded passes advance host-side optimizer state as an executed pass would; the first replay (right after
+        # the capture) is that pass's execution
+        snap = [(o, list(o._pstep), o.step_count) for o in (og, od)]
+        rec = self._record(dev, body)
+        for o, ps, sc in snap:
+            o._pstep, o.step_count = ps, sc
+        if rec is None:
             return None
-        finally:
-            L.vcv_set_seed_offset_ptr(None)
-            ops.CAPTURING[0] = None
-            if gc_was_on:
-                gc.enable()
-        ops.invalidate_weights()  # derived weights created while capturing hold no data (a capture records, it does not run)
-        ent = self.entries[key] = {"graph": graph, "inputs": static, "loss": loss.detach(), "seed": seed, "keep": keep,
-                                   "touched": bytes(opt._touched), "logged": dict(self.module.logged)}
+        graph, cap, seed, losses = rec
+        cap.append(arena["buf"])
+        ent = {"graph": graph, "inputs": static, "losses": losses, "seed": seed, "cap": cap, "logged": dict(m.logged),
+               "touched_g": state["touched_g"], "touched_d": state["touched_d"],
+               "ranges_g": state["ranges_g"], "ranges_d": state["ranges_d"],
+               "idx_g": [i for i, t in enumerate(state["touched_g"]) if t],
+               "idx_d": [i for i, t in enumerate(state["touched_d"]) if t]}
+        self._store(key, ent)
         return ent

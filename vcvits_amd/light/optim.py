@@ -38,16 +38,22 @@ def shutdown_flag_groups():
     _FLAG_GROUPS.clear()
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay 0.01 by default) over a flat buffer.
     Parameters are re-pointed at views of the buffer; `.grad` of every parameter is a permanent
-    view of the flat gradient buffer (autograd accumulates into it in place)."""
+    view of the flat gradient buffer (autograd accumulates into it in place).
+
+    A `torch.optim.Optimizer` (one parameter group), so what consumes the reference's `configure_optimizers`
+    (vits/light/vcvits.py:247-263 returns two torch.optim.AdamW to Lightning, which type-checks them) accepts it:
+    `param_groups[0]["lr"]` is the live learning rate (an external scheduler may write it), `step(closure)` runs the
+    closure first as Lightning's automatic optimisation does, `zero_grad()` keeps the permanent gradient views."""
 
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_mb=32,
                  process_group=None):
         params = [p for p in params]
         if not params:
             raise ValueError("FlatAdamW: empty parameter list")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         dev = params[0].device
         # reverse registration order ~ the order gradients become ready in backward, so a bucket
         # (a contiguous range of the buffer) completes early and its all-reduce overlaps the rest
@@ -72,7 +78,9 @@ class FlatAdamW:
         self.lr, self.base_lr = lr, lr
         self.betas, self.eps, self.weight_decay = tuple(betas), eps, weight_decay
         self.step_count = 0
-        self.param_groups = [{"lr": lr}]  # the reference reads optim_g.param_groups[0]['lr'] (vcvits.py:122)
+        self.hyper = None  # device record {lr, step delta} of optimizer steps recorded into a HIP graph (step())
+        self.captured_ranges = None
+        # (the reference reads optim_g.param_groups[0]['lr'], vcvits.py:122: torch's own group dict, kept in step with self.lr)
         # ---- data parallel ----
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -228,21 +236,40 @@ class FlatAdamW:
             self._pstep[i] += 1
             lo, hi, st = self.offsets[i], self.offsets[i] + p.numel(), self._pstep[i]
             if ranges and ranges[-1][1] == lo and ranges[-1][2] == st:
-                ranges[-1] = (ranges[-1][0], hi, st)
+                ranges[-1] = (ranges[-1][0], hi, st, ranges[-1][3])
             else:
-                ranges.append((lo, hi, st))
+                ranges.append((lo, hi, st, i))  # (i: the run's first parameter -- its step count stands for the run's)
         return ranges
 
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:  # (Lightning's automatic optimisation: zero_grad + training_step + backward live in the closure)
+            with torch.enable_grad():
+                loss = closure()
+        glr = self.param_groups[0]["lr"]
+        if glr != self.lr:  # an external scheduler (torch.optim.lr_scheduler / Lightning) wrote the group's rate
+            self.lr = float(glr)
         self.finish_grad_sync()
         self.step_count += 1
         if not self.flat.is_cuda:
             raise RuntimeError("FlatAdamW.step: parameters are not on the GPU (no CPU fallback)")
-        for lo, hi, st in self._update_ranges():
-            ops.adamw_step(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
-                           self.betas, self.eps, self.weight_decay, st)
+        ranges = self._update_ranges()
+        if ops.CAPTURING[0] is not None:
+            # recorded into a HIP graph (light/graphed.py): the learning rate and the step count come from a device record
+            # the host refreshes before each replay; `captured_ranges` lets the replay work out the step delta
+            if self.hyper is None:
+                self.hyper = torch.zeros(2, device=self.flat.device, dtype=torch.int32)
+            for lo, hi, st, _i in ranges:
+                ops.adamw_step_dev(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                                   self.betas, self.eps, self.weight_decay, self.hyper, st)
+            self.captured_ranges = [(i, st) for _lo, _hi, st, i in ranges]
+        else:
+            for lo, hi, st, _i in ranges:
+                ops.adamw_step(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                               self.betas, self.eps, self.weight_decay, st)
         # the kernel wrote the parameters through raw pointers: drop weights derived from them
         ops.invalidate_weights(self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel)
+        return loss
 
     def set_lr(self, lr):
         self.lr = float(lr)

@@ -1,6 +1,12 @@
-"""VCVITS training module -- the step semantics of vits/light/vcvits.py:28-283 of the reference
-without Lightning (not installed; its 1.x loop "for optimizer_idx in (0, 1): training_step ->
-backward -> step" is restated in `fit_batch`).
+"""VCVITS training module -- the step semantics of vits/light/vcvits.py:28-283 of the reference.
+
+The class IS a `pytorch_lightning.LightningModule` wherever that package imports (the reference's is:
+vits/light/vcvits.py:14,28, handed to `Trainer.fit` by train.py:85,110-113, which type-checks it) and a plain
+`nn.Module` otherwise (this image has no Lightning).  Either way it carries its own loop: Lightning-1.x's
+"for optimizer_idx in (0, 1): training_step -> backward -> step" is restated in `fit_batch`, which is what the
+benchmarks, the tests and the HIP-graph replay drive; under a Lightning Trainer the hooks below (`training_step(batch,
+batch_idx, optimizer_idx)`, `configure_optimizers` -> two `torch.optim.Optimizer`s + two schedulers,
+`validation_step`, `on_load_checkpoint`) are what it calls.
 
 Kept: attribute names (net_g, net_period_d, net_scale_d, hparams), `training_step(batch,
 batch_idx, optimizer_idx)`, `validation_step`, `configure_optimizers`, `on_load_checkpoint`, the
@@ -36,10 +42,24 @@ def _hp(v):
     return HParams(**v) if isinstance(v, dict) else v
 
 
-class VCVITS(nn.Module):
+try:  # the reference's base class, where it exists (vits/light/vcvits.py:14)
+    import pytorch_lightning as _pl
+    _Base, HAS_LIGHTNING = _pl.LightningModule, True
+except Exception:  # noqa: BLE001 -- not installed (this image) or broken: the module carries its own loop anyway
+    _Base, HAS_LIGHTNING = nn.Module, False
+
+
+class VCVITS(_Base):
     def __init__(self, **kwargs):
         super().__init__()
-        self.hparams = HParams(**{k: (v.to_dict() if isinstance(v, HParams) else v) for k, v in kwargs.items()})
+        hp = HParams(**{k: (v.to_dict() if isinstance(v, HParams) else v) for k, v in kwargs.items()})
+        if HAS_LIGHTNING:
+            # vcvits.py:31: `self.save_hyperparameters(*[k for k in kwargs])` -- Lightning collects them from this frame's
+            # `kwargs`; nested dicts become HParams first so `self.hparams.data.hop_length` reads as in the reference
+            kwargs = {k: hp[k] for k in kwargs}
+            self.save_hyperparameters(*[k for k in kwargs])
+        else:
+            self.hparams = hp
         hp = self.hparams
         self.net_g = self._build_generator()
         periods = hp.model.get("multi_period_discriminator_periods", None) or DEFAULT_PERIODS
@@ -52,11 +72,34 @@ class VCVITS(nn.Module):
         self.audio_pipeline = SpeechConversionAudioPipeline(sr=hp.data.source_sampling_rate, n_fft=hp.data.filter_length,
                                                             n_mel=hp.data.n_mel_channels, win_length=hp.data.win_length,
                                                             hop_length=hp.data.hop_length)
-        self.current_epoch = 0
-        self.global_step = 0
+        self._own_epoch = 0
+        self._own_step = 0
         self.logged = {}
         self.optim_g = self.optim_d = None
         self.scheduler_g = self.scheduler_d = None
+
+    # `current_epoch` / `global_step`: the attached Trainer's when there is one (LightningModule's read-only properties),
+    # this module's own counters otherwise (fit_batch / on_epoch_end advance them; checkpoints restore them)
+    def _trainer_or_none(self):
+        return getattr(self, "_trainer", None) if HAS_LIGHTNING else None
+
+    @property
+    def current_epoch(self):
+        t = self._trainer_or_none()
+        return t.current_epoch if t is not None else self._own_epoch
+
+    @current_epoch.setter
+    def current_epoch(self, v):
+        self._own_epoch = int(v)
+
+    @property
+    def global_step(self):
+        t = self._trainer_or_none()
+        return t.global_step if t is not None else self._own_step
+
+    @global_step.setter
+    def global_step(self, v):
+        self._own_step = int(v)
 
     def set_feature_extractor(self, extractor):
         """Plug the frozen HuBERT (or any stand-in with its `extract_features` contract) into the content encoder."""
@@ -95,7 +138,8 @@ class VCVITS(nn.Module):
         alone): the generator computes only what y_hat depends on (SynthesizerSVC.forward)."""
         d, t = self.hparams.data, self.hparams.train
         speakers = batch.get("sid", None)
-        x_feat, x_lengths = self._source(batch)
+        # (decoder_only: the content encoder does not run, so neither does the source pipeline that feeds it)
+        x_feat, x_lengths = (None, None) if decoder_only else self._source(batch)
         x_pitch, x_pitch_lengths = batch["x_pitch_values"], batch["x_pitch_lengths"]
         y_wav, y_wav_lengths = batch["y_wav_values"], batch["y_wav_lengths"]
         with torch.no_grad():
@@ -123,7 +167,32 @@ class VCVITS(nn.Module):
             # (with the dropout trace of tests/test_dropout_step_gpu.py on, the pass stays whole: the trace lists its draws)
             g = self.__dict__["_g_graph"] = GraphedNoGrad(
                 lambda b: self._generator_pass(b, decoder_only=ops.DROPOUT_TRACE[0] is None)[:2])
+        if ops.DROPOUT_TRACE[0] is None:
+            # the decoder-only pass reads the target waveform, the speaker ids and the two injected draws: only those are
+            # copied into the graph's static inputs (and only their shapes key it)
+            batch = {k: batch[k] for k in ("y_wav_values", "y_wav_lengths", "sid", "noise", "ids_slice", "z_slice",
+                                           "x_pitch_values", "x_pitch_lengths") if k in batch}
         return g(batch, extra=(self.training, ops.compute_dtype(), ops._USE_X3[0], ops.bf16_activations()))
+
+    def drop_graphs(self):
+        """Forget every recorded HIP graph of this module: they bake parameter addresses (call after anything that moves
+        parameter storage -- a rebuilt optimizer, `.to()`, a state_dict that swaps a layer's form)."""
+        for name in ("_g_graph", "_batch_graph"):
+            g = self.__dict__.pop(name, None)
+            if g is not None:
+                g.drop()
+
+    def _apply(self, fn, *args, **kwargs):
+        self.drop_graphs()
+        ops.GRAPH_EPOCH[0] += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.drop_graphs()
+        ops.GRAPH_EPOCH[0] += 1
+        out = super().load_state_dict(*args, **kwargs)
+        ops.invalidate_weights()
+        return out
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int, optimizer_idx: int):
         t = self.hparams.train
@@ -199,8 +268,29 @@ class VCVITS(nn.Module):
     def generator_parameters(self):
         return self.net_g.parameters()
 
+    def train_stream(self):
+        """The module's own HIP stream: `fit_batch` runs eager batches, graph captures and replays on it, and
+        `configure_optimizers` registers the gradient hooks under it (light/graphed.py: ONE stream).  None on the CPU."""
+        if not torch.cuda.is_available() or not next(self.parameters()).is_cuda:
+            return None
+        s = self.__dict__.get("_stream")
+        if s is None:
+            s = self.__dict__["_stream"] = torch.cuda.Stream(device=next(self.parameters()).device)
+        return s
+
     def configure_optimizers(self, process_group=None):
+        s = self.train_stream()
+        if s is None:
+            return self._configure_optimizers(process_group)
+        s.wait_stream(torch.cuda.current_stream(s.device))
+        with torch.cuda.stream(s):
+            out = self._configure_optimizers(process_group)
+        torch.cuda.current_stream(s.device).wait_stream(s)
+        return out
+
+    def _configure_optimizers(self, process_group=None):
         t = self.hparams.train
+        self.drop_graphs()  # recorded graphs bake the addresses of the flat buffers the old optimizers owned
         for old in (self.optim_g, self.optim_d):
             if old is not None:
                 old.close()  # hooks / gradient sinks of a replaced optimizer must not outlive it
@@ -233,38 +323,55 @@ class VCVITS(nn.Module):
 
     def fit_batch(self, batch, batch_idx=0, after_backward=None):
         """One batch of the reference's loop: generator step, then discriminator step.
-        `after_backward(optimizer_idx, optimizer)` is an optional probe called before each step."""
+        `after_backward(optimizer_idx, optimizer)` is an optional probe called before each step.
+        Runs on the module's own stream (train_stream), ordered after the caller's current stream on entry and before it on
+        exit -- to the caller it behaves as if it ran on the current stream."""
         if self.optim_g is None:
             self.configure_optimizers()
+        s = self.train_stream()
+        if s is None:
+            return self._fit_batch(batch, batch_idx, after_backward)
+        cur = torch.cuda.current_stream(s.device)
+        if cur.cuda_stream == s.cuda_stream:
+            return self._fit_batch(batch, batch_idx, after_backward)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            out = self._fit_batch(batch, batch_idx, after_backward)
+        cur.wait_stream(s)
+        return out
+
+    def _fit_batch(self, batch, batch_idx=0, after_backward=None):
+        if after_backward is None:
+            # the whole batch -- both passes and their AdamW steps -- replayed from ONE HIP graph once the batch shapes
+            # repeat (light/graphed.py); None: run it eagerly (shapes still new, profiler active, graphs off)
+            bg = self.__dict__.get("_batch_graph")
+            if bg is None:
+                from .graphed import GraphedBatch
+                bg = self.__dict__["_batch_graph"] = GraphedBatch(self)
+            out = bg.run(batch, extra=(ops.compute_dtype(), ops._USE_X3[0], ops._USE_X3_WGRAD[0], ops._USE_PK[0],
+                                       ops.bf16_activations(), ops._DETERMINISTIC[0]))
+            if out is not None:
+                self._own_step += 1
+                return dict(out)
         out = {}
         for idx, opt in ((0, self.optim_g), (1, self.optim_d)):
             self._toggle(idx)
-            loss = None
-            if after_backward is None:
-                # zero_grad + forward + backward replayed from a HIP graph once the batch shapes repeat (light/graphed.py)
-                sg = self.__dict__.get("_step_graph")
-                if sg is None:
-                    from .graphed import GraphedStep
-                    sg = self.__dict__["_step_graph"] = GraphedStep(self)
-                loss = sg.run(idx, opt, batch, extra=(ops.compute_dtype(), ops._USE_X3[0], ops._USE_X3_WGRAD[0], ops._USE_PK[0],
-                                                      ops.bf16_activations(), ops._DETERMINISTIC[0]))
-            if loss is None:
-                opt.zero_grad()
-                loss = self.training_step(batch, batch_idx, idx)
-                loss.backward()
-                if after_backward is not None:
-                    opt.finish_grad_sync()
-                    after_backward(idx, opt)
+            opt.zero_grad()
+            loss = self.training_step(batch, batch_idx, idx)
+            loss.backward()
+            if after_backward is not None:
+                opt.finish_grad_sync()
+                after_backward(idx, opt)
             opt.step()
             out["g" if idx == 0 else "d"] = loss.detach()
         for p in itertools.chain(self.optim_g.params, self.optim_d.params):
             p.requires_grad_(True)
-        self.global_step += 1
+        self._own_step += 1
         return out
 
     def on_epoch_end(self):
         """Lightning steps both epoch-interval schedulers at the end of every training epoch."""
-        self.current_epoch += 1
+        self._own_epoch += 1
         self.scheduler_g.step()
         self.scheduler_d.step()
 

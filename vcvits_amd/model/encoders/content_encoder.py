@@ -80,7 +80,7 @@ class HubertContentEncoder(nn.Module):
         if x.dim() == 3 and x.shape[1] == 1 and self.hubert_channels != 1:
             x = self.extract(x)
         hubert_out = self.hubert_proj(x)
-        pitch_out = F.embedding(pitch, self.emb_pitch.weight).transpose(1, -1).contiguous()  # gather: torch glue
+        pitch_out = ops.embedding_t(pitch, self.emb_pitch.weight)  # [B, proj, T]: emb_pitch(pitch).transpose(1, -1)
         if self.concat:
             out = torch.cat((hubert_out, self.pitch_proj(pitch_out)), dim=1)
         else:

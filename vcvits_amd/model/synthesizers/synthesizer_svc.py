@@ -47,7 +47,7 @@ class SynthesizerSVC(nn.Module):
 
     def _g(self, sid):
         if self.n_speakers >= 1:
-            return self.emb_g(sid).unsqueeze(-1)  # [b, h, 1]  (row gather: torch glue)
+            return ops.embedding_t(sid, self.emb_g.weight)  # [b, h, 1] = emb_g(sid).unsqueeze(-1)
         return None
 
     def forward(self, x_wav, x_wav_lengths, x_pitch, x_pitch_lengths, y_spec, y_spec_lengths, sid=None,
@@ -92,8 +92,8 @@ class SynthesizerSVC(nn.Module):
 
     def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
         assert self.n_speakers > 0, "n_speakers have to be larger than 0."
-        g_src = self.emb_g(sid_src).unsqueeze(-1)
-        g_tgt = self.emb_g(sid_tgt).unsqueeze(-1)
+        g_src = ops.embedding_t(sid_src, self.emb_g.weight)
+        g_tgt = ops.embedding_t(sid_tgt, self.emb_g.weight)
         z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g_src)
         z_p = self.flow(z, y_mask, g=g_src)
         z_hat = self.flow(z_p, y_mask, g=g_tgt, reverse=True)

@@ -88,24 +88,35 @@ def set_bf16_activations(on):
     _BF16_ACT[0] = bool(on)
 
 
-# a list while a launch sequence is being captured into a HIP graph (vcvits_amd/light/graphed.py): derived-weight caches
-# are bypassed (the graph must contain the launches that make its weights) and host arrays that captured copies read
-# from are appended to it (kept alive with the graph)
-CAPTURING = [None]
+# CAPTURING[0] is the _lib.Capture of the launch sequence being recorded into a HIP graph (vcvits_amd/light/graphed.py), None
+# in eager execution.  While it is set: weights derived from parameters are made INSIDE the sequence (caches filled by eager
+# passes are not consulted; entries made by this capture are, so the discriminators' weights are normalised and packed once
+# per recorded batch as in the eager loop), device tables are filled once after the capture instead of by recorded copy
+# nodes, and every tensor from outside the graph's pool that a launcher is handed is held by the graph (_lib.Capture).
+CAPTURING = _lib.CAPTURE
+
+
+_DBG_TABLE_NODES = __import__("os").environ.get("VCVITS_DBG_TABLE_NODES", "0") == "1"
+_DBG_NO_LOCAL_CACHE = __import__("os").environ.get("VCVITS_DBG_NO_LOCAL_CACHE", "0") == "1"
 
 
 def _upload_table(tab, dev):
-    """int64 host table (numpy) -> device tensor on the current stream.  Eager: through a pinned staging copy.  While a
-    launch sequence is being captured (CAPTURING): a plain asynchronous copy from the numpy array itself, which is kept
-    alive with the graph -- the captured copy node re-reads it at every replay, and pinning memory is not a capturable
-    operation."""
-    if CAPTURING[0] is None:
+    """int64 host table (numpy) -> device tensor.  Eager: through a pinned staging copy on the current stream.  While a
+    launch sequence is being recorded (CAPTURING): the tensor is allocated now (its address is what the recorded launches
+    bake) and filled ONCE, right after the capture (Capture.flush) -- its contents are addresses of the graph's own tensors
+    and never change between replays.  It is cut from the capture's table arena, which lives OUTSIDE the graph's pool: a pool
+    block is re-written at every replay by the earlier tensors of the sequence that shared it.  (Round 4 recorded a copy
+    node from the numpy array instead, re-read at every replay; that remains the fallback when the arena is full.)"""
+    cap = CAPTURING[0]
+    if cap is None:
         return torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
     import numpy as np
     tab = np.ascontiguousarray(tab)
-    out = torch.empty(tab.shape, device=dev, dtype=torch.int64)
-    check(lib().vcv_upload_table(ptr(out), ctypes.c_void_p(tab.ctypes.data), tab.nbytes, stream()), "vcv_upload_table")
-    CAPTURING[0].append(tab)
+    out = None if _DBG_TABLE_NODES else cap.table(tab, torch.int64, tab.shape)
+    if out is None:  # (table arena full, or the A/B switch: round 4's form -- a recorded copy node re-reading the host array)
+        out = torch.empty(tab.shape, device=dev, dtype=torch.int64)
+        check(lib().vcv_upload_table(ptr(out), ctypes.c_void_p(tab.ctypes.data), tab.nbytes, stream()), "vcv_upload_table")
+        cap.append(tab)
     return out
 
 
@@ -381,6 +392,15 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
 # launch per layer, slices of one arena are handed out and the used part is re-zeroed once per backward pass
 # (wgrad_arena_reset, called from the optimizer's zero_grad).
 _ARENA = {"buf": None, "off": 0, "need": 0, "on": False}
+
+
+def arena_swap(new):
+    """Install `new` (a dict like _ARENA) as the weight-gradient arena and return the old one's state (light/graphed.py: a
+    recorded batch has an arena of its own, so eager passes between replays cannot move or resize what it baked)."""
+    old = dict(_ARENA)
+    _ARENA.clear()
+    _ARENA.update(new)
+    return old
 
 
 def wgrad_arena_reset():
@@ -1075,7 +1095,8 @@ WEIGHT_EPOCH = [0]
 def invalidate_weights(lo=None, hi=None):
     """Parameters stored in [lo, hi) (all parameters when None) were modified behind torch's back."""
     WEIGHT_EPOCH[0] += 1
-    for e in _PARAM_REGIONS.values():
+    cap = CAPTURING[0]
+    for e in list(_PARAM_REGIONS.values()) + (list(cap.__dict__.get("regions", {}).values()) if cap is not None else []):
         if lo is None or (lo < e["hi"] and e["lo"] < hi):
             e["dirty"] = True
     if lo is None:
@@ -1090,30 +1111,47 @@ def invalidate_weights(lo=None, hi=None):
 # treatment as the weight-normed trees: their packed copies are cached until the region is written (invalidate_weights)
 # and re-made in ONE batched launch at the first use afterwards, instead of one pack launch per layer and use (110 launches of
 # ~8 us per bf16-mode step of the full model).
+# bumped whenever parameter STORAGE may have moved (an optimizer re-seating parameters into a new flat buffer, a module
+# replacing a layer): launch sequences recorded into HIP graphs bake parameter addresses and key on this counter
+GRAPH_EPOCH = [0]
+
 _PARAM_REGIONS = {}
 _PARAM_REGIONS_ON = [__import__("os").environ.get("VCVITS_PARAM_REGIONS", "1") == "1"]
 
 
 def register_param_region(flat):
+    GRAPH_EPOCH[0] += 1
     lo = flat.data_ptr()
     hi = lo + 4 * flat.numel()
     _PARAM_REGIONS[lo] = dict(lo=lo, hi=hi, packs={}, key=("region", lo, hi), shapes=(int(flat.numel()),), wbuf=flat, dirty=True)
 
 
 def unregister_param_region(flat):
+    GRAPH_EPOCH[0] += 1
     _PARAM_REGIONS.pop(flat.data_ptr(), None)
 
 
 def _stable_entry(w_ptr):
     """The cached weight-norm buffer (its cache entry) -- or the registered parameter region -- that contains address w_ptr,
-    if any."""
+    if any.  Inside a capture only entries made by that capture count (and in eager execution only eager ones): a recorded
+    sequence must contain the launches that make the weights and packs it reads."""
     if w_ptr is None:
         return None
+    cap = CAPTURING[0]
+    capid = cap.id if cap is not None else None
     for e in _WN_CACHE.values():
-        if e["lo"] <= w_ptr < e["hi"]:
+        if e["lo"] <= w_ptr < e["hi"] and e.get("cap") == capid:
             return e
-    if _PARAM_REGIONS_ON[0] and CAPTURING[0] is None:  # (a captured sequence must contain the launches that pack its weights)
-        for e in _PARAM_REGIONS.values():
+    if _PARAM_REGIONS_ON[0]:
+        regions = _PARAM_REGIONS
+        if cap is not None and _DBG_NO_LOCAL_CACHE:
+            return None
+        if cap is not None:
+            regions = cap.__dict__.get("regions")
+            if regions is None:  # the capture's own view of the regions: nothing packed yet
+                regions = cap.regions = {lo: dict(lo=e["lo"], hi=e["hi"], packs={}, key=e["key"], shapes=e["shapes"],
+                                                  wbuf=e["wbuf"], dirty=True) for lo, e in _PARAM_REGIONS.items()}
+        for e in regions.values():
             if e["lo"] <= w_ptr < e["hi"]:
                 if e["dirty"]:
                     e["dirty"] = False
@@ -1181,11 +1219,23 @@ def _replay_packs(key, ent):
         n += 1
     if n == 0:
         return
-    table = torch.empty((n * ctypes.sizeof(VcvPackJob) // 4 + 8,), device=dev, dtype=torch.float32)
-    check(L.vcv_pack_many(arr, n, ptr(table), stream()), "vcv_pack_many")
+    nwords = n * ctypes.sizeof(VcvPackJob) // 4 + 8
+    cap = CAPTURING[0]
+    table = None
+    if cap is not None and not _DBG_TABLE_NODES:
+        # recorded: the job table is finalised on the host by the call below and copied into `table` (cut from the capture's
+        # table arena, outside the graph's pool) once after the capture; the packs themselves are re-made at every replay
+        host = (ctypes.c_char * (4 * nwords))()
+        table = cap.table(host, torch.float32, (nwords,))
+    if table is not None:
+        check(L.vcv_pack_many_prepared(arr, n, ptr(table), stream()), "vcv_pack_many_prepared")
+        ctypes.memmove(host, arr, n * ctypes.sizeof(VcvPackJob))
+    else:
+        table = torch.empty((nwords,), device=dev, dtype=torch.float32)
+        check(L.vcv_pack_many(arr, n, ptr(table), stream()), "vcv_pack_many")
+        if cap is not None:
+            cap.extend((arr, table))  # the recorded upload re-reads `arr` at every replay
     ent["pack_table"] = table  # (kept alive with the entry)
-    if CAPTURING[0] is not None:
-        CAPTURING[0].extend((arr, table, arena))  # the captured upload reads `arr` at every replay
     for k, view in reg:
         ent["packs"][k] = view
     LAUNCH_COUNTS["pack_many"] = LAUNCH_COUNTS.get("pack_many", 0) + 1
@@ -1222,7 +1272,10 @@ def _wn_forward_all(vg, n):
         _WN_TABLES[key] = ent
     tab, tab_dev, total, rows = ent
     versions = tuple(t._version for t in vg)
-    hit = _WN_CACHE.get(key) if (_WN_CACHE_ON[0] and CAPTURING[0] is None) else None
+    cap = CAPTURING[0]
+    hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
+    if hit is not None and (hit.get("cap") != (cap.id if cap is not None else None) or (cap is not None and _DBG_NO_LOCAL_CACHE)):
+        hit = None  # (an eager pass's entry inside a capture, or a capture's entry in eager execution: not this sequence's)
     if hit is not None and hit["versions"] == versions and all(r() is t for r, t in zip(hit["refs"], vg)):
         wbuf, norm = hit["wbuf"], hit["norm"]  # (identity: a recycled address is not the same parameter)
     else:
@@ -1236,7 +1289,7 @@ def _wn_forward_all(vg, n):
             import weakref
             ent = dict(versions=versions, refs=tuple(weakref.ref(t) for t in vg), wbuf=wbuf, norm=norm,
                        lo=wbuf.data_ptr(), hi=wbuf.data_ptr() + 4 * total, packs={}, key=key,
-                       shapes=tuple(tuple(t.shape) for t in vg))
+                       shapes=tuple(tuple(t.shape) for t in vg), cap=cap.id if cap is not None else None)
             _WN_CACHE[key] = ent
             _replay_packs(key, ent)
     h = _WnHolder()
@@ -1654,6 +1707,19 @@ def mel_log(spec, melmat, clamp=1e-5):
 def adamw_step(p, g, m, v, lr, betas, eps, weight_decay, step):
     check(lib().vcv_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps,
                           weight_decay, step, stream()), "vcv_adamw")
+
+
+def adamw_step_dev(p, g, m, v, betas, eps, weight_decay, hyper, step_base):
+    """The same step with lr and the step delta read from the device record `hyper` (int32[2]: fp32 bits of lr, delta):
+    the form an optimizer step recorded into a HIP graph takes (light/graphed.py refreshes the record before each replay)."""
+    check(lib().vcv_adamw_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), betas[0], betas[1], eps, weight_decay,
+                              ptr(hyper), int(step_base), stream()), "vcv_adamw_dev")
+
+
+def set_hyper(hyper, lr, delta):
+    import struct
+    check(lib().vcv_set_words(ptr(hyper), 2, struct.unpack("<i", struct.pack("<f", float(lr)))[0], int(delta), 0, 0, stream()),
+          "vcv_set_words")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -2099,6 +2165,45 @@ class _NearestFn(torch.autograd.Function):
 
 def interpolate_nearest(x, size):
     return _NearestFn.apply(x, int(size))
+
+
+class _EmbeddingTFn(torch.autograd.Function):
+    """W[idx] laid out [B, C, T] (idx int64 [B, T]); the table gradient is one launch without atomics, sort or host
+    read-back, added straight into the parameter's gradient sink when it has one."""
+
+    @staticmethod
+    def forward(ctx, idx, W):
+        W = _f32c(W)
+        idx = idx.to(torch.int64).contiguous()
+        B, T = idx.shape
+        rows, C = W.shape
+        y = torch.empty((B, C, T), device=W.device, dtype=torch.float32)
+        check(lib().vcv_embedding_t_fwd(ptr(idx), ptr(W), ptr(y), B, T, C, rows, stream()), "vcv_embedding_t_fwd")
+        ctx.w_sink = _sink(W)
+        ctx.shape = (B, T, C, rows)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, T, C, rows = ctx.shape
+        if not ctx.needs_input_grad[1]:
+            return None, None
+        dy = _f32c(dy)
+        sink = ctx.w_sink
+        dW = sink[0].view(rows, C) if sink is not None else torch.empty((rows, C), device=dy.device, dtype=torch.float32)
+        check(lib().vcv_embedding_t_bwd(ptr(idx), ptr(dy), ptr(dW), B, T, C, rows, 1 if sink is not None else 0, stream()),
+              "vcv_embedding_t_bwd")
+        return None, _sunk(sink, dW)
+
+
+def embedding_t(idx, W):
+    """F.embedding(idx, W).transpose(1, -1) for idx [B, T] -> [B, C, T] (content_encoder.py:58-60); idx [B] -> [B, C, 1]
+    (emb_g(sid).unsqueeze(-1), synthesizer_svc.py:77)."""
+    if idx.dim() == 1:
+        idx = idx.view(-1, 1)
+    return _EmbeddingTFn.apply(idx, W)
 
 
 class _SliceFn(torch.autograd.Function):
