@@ -72,7 +72,7 @@ def test_oracle_attention_full_width_vs_reference_fixture(ci):
     _against_fixture(g, ci, "attn", p)
     _against_fixture(g, ci, "dx", dx)
     for n, d in dps.items():
-        if d is not None:
+        if d is not None and n != "conv_k.bias":  # (analytically zero: rounding noise on both sides, see the GPU test)
             _against_fixture(g, ci, "dp_" + n, d)
 
 
@@ -110,14 +110,20 @@ def test_hip_attention_full_width_vs_reference_and_oracle(gpu, ci):
     _close("y", y, y_o)
     _close("attn", m.attn, p_o)
     _close("dx", xg.grad, dx_o)
+    qb = float(dps_o["conv_q.bias"].abs().max())
     for n, p in m.named_parameters():
         if dps_o.get(n) is not None:
             assert p.grad is not None, n
+            if n == "conv_k.bias":
+                # analytically ZERO (a constant added to every key's logit cancels in the softmax): both sides hold fp32
+                # rounding noise of the row sums, ~1e-6 against a query-bias gradient of order 1
+                assert float(p.grad.abs().max()) <= 1e-4 * qb + 2e-5 and float(dps_o[n].abs().max()) <= 1e-4 * qb + 2e-5
+                continue
             _close("dp_" + n, p.grad, dps_o[n], tol=2e-4 if n.startswith("emb_rel") else TOL, atol=5e-6)
     # (ii) against the values the reference's own module produced
     _against_fixture(g, ci, "y", y)
     _against_fixture(g, ci, "attn", m.attn)
     _against_fixture(g, ci, "dx", xg.grad)
     for n, p in m.named_parameters():
-        if p.grad is not None and not n.startswith("emb_rel"):
+        if p.grad is not None and not n.startswith("emb_rel") and n != "conv_k.bias":
             _against_fixture(g, ci, "dp_" + n, p.grad)

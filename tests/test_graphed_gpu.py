@@ -67,6 +67,7 @@ def test_graphed_generator_pass_equals_eager(gpu, dtype):
     losses = {}
     ops.set_compute_dtype(dtype)
     try:
+        graphed.set_batch_enabled(False)  # the eager loop: its discriminator step's generator pass is the graph under test
         for mode in (False, True):
             graphed.set_enabled(mode)
             torch.manual_seed(12)
@@ -86,6 +87,7 @@ def test_graphed_generator_pass_equals_eager(gpu, dtype):
             mod.optim_d.close()
     finally:
         graphed.set_enabled(True)
+        graphed.set_batch_enabled(True)
         ops.set_compute_dtype("f32")
     tol = 2e-5 if dtype == "f32" else 2e-3  # (weight-gradient atomics / split orders move the parameters in the last bits)
     for (g0, d0), (g1, d1) in zip(losses[False], losses[True]):

@@ -51,7 +51,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     a = ap.parse_args()
     from vcvits_amd import configs, ops, synthetic
+    from vcvits_amd.light import graphed
     from vcvits_amd.light.vcvits import VCVITS, VocoderGAN
+    graphed.set_enabled(False)  # the eager loop is what issues the calls (a graph replay issues none: it replays them)
     dev = torch.device("cuda:0")
     ops.set_compute_dtype(a.dtype)
     cfg = configs.base() if a.config == "base" else configs.base_48k()

@@ -209,11 +209,13 @@ class WN(nn.Module):
             g = self.cond_layer(g)  # [B, 2H*L, 1]
         output = None
         H = self.hidden_channels
+        # the layers' conditioning gradients are disjoint slices of d(g): one shared buffer (ops.GateGradShare)
+        share = ops.GateGradShare(self.n_layers) if (g is not None and g.requires_grad and torch.is_grad_enabled()) else None
         for i in range(self.n_layers):
             # x feeds this layer's conv and its residual add: the two gradients are summed in the conv's data-gradient launch
             link = ops.ResGradLink() if (_WN_LINK and i < self.n_layers - 1 and x.requires_grad and torch.is_grad_enabled()) else None
             x_in = self.in_layers[i](x, link=(link, "dst") if link else None)
-            acts = ops.wn_gate(x_in, g, i * 2 * H)
+            acts = ops.wn_gate(x_in, g, i * 2 * H, share)
             acts = ops.dropout(acts, self.p_dropout, self.training)
             rs = self.res_skip_layers[i](acts)
             if i < self.n_layers - 1:

@@ -1725,11 +1725,21 @@ def set_hyper(hyper, lr, delta):
 # ---------------------------------------------------------------------------------------------
 # WaveNet block glue
 # ---------------------------------------------------------------------------------------------
+class GateGradShare:
+    """Shared by the `n` wn_gate calls of ONE WaveNet stack forward: every layer's conditioning gradient is its own slice
+    of d(g) [B, 2H*L, 1], so the layers write their slices into one buffer and the layer whose backward runs last hands it
+    to autograd -- instead of L full-size tensors that are zero outside one slice and L - 1 accumulation adds."""
+    __slots__ = ("n", "left", "buf")
+
+    def __init__(self, n):
+        self.n, self.left, self.buf = int(n), int(n), None
+
+
 class _WnGateFn(torch.autograd.Function):
     """acts = tanh(xin[:, :H] + g_l[:H]) * sigmoid(xin[:, H:] + g_l[H:]);  g: [B, 2H*L, 1] or None."""
 
     @staticmethod
-    def forward(ctx, xin, g, goff):
+    def forward(ctx, xin, g, goff, share=None):
         xin, g = _f32c(xin), _f32c(g)
         B, H2, T = xin.shape
         H = H2 // 2
@@ -1737,7 +1747,7 @@ class _WnGateFn(torch.autograd.Function):
         acts = torch.empty((B, H, T), device=xin.device, dtype=torch.float32)
         check(lib().vcv_wn_gate_fwd(ptr(xin), ptr(g), gstride, goff, ptr(acts), B, H, T, stream()),
               "vcv_wn_gate_fwd")
-        ctx.goff = goff
+        ctx.goff, ctx.share = goff, share
         ctx.save_for_backward(xin, g)
         return acts
 
@@ -1753,14 +1763,26 @@ class _WnGateFn(torch.autograd.Function):
                                     stream()), "vcv_wn_gate_bwd")
         dg = None
         if g is not None and ctx.needs_input_grad[1]:
-            dg = torch.zeros_like(g)
+            sh = ctx.share
+            if sh is None:
+                dg = torch.zeros_like(g)
+            else:
+                if sh.buf is None:
+                    sh.buf, sh.left = torch.zeros_like(g), sh.n
+                dg = sh.buf
             check(lib().vcv_row_sum(ptr(dxin), ptr(dg), B * H2, T, H2, gstride, ctx.goff, stream()),
                   "vcv_row_sum")
-        return dxin, dg, None
+            if sh is not None:
+                sh.left -= 1
+                if sh.left > 0:
+                    dg = None  # (a later layer's backward of this stack returns the buffer)
+                else:
+                    sh.buf = None
+        return dxin, dg, None, None
 
 
-def wn_gate(xin, g, goff):
-    return _WnGateFn.apply(xin, g, goff)
+def wn_gate(xin, g, goff, share=None):
+    return _WnGateFn.apply(xin, g, goff, share)
 
 
 class _WnResSkipFn(torch.autograd.Function):
