@@ -196,6 +196,8 @@ int vcv_conv_x3_run(const VcvConvArgs* args, float* pack_ws, float* scratch_ws, 
 int vcv_conv_x3_set_terms(int n);
 int vcv_conv_x3_get_terms(void);
 int vcv_conv_x3_set_all(int all);
+/* tuning probe: fix the tile variant (0..6; -1 = the library's choice), taps per stage (1 | 2) and channel-group split (>= 2 | -1) */
+int vcv_conv_x3_set_variant(int variant, int js, int ks);
 
 /*
  * Weight gradient of the same family (torch autograd of the call sites above):
@@ -244,6 +246,8 @@ int vcv_wgrad_bf16(const VcvWgradArgs* args, float* scratch, int64_t scratch_flo
  * a fixed order) */
 int64_t vcv_wgrad_x3_scratch(const VcvWgradArgs* args);
 int vcv_wgrad_x3(const VcvWgradArgs* args, float* scratch, int64_t scratch_floats, void* stream);
+/* tuning probe: fix the tile candidate (0..5, -1 = first that fits) and the reduction split (> 0, -1 = cost model) */
+int vcv_wgrad_bf16_set_force(int cand, int z);
 
 /* Thin convolutions (HBM-bound, no MFMA): a conv with ONE output channel (discriminator conv_post
  * 1024->1, discriminator.py:25,61; generator conv_post 32->1 + tanh) and the weight gradient of a

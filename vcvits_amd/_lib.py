@@ -96,7 +96,7 @@ EXPORTS = [
     "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16", "vcv_act_grad_bias", "vcv_conv_pk_plan", "vcv_conv_pk_run",
     "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_rel_attn_bwd2", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause", "vcv_conv_x3_pack_job", "vcv_conv_pk_pack_job", "vcv_conv_bf16_pack_job", "vcv_pack_many", "vcv_upload_table",
     "vcv_conv_bf16io_plan", "vcv_conv_bf16io_run", "vcv_cast_f32_x16", "vcv_cast_x16_f32", "vcv_conv_m1_x16_fwd",
-    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_bwd",
+    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force",
 ]
 
 
@@ -184,6 +184,8 @@ _ARGTYPES = {
     "vcv_conv_x3_set_terms": [_I],
     "vcv_conv_x3_get_terms": [],
     "vcv_conv_x3_set_all": [_I],
+    "vcv_conv_x3_set_variant": [_I, _I, _I],
+    "vcv_wgrad_bf16_set_force": [_I, _I],
     "vcv_wgrad_bf16_scratch": [ctypes.POINTER(VcvWgradArgs)],
     "vcv_wgrad_x3_scratch": [ctypes.POINTER(VcvWgradArgs)],
     "vcv_wgrad_x3": [ctypes.POINTER(VcvWgradArgs), _P, _L, _P],

@@ -416,9 +416,29 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
 
 // variants: 0: 128x256 (8 MFMA waves of 2x2 tiles)   1: 128x128 (8 waves of 2x1)   2: 256x128 (8 waves of 2x2)   3: 64x256 (8 waves of 1x2)
 //           4: 64x128 (8 waves of 1x1)   5: 32x256 (8 waves of 1x1)   6: 64x512 (8 waves of 1x4)
+int g_force_variant = [] { const char* e = getenv("VCVITS_X3_VARIANT"); return e ? atoi(e) : -1; }();  // tuning probe: -1 = choose
+int g_force_js = -1, g_force_ks = -1;
+
 bool choose(const VcvConvArgs& a, Plan& pl) {
   const int U = a.Q * a.P;
   if (U < 96) return false;
+  if (g_force_variant >= 0) {  // tools/x3_variant_sweep.py: one fixed tile shape for every launch that can take it
+    static const int VBM[7] = {128, 128, 256, 64, 64, 32, 64}, VBN[7] = {256, 128, 128, 256, 128, 256, 512};
+    const int v = g_force_variant;
+    if (v > 6 || a.Mg < (v == 5 ? 32 : VBM[v] / 2 + 1)) return false;
+    const int js = (g_force_js == 2 && (v == 0 || v == 1) && vcv_cdiv(a.K, a.phases > 1 ? a.phases : 1) >= 2) ? 2 : 1;
+    if (!make_plan(a, VBM[v], VBN[v], 8, pl, v == 2 ? 2 : NRING_DEF, js)) return false;
+    pl.variant = v;
+    const int nph0 = a.phases > 1 ? a.phases : 1;
+    if (g_force_ks >= 2 && nph0 == 1 && pl.g.nch >= 2 * g_force_ks) {
+      pl.g.ks = g_force_ks;
+      pl.scratch_floats = (size_t)g_force_ks * a.B * a.Mg * U;
+    }
+    static const bool no_vec0 = getenv("VCVITS_PK_NO_VEC") != nullptr;
+    pl.g.vec = (!no_vec0 && nph0 == 1 && a.os == 1 && a.oo == 0 && (!a.mask || a.P == 1) &&
+                (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
+    return true;
+  }
   const int nph = a.phases > 1 ? a.phases : 1;
   auto blocks = [&](int bm, int bn) { return (long long)a.B * vcv_cdiv(U, bn) * vcv_cdiv(a.Mg, bm) * nph; };
   auto eff = [&](int bm, int bn) {
@@ -550,6 +570,14 @@ extern "C" int vcv_conv_x3_set_all(int all) {
   return VCV_OK;
 }
 extern "C" int vcv_conv_x3_get_all(void) { return g_all; }
+// Tuning probe (tools/x3_variant_sweep.py): fix the tile variant (0..6: 128x256, 128x128, 256x128, 64x256, 64x128, 32x256,
+// 64x512; -1 = the library's choice), the taps per stage (2 or 1) and the channel-group split (>= 2, or -1) of every launch.
+extern "C" int vcv_conv_x3_set_variant(int variant, int js, int ks) {
+  g_force_variant = variant;
+  g_force_js = js;
+  g_force_ks = ks;
+  return VCV_OK;
+}
 
 // Same calling convention as vcv_conv_pk_plan / vcv_conv_pk_run: out[0] = size of the packed-weight buffer in 4-byte
 // words, out[1] = floats of per-launch scratch, out[2] = signature of the pack layout.

@@ -393,6 +393,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_finish_kernel(const float* __r
   }
 }
 
+int g_force_cand = -1, g_force_z = -1;  // tuning probe (tools/wgrad_variant_sweep.py): -1 = the library's choice
+
 constexpr int MAXT = 2;
 constexpr int MAXT_WS = 3;  // staging tasks per producer wave of a split-operand launch
 
@@ -449,6 +451,10 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
     const double cost = rounds * ((double)((total + z - 1) / z) + 2.0) / (double)occ + 0.02 * z;  // + slab traffic
     if (cost < best - 1e-9) best = cost, Z = z;
   }
+  if (g_force_z > 0) {
+    Z = g_force_z;
+    while (Z > 1 && ((size_t)Z * n > (size_t)scratch_floats || Z > total)) --Z;
+  }
   g.Z = (int)Z;
   void (*kern)(const VcvWgradArgs, const WbGeom, float*);
   static const bool ws1 = getenv("VCVITS_WGRAD_BF16_NO_WS") == nullptr;
@@ -486,6 +492,7 @@ bool pick(const VcvWgradArgs& a, Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
   // the wide-period layouts) falls through to a narrower channel tile
   static const int cand[6][3] = {{4, 2, 1}, {4, 1, 2}, {2, 2, 2}, {2, 1, 4}, {1, 2, 4}, {1, 1, 8}};
   for (int i = 0; i < 6; ++i) {
+    if (g_force_cand >= 0 && i != g_force_cand) continue;
     const int bm = 32 * cand[i][0], bc = 32 * cand[i][1];
     if (bm > 32 && bm > a.Mg) continue;
     if (bc > 32 && bc > ((a.Cg + 31) & ~31)) continue;
@@ -543,6 +550,14 @@ int run(const VcvWgradArgs* a, float* scratch, int64_t scratch_floats, void* str
 }
 
 }  // namespace
+
+// Tuning probe: fix the tile candidate (0..5: 128x64, 128x32 x2, 64x64 x2, 64x32 x4, 32x64 x4, 32x32 x8; -1 = first that fits)
+// and the reduction split Z (> 0; -1 = the cost model) of every launch.
+extern "C" int vcv_wgrad_bf16_set_force(int cand, int z) {
+  g_force_cand = cand;
+  g_force_z = z;
+  return VCV_OK;
+}
 
 // Scratch floats the launch wants (0: not eligible -> the caller uses vcv_conv_wgrad).  The kernel takes any scratch
 // >= Mg*Cg*K floats and splits the reduction as far as the scratch allows.
