@@ -422,10 +422,40 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     dt = time.perf_counter() - t0
     calls = (_lib.CALLS[0] - calls0) / max(steps, 1)
     bg = module.__dict__.get("_batch_graph") if module is not None else None
-    host = {"issue_ms": 1e3 * t_issue / max(steps, 1), "cpu_ms": 1e3 * c_issue / max(steps, 1),
-            "graph_replays": (bg.replays - replays0) if bg is not None else 0,
-            "issue_ms_unprofiled_step": round(1e3 * t_replay / n_replay, 2) if n_replay else None,
-            "issue_ms_profiled_eager_step": round(1e3 * t_eager / n_eager, 2) if n_eager else None}
+    n_graph = (bg.replays - replays0) if bg is not None else 0
+    # Host time to ISSUE one step with the device idle -- what the host itself costs.  Inside the timed region the host runs
+    # ahead of the GPU until the launch queue is full and then blocks at the device's pace (a replayed batch is ~1,000-1,800
+    # queued packets), so the wall time per issue there measures back-pressure, not host work; both are reported.
+    unloaded = {}
+    if module is not None:
+        from vcvits_amd.light import graphed
+
+        def issue_once():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run()
+            d = time.perf_counter() - t1
+            torch.cuda.synchronize()
+            return 1e3 * d
+        if prof:
+            L.vcv_prof_pause(1)
+        if n_graph > 0:
+            unloaded["graph"] = min(issue_once() for _ in range(3))
+        was = graphed.BATCH_ENABLED[0]
+        graphed.set_batch_enabled(False)
+        unloaded["eager"] = min(issue_once() for _ in range(2))
+        graphed.set_batch_enabled(was)
+    n_eager_steps = steps - n_graph
+    if unloaded:
+        mix = (n_graph * unloaded.get("graph", 0.0) + n_eager_steps * unloaded["eager"]) / max(steps, 1)
+    else:
+        mix = 1e3 * t_issue / max(steps, 1)
+    host = {"issue_ms": mix, "cpu_ms": 1e3 * c_issue / max(steps, 1), "graph_replays": n_graph,
+            "wall_ms_in_timed_region": 1e3 * t_issue / max(steps, 1),
+            "issue_ms_unloaded_graph_step": round(unloaded["graph"], 2) if "graph" in unloaded else None,
+            "issue_ms_unloaded_eager_step": round(unloaded["eager"], 2) if "eager" in unloaded else None,
+            "wall_ms_unprofiled_step": round(1e3 * t_replay / n_replay, 2) if n_replay else None,
+            "wall_ms_profiled_eager_step": round(1e3 * t_eager / n_eager, 2) if n_eager else None}
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -489,7 +519,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     if f32_split is not None:
         ops.set_f32_split(True, terms=6)
     torch.cuda.empty_cache()
-    return {"arith": arith, "dt": dt, "roof": roof, "host_issue_ms": 1e3 * t_issue / max(steps, 1), "host": host, "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
+    return {"arith": arith, "dt": dt, "roof": roof, "host_issue_ms": host["issue_ms"], "host": host, "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
             "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world}
 
 
@@ -542,13 +572,19 @@ def make_line(r):
                                if workload == "full" else {}),
                             # host side of a step: time this process needed to ISSUE one step's launches (the step is
                             # GPU-bound while this stays below ms_per_step) and the library launcher calls it made
+                            # host side of a step.  A training batch whose shapes repeat is ONE HIP-graph replay
+                            # (vcvits_amd/light/graphed.py); the steps that carry per-launch events (every fourth) run the
+                            # eager loop.  host_issue_ms_per_step = host time to issue a step with the device idle (measured
+                            # after the timed region: graph replay / eager step), weighted by the timed region's mix of the
+                            # two; host_wall_ms_per_step_in_timed_region is the wall time the issuing thread spent per step
+                            # inside the timed region, where it runs ahead until the launch queue is full and then waits for
+                            # the device (back-pressure, not host work)
                             "host_issue_ms_per_step": round(r["host_issue_ms"], 2),
-                            "host_cpu_ms_per_step": round(r["host"]["cpu_ms"], 2),
-                            # a training batch whose shapes repeat is ONE HIP-graph replay (vcvits_amd/light/graphed.py); the
-                            # steps that carry per-launch events (every fourth) run the eager loop -- the two kinds apart:
+                            "host_issue_ms_graph_replay_step": r["host"]["issue_ms_unloaded_graph_step"],
+                            "host_issue_ms_eager_step": r["host"]["issue_ms_unloaded_eager_step"],
                             "hip_graph_replays_in_timed_steps": r["host"]["graph_replays"],
-                            "host_issue_ms_graph_replay_step": r["host"]["issue_ms_unprofiled_step"],
-                            "host_issue_ms_profiled_eager_step": r["host"]["issue_ms_profiled_eager_step"],
+                            "host_wall_ms_per_step_in_timed_region": round(r["host"]["wall_ms_in_timed_region"], 2),
+                            "host_cpu_ms_per_step_in_timed_region": round(r["host"]["cpu_ms"], 2),
                             "library_launcher_calls_per_step": round(r["calls"], 1),
                             "arithmetic": (r["arith"] if dtype == "f32" else
                                            "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},

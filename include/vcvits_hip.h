@@ -436,6 +436,12 @@ int vcv_layernorm_c_fwd(const float* x, const float* y, const float* gamma, cons
 int vcv_layernorm_c_bwd(const float* x, const float* y, const float* gamma, const float* mean,
                         const float* rstd, const float* dout, float* dx, float* dgamma, float* dbeta, int B,
                         int C, int T, void* stream);
+/* The same with a caller-owned workspace for the partial sums of the register-resident form (C = 128 / 256):
+ * vcv_layernorm_c_bwd_scratch floats (0: none needed).  vcv_layernorm_c_bwd keeps a library-owned scratch per device. */
+int64_t vcv_layernorm_c_bwd_scratch(int B, int C, int T);
+int vcv_layernorm_c_bwd_ws(const float* x, const float* y, const float* gamma, const float* mean, const float* rstd,
+                           const float* dout, float* dx, float* dgamma, float* dbeta, int B, int C, int T,
+                           float* scratch, int64_t scratch_floats, void* stream);
 
 /* ---- banded relative-position softmax (relative_attention_transformer.py:157-180).
  * S,P,Pt,dP,dSt: [B*H, T, T]; q,dO,dqband: [B, H*dk, T]; embk/embv: [2w+1, dk]; mask [B,T]. ---- */

@@ -221,6 +221,7 @@ def _static_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vcvits_amd.light.optim import FlatAdamW
+    FlatAdamW.CHECK_EVERY = 2  # (the periodic one-byte check of the frozen set: every second step here, 64 in production)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
     extra = torch.nn.Linear(8, 1)  # used from step 5 on by rank 1 only: a change of the frozen set
@@ -242,10 +243,11 @@ def _static_worker(rank, world, port, out):
             break
         counts.append(opt.flag_exchanges)
     out[rank] = (counts, err, opt._static_set is not None)
-    dist.destroy_process_group()  # (no barrier: the rank that raised has left the lock step)
+    dist.barrier()  # (both ranks raised at the same check: they are still in lock step)
+    dist.destroy_process_group()
 
 
-def test_flag_exchange_stops_after_agreement_and_a_later_change_raises():
+def test_flag_exchange_stops_after_agreement_and_a_later_change_raises_on_every_rank():
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
@@ -254,8 +256,9 @@ def test_flag_exchange_stops_after_agreement_and_a_later_change_raises():
     n = FlatAdamW.STATIC_AFTER
     c0, e0, f0 = out[0]
     c1, e1, f1 = out[1]
-    # the exchange ran in the first STATIC_AFTER steps only; rank 0 (whose set never changes) runs all six steps without
-    # another collective, rank 1 is told that its set changed instead of silently diverging
-    assert c0[:n + 2] == list(range(1, n + 1)) + [n, n] and f0 and f1, (c0, c1)
-    assert e0 is None and c0[-1] == n
-    assert e1 is not None and "static-graph" in e1, e1
+    # the per-step exchange ran in the first STATIC_AFTER steps only; afterwards one byte every CHECK_EVERY (= 2 here) steps.
+    # Rank 1's set changes at step 5, which is a check step: BOTH ranks are told (rank 0 would otherwise sit in its next
+    # collective until the watchdog fires), rank 1's message says it was the one
+    assert c0 == c1 == [1, 2, 2, 3, 3] and f0 and f1, (c0, c1)
+    assert e0 is not None and "static-graph" in e0 and "on this rank" not in e0, e0
+    assert e1 is not None and "static-graph" in e1 and "on this rank" in e1, e1

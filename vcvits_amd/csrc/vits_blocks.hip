@@ -818,26 +818,23 @@ layernorm_c_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict_
   if (i < C) dgamma[i] = v; else dbeta[i - C] = v;
 }
 
-extern "C" int vcv_layernorm_c_bwd(const float* x, const float* y, const float* gamma, const float* mean,
-                                   const float* rstd, const float* dout, float* dx, float* dgamma, float* dbeta,
-                                   int B, int C, int T, void* stream) {
+// Workspace floats vcv_layernorm_c_bwd_ws wants for (B, C, T): 0 = none (the atomics form).
+extern "C" int64_t vcv_layernorm_c_bwd_scratch(int B, int C, int T) {
+  static const bool regs_on = [] { const char* e = getenv("VCVITS_LN_REGS"); return !(e && e[0] == '0'); }();
+  if (!regs_on || (C != 128 && C != 256) || B <= 0 || T <= 0) return 0;
+  return (int64_t)vcv_cdiv(T, 64) * B * 2 * C;
+}
+
+// C = 128 / 256: the register-resident form; its per-workgroup partial rows go to `scratch` (>= vcv_layernorm_c_bwd_scratch
+// floats, caller-owned: per call, so two devices or two streams never share it) and are consumed by the reduce launch.
+extern "C" int vcv_layernorm_c_bwd_ws(const float* x, const float* y, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dout, float* dx, float* dgamma, float* dbeta,
+                                      int B, int C, int T, float* scratch, int64_t scratch_floats, void* stream) {
   if (!x || !gamma || !mean || !rstd || !dout || !dx || !dgamma || !dbeta || B <= 0 || C <= 0 || T <= 0)
     return VCV_EINVAL;
-  // C = 128 / 256: the register-resident form; its per-workgroup partial rows live in a library-owned scratch (grown on
-  // demand, one per process: launches on one stream are ordered, and the partials are consumed by the next launch)
-  static const bool regs_on = [] { const char* e = getenv("VCVITS_LN_REGS"); return !(e && e[0] == '0'); }();
-  if (regs_on && (C == 128 || C == 256)) {
-    static float* scratch = nullptr;
-    static size_t scratch_floats = 0;
+  const int64_t need = vcv_layernorm_c_bwd_scratch(B, C, T);
+  if (need > 0 && scratch && scratch_floats >= need) {
     const int nwg = vcv_cdiv(T, 64) * B;
-    const size_t need = (size_t)nwg * 2 * C;
-    if (need > scratch_floats) {
-      // (the old buffer may still be read by an enqueued reduce: keep it -- a few hundred KB, grown a handful of times)
-      float* nb = nullptr;
-      if (hipMalloc((void**)&nb, need * 2 * sizeof(float)) != hipSuccess) return VCV_EHIP;
-      scratch = nb;
-      scratch_floats = need * 2;
-    }
     if (C == 256)
       hipLaunchKernelGGL(layernorm_c_bwd_regs_kernel<64>, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, mean, rstd, dout, dx, scratch, T);
     else
@@ -850,6 +847,30 @@ extern "C" int vcv_layernorm_c_bwd(const float* x, const float* y, const float* 
   hipLaunchKernelGGL(layernorm_c_bwd_kernel, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, mean, rstd,
                      dout, dx, dgamma, dbeta, C, T);
   return vcv_check_launch();
+}
+
+// The same without a caller workspace (kept for ABI users of rounds 3-4): the register-resident form's partial rows live in a
+// scratch keyed by the current DEVICE (grown on demand, old buffers kept: an enqueued reduce may still read them).  Launches
+// of one device on different streams would share it -- callers that use several streams pass their own (_ws above).
+extern "C" int vcv_layernorm_c_bwd(const float* x, const float* y, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dout, float* dx, float* dgamma, float* dbeta,
+                                   int B, int C, int T, void* stream) {
+  const int64_t need = vcv_layernorm_c_bwd_scratch(B, C, T);
+  float* ws = nullptr;
+  if (need > 0) {
+    static float* scratch[16] = {};
+    static int64_t floats[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return VCV_EHIP;
+    if (need > floats[dev]) {
+      float* nb = nullptr;
+      if (hipMalloc((void**)&nb, (size_t)need * 2 * sizeof(float)) != hipSuccess) return VCV_EHIP;
+      scratch[dev] = nb;
+      floats[dev] = need * 2;
+    }
+    ws = scratch[dev];
+  }
+  return vcv_layernorm_c_bwd_ws(x, y, gamma, mean, rstd, dout, dx, dgamma, dbeta, B, C, T, ws, need, stream);
 }
 
 extern "C" int vcv_rel_softmax_fwd(const float* S, const float* q, const float* embk, const float* mask,

@@ -293,6 +293,7 @@ class GraphedBatch(_Recorder):
             opt.step_count += 1
             opt._touched[:] = touched
             opt._synced = True
+            opt.static_check()  # (data parallel: the periodic "did any rank's used-parameter set change" byte)
         ops.invalidate_weights()  # the recorded AdamW steps wrote the parameters
         m.logged = ent["logged"]
         self.replays += 1

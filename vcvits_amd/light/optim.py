@@ -97,6 +97,8 @@ class FlatAdamW(torch.optim.Optimizer):
         # set differs raises (the other ranks no longer take part in an exchange).  VCVITS_DDP_STATIC=0 exchanges every step.
         self._static_ok = os.environ.get("VCVITS_DDP_STATIC", "1") == "1"
         self._static_set = None
+        self._static_steps = 0
+        self._violation = False
         self._agree_steps = 0
         self.flag_exchanges = 0  # (observable: tests / bench)
         if self._ddp:
@@ -193,10 +195,12 @@ class FlatAdamW(torch.optim.Optimizer):
         # OR-ed across the group (torch DDP reduces its used-parameter bitmap for the same reason).
         if self._ddp:  # (also in a forced 1-rank group, so that the single-GPU tests run this collective)
             if self._static_set is not None:
+                # frozen set: no per-step exchange.  A rank whose local set changes must not raise on its own -- its peers
+                # have no exchange left in the step and would sit in the next collective until the RCCL watchdog fires --
+                # so the violation is remembered and surfaced on EVERY rank at the next periodic check (static_check).
                 if bytes(self._touched) != self._static_set:
-                    raise RuntimeError("FlatAdamW: the set of parameters that received a gradient changed after it was "
-                                       "frozen (static-graph mode); set VCVITS_DDP_STATIC=0 for models whose used-parameter "
-                                       "set varies from step to step")
+                    self._violation = True
+                self.static_check()
                 return
             n = len(self._touched)
             # one MAX all-reduce of [flags, 1 - flags]: the first half is the OR over ranks, the second half NOT(AND) --
@@ -213,6 +217,25 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._static_set = bytes(self._touched)
 
     STATIC_AFTER = 2  # steps of cross-rank agreement before the used-parameter set is frozen
+    CHECK_EVERY = 64  # frozen set: every this many steps the ranks exchange one "my set changed" byte (host side)
+
+    def static_check(self, steps=1):
+        """Count `steps` optimizer steps under the frozen used-parameter set; every CHECK_EVERY of them all ranks exchange one
+        byte over the host-side channel and ALL raise if any rank saw its set change (light/graphed.py calls this for the
+        steps a graph replay stands for)."""
+        if not self._ddp or self._static_set is None:
+            return
+        before = self._static_steps // self.CHECK_EVERY
+        self._static_steps += int(steps)
+        if self._static_steps // self.CHECK_EVERY == before:
+            return
+        flag = torch.tensor([1 if self._violation else 0], dtype=torch.uint8)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._flag_pg)
+        self.flag_exchanges += 1
+        if int(flag.item()):
+            raise RuntimeError("FlatAdamW: on at least one rank the set of parameters that received a gradient changed after "
+                               "it was frozen (static-graph mode)%s; set VCVITS_DDP_STATIC=0 for models whose "
+                               "used-parameter set varies from step to step" % (" -- on this rank" if self._violation else ""))
 
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -288,6 +311,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 "exp_avg_sq": self.exp_avg_sq.clone(), "param_steps": list(self._pstep)}
 
     def load_state_dict(self, sd):
+        # (a restored run re-learns its used-parameter set: the frozen one belonged to the run that saved)
+        self._static_set, self._agree_steps, self._static_steps, self._violation = None, 0, 0, False
         self.step_count = int(sd["step"])
         self.set_lr(sd["lr"])
         self.exp_avg.copy_(sd["exp_avg"])

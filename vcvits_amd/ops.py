@@ -1928,8 +1928,11 @@ class _LayerNormCFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(gamma)
-        check(lib().vcv_layernorm_c_bwd(ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dout), ptr(dx),
-                                        ptr(dgamma), ptr(dbeta), B, C, T, stream()), "vcv_layernorm_c_bwd")
+        # (the partial sums of the register-resident form go to a workspace of this call: nothing shared between streams / devices)
+        nws = lib().vcv_layernorm_c_bwd_scratch(B, C, T)
+        ws = torch.empty((nws,), device=x.device, dtype=torch.float32) if nws > 0 else None
+        check(lib().vcv_layernorm_c_bwd_ws(ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dout), ptr(dx),
+                                           ptr(dgamma), ptr(dbeta), B, C, T, ptr(ws), nws, stream()), "vcv_layernorm_c_bwd_ws")
         return dx, (dx if ctx.has_y else None), dgamma, dbeta, None
 
 
