@@ -27,7 +27,7 @@ def test_step_graph_tests_in_child_process(gpu):
                        timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
-    assert "7 passed" in out, out[-1500:]
+    assert "8 passed" in out, out[-1500:]
 
 
 def _cfg(p_dropout):
@@ -306,6 +306,57 @@ def test_graphed_batch_follows_a_learning_rate_change_and_a_rebuilt_optimizer(gp
         assert abs(g0 - g1) <= 5e-5 * abs(g0) and abs(d0 - d1) <= 5e-5 * abs(d0), (res[False][0], res[True][0])
     lr = float(cfg["train"]["learning_rate"])
     assert float((res[False][1] - res[True][1]).abs().max()) <= 2.5 * lr * 12 + 1e-4 * float(res[False][1].abs().max())
+
+
+@step_graph
+def test_graphed_batch_records_the_bucket_all_reduces(gpu):
+    """Data parallel: the bucket all-reduces launched by the gradient hooks while recording are part of the graph and the
+    replayed batches follow the eager loop -- on the one-GPU box with a forced ONE-rank RCCL group (VCVITS_FORCE_DDP=1: the
+    hooks, the forked communication stream, wait() inside the recorded step(); the collectives themselves move nothing)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    from vcvits_amd import configs, synthetic
+    from vcvits_amd.light import graphed
+    from vcvits_amd.light.optim import shutdown_flag_groups
+    from vcvits_amd.light.vcvits import VocoderGAN
+    os.environ.update({"VCVITS_FORCE_DDP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29641"})
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg = configs.base()
+        cfg["model"].update({"inter_channels": 16, "upsample_initial_channel": 32, "multi_period_discriminator_periods": [2, 3]})
+        cfg["data"]["n_mel_channels"] = 40
+        cfg["train"]["segment_size"] = 4096
+        torch.manual_seed(5)
+        sd = copy.deepcopy(VocoderGAN(**cfg).state_dict())
+        batch = {k: v.to(gpu) for k, v in synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3).items()}
+        res = {}
+        for mode in (False, True):
+            graphed.set_step_enabled(mode)
+            mod = VocoderGAN(**cfg)
+            mod.load_state_dict(sd)
+            mod = mod.to(gpu)
+            mod.configure_optimizers()
+            assert mod.optim_g._ddp and mod.optim_d._ddp and len(mod.optim_d._buckets) >= 1
+            ls = []
+            for _ in range(10):
+                out = mod.fit_batch(batch)
+                ls.append((float(out["g"]), float(out["d"])))
+            res[mode] = ls
+            if mode:
+                sg = mod.__dict__["_batch_graph"]
+                # (recording waits for the frozen used-parameter set: two steps of agreement, then three sightings)
+                assert not sg.failed and sg.replays >= 4, (sg.failed, sg.replays)
+            mod.optim_g.close()
+            mod.optim_d.close()
+        for (g0, d0), (g1, d1) in zip(res[False], res[True]):
+            assert abs(g0 - g1) <= 5e-5 * abs(g0) and abs(d0 - d1) <= 5e-5 * abs(d0), (res[False], res[True])
+    finally:
+        graphed.set_step_enabled(True)
+        os.environ.pop("VCVITS_FORCE_DDP", None)
+        shutdown_flag_groups()
+        dist.destroy_process_group()
 
 
 @step_graph
