@@ -367,6 +367,26 @@ int vcv_loss_many_sum(const void* items_dev, int n_items, int total_blocks, floa
 int vcv_loss_many_grad(const void* items_dev, int n_items, int total_blocks, float target, int mode,
                        const float* gout, float* dabuf, void* stream);
 
+/* ---- one conv PAIR of a ResBlock1 over 16-bit activations as ONE launch (inference; modules.py:186-222 behind
+ * synthesizer_svc.py:108 under fp16 autocast):  xt = leaky(conv1(leaky(x); w1, dilation dil) + b1);  out = conv2(xt; w2) + b2 + x;
+ * y = out, or y += post_scale * out with `accumulate` (a block's last pair: the stage mean).  x, y: fp16 [B, C, T], T a multiple
+ * of 8, 16-byte aligned; both convs [C, C, K] "same"-padded; the intermediate xt (rounded to bf16 as the two-launch path stores
+ * it) never leaves the CU.  C in {32, 64}, K in {3, 7, 11}, dil <= 5 where the LDS images fit (vcv_resblock_pair_supported
+ * returns the bytes of the packed weight buffer, 0 = run the pair as two vcv_conv_bf16io_* launches). */
+typedef struct VcvResPairArgs {
+  const void* x;    /* fp16 [B, C, T] */
+  const void* wp;   /* packed weights of both convs (vcv_resblock_pair_pack) */
+  const float* b1;  /* [C] */
+  const float* b2;  /* [C] */
+  void* y;          /* fp16 [B, C, T] */
+  int32_t B, C, T, K, dil, accumulate;
+  float post_scale; /* 0 = none */
+  float slope;      /* leaky-ReLU slope of both convs' inputs */
+} VcvResPairArgs;
+int64_t vcv_resblock_pair_supported(int C, int K, int dil, int T);
+int vcv_resblock_pair_pack(const float* w1, const float* w2, void* wp, int C, int K, void* stream);
+int vcv_resblock_pair_x16(const VcvResPairArgs* args, void* stream);
+
 /* ---- embedding rows laid out [B, C, T] (content_encoder.py:58-60: emb_pitch(pitch).transpose(1, -1); synthesizer_svc.py:77:
  * emb_g(sid).unsqueeze(-1) with T = 1) and the table gradient.  idx: int64 [B, T]; W: [rows, C]; y / dy: [B, C, T].
  * An index outside [0, rows) reads as a zero row.  The gradient is one workgroup per table row, positions summed in ascending

@@ -201,9 +201,10 @@ def test_infer_waveform_rms_bf16_48k(gpu, bf16_mode):
         spk = net.emb_g(sid.to(gpu)).unsqueeze(-1)
         z_p = ops.prior_sample(m_p.to(gpu), logs_p.to(gpu), noise.to(gpu), 1.0)
         z = net.flow(z_p, mask.to(gpu), g=spk, reverse=True)
-        before = ops.LAUNCH_COUNTS["bf16"] + ops.LAUNCH_COUNTS["bf16io"]
+        count = lambda: ops.LAUNCH_COUNTS["bf16"] + ops.LAUNCH_COUNTS["bf16io"] + 2 * ops.LAUNCH_COUNTS.get("pair_fused", 0)
+        before = count()
         o = net.dec(ops.mask_mul(z, mask.to(gpu).reshape(B, -1)))
-        used = ops.LAUNCH_COUNTS["bf16"] + ops.LAUNCH_COUNTS["bf16io"] - before
+        used = count() - before
         g = F.embedding(sid, sd["n.emb_g.weight"]).unsqueeze(-1)
         z_o = O.flow_forward(sd, "n.flow", m_p + noise * torch.exp(logs_p), mask, g, True, C, H, 5, 1, 4)
         o_o = O.generator_forward(sd, "n.dec", z_o * mask)

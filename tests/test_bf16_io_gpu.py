@@ -184,7 +184,8 @@ def test_generator_waveform_rms_bf16_activations(gpu, bf16_mode, widths):
         o_ref = O.generator_forward({"g." + k: v for k, v in sd.items()}, "g", z)
         before = dict(ops.LAUNCH_COUNTS)
         o = gen.to(gpu)(z.to(gpu))
-        used = ops.LAUNCH_COUNTS["bf16io"] - before["bf16io"]
+        # (a fused ResBlock pair launch -- the 32- / 64-channel stages, resblock_pair.hip -- stands for two of the 72 convs)
+        used = ops.LAUNCH_COUNTS["bf16io"] - before["bf16io"] + 2 * (ops.LAUNCH_COUNTS.get("pair_fused", 0) - before.get("pair_fused", 0))
         assert used == 4 + 72, "%d launches on the bf16-activation kernel (4 transposed convs + 72 ResBlock convs expected)" % used
         ops.set_bf16_activations(False)
         try:

@@ -53,10 +53,11 @@ def test_hifigan_lineage_vs_oracle(gpu, bf16_infer):
     if bf16_infer:  # the 16-bit-activation inference pass takes the same layers (bias of conv_post in its last launch)
         ops.set_compute_dtype("bf16")
         try:
-            before = ops.LAUNCH_COUNTS["bf16io"]
+            count = lambda: ops.LAUNCH_COUNTS["bf16io"] + 2 * ops.LAUNCH_COUNTS.get("pair_fused", 0)  # (a fused pair = two convs)
+            before = count()
             with torch.no_grad():
                 yg = gen(x.to(gpu))
-            assert ops.LAUNCH_COUNTS["bf16io"] - before == 4 + 72
+            assert count() - before == 4 + 72
         finally:
             ops.set_compute_dtype("f32")
         sig = yc.detach().pow(2).mean().sqrt().item()

@@ -320,7 +320,11 @@ def test_graphed_batch_records_the_bucket_all_reduces(gpu):
     from vcvits_amd.light import graphed
     from vcvits_amd.light.optim import shutdown_flag_groups
     from vcvits_amd.light.vcvits import VocoderGAN
-    os.environ.update({"VCVITS_FORCE_DDP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29641"})
+    import socket
+    with socket.socket() as sk:  # a free port (a fixed one collided with a lingering listener once)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update({"VCVITS_FORCE_DDP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:

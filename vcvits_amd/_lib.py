@@ -43,6 +43,13 @@ class VcvPackJob(ctypes.Structure):
                [("total", ctypes.c_int64), ("block0", ctypes.c_int64)]
 
 
+class VcvResPairArgs(ctypes.Structure):
+    """mirrors include/vcvits_hip.h"""
+    _fields_ = [("x", _f32p), ("wp", _f32p), ("b1", _f32p), ("b2", _f32p), ("y", _f32p)] + \
+               [(n, _i32) for n in ("B", "C", "T", "K", "dil", "accumulate")] + \
+               [("post_scale", ctypes.c_float), ("slope", ctypes.c_float)]
+
+
 class VcvWgradArgs(ctypes.Structure):
     _fields_ = [
         ("a", _f32p), ("b", _f32p), ("aaux", _f32p), ("baux", _f32p), ("dw", _f32p),
@@ -74,7 +81,7 @@ def lib():
         for name in EXPORTS:
             fn = getattr(L, name)
             if name != "vcv_version":
-                fn.restype = (ctypes.c_int64 if name in ("vcv_conv_dma_workspace", "vcv_wgrad_bf16_scratch", "vcv_wgrad_x3_scratch", "vcv_layernorm_c_bwd_scratch")
+                fn.restype = (ctypes.c_int64 if name in ("vcv_conv_dma_workspace", "vcv_wgrad_bf16_scratch", "vcv_wgrad_x3_scratch", "vcv_layernorm_c_bwd_scratch", "vcv_resblock_pair_supported")
                               else ctypes.c_void_p if name == "vcv_get_seed_offset_ptr" else ctypes.c_int)
                 fn.argtypes = _ARGTYPES[name]
         _lib = L
@@ -96,7 +103,7 @@ EXPORTS = [
     "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16", "vcv_act_grad_bias", "vcv_conv_pk_plan", "vcv_conv_pk_run",
     "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_rel_attn_bwd2", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause", "vcv_conv_x3_pack_job", "vcv_conv_pk_pack_job", "vcv_conv_bf16_pack_job", "vcv_pack_many", "vcv_upload_table",
     "vcv_conv_bf16io_plan", "vcv_conv_bf16io_run", "vcv_cast_f32_x16", "vcv_cast_x16_f32", "vcv_conv_m1_x16_fwd",
-    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force", "vcv_layernorm_c_bwd_scratch", "vcv_layernorm_c_bwd_ws",
+    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force", "vcv_layernorm_c_bwd_scratch", "vcv_layernorm_c_bwd_ws", "vcv_resblock_pair_supported", "vcv_resblock_pair_pack", "vcv_resblock_pair_x16",
 ]
 
 
@@ -132,6 +139,9 @@ _ARGTYPES = {
     "vcv_layernorm_c_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "vcv_layernorm_c_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vcv_layernorm_c_bwd_scratch": [_I, _I, _I],
+    "vcv_resblock_pair_supported": [_I, _I, _I, _I],
+    "vcv_resblock_pair_pack": [_P, _P, _P, _I, _I, _P],
+    "vcv_resblock_pair_x16": [ctypes.POINTER(VcvResPairArgs), _P],
     "vcv_layernorm_c_bwd_ws": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P],
     "vcv_rel_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, ctypes.c_uint64, _P],
     "vcv_dropout": [_P, _P, _L, _F, ctypes.c_uint64, _P],

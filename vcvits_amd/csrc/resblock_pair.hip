@@ -1,0 +1,433 @@
+// resblock_pair.hip -- one conv PAIR of a HiFi-GAN ResBlock1 as ONE launch over 16-bit activations (inference):
+//
+//     xt  = leaky( conv1( leaky(x); W1, dilation d ) + b1 )          (k taps, "same" padding)
+//     out = conv2( xt; W2, dilation 1 ) + b2 + x                      (k taps, "same" padding)
+//     y   = out                      (a middle pair: the next residual stream)
+//     y   = y + post_scale * out     (a block's last pair: the stage mean accumulated in place)
+//
+// Reference: vits/model/modules.py:186-222 (ResBlock1.forward: xt = c1(leaky(x)); xt = c2(leaky(xt)); x = xt + x) behind the
+// decoder call of synthesizer_svc.py:108 under fp16 autocast (train.py:104-106).
+//
+// Why one launch: in the 32- and 64-channel stages of the 48 kHz decode (64 x 10 s: tensors of 2 GB in 16 bits) the two
+// launches of a pair move five tensor passes through HBM -- x in, xt out, xt in, x in again (residual), y out -- at
+// 2.2 - 3.6 TB/s each and are bound by exactly that (profiles/r4_48k_infer_bf16_*: conv_pk_kernel<Bf16El, ..., IO> 1.4 - 2.0 ms
+// per launch).  Here the intermediate xt never leaves the CU: a workgroup stages the input span of its output tile once
+// (+ the halo of BOTH convs), keeps leaky(x) and xt as channel-innermost bf16 images in LDS, and the residual re-read of
+// x hits L2 a few microseconds after the staging read: two passes instead of five.
+//
+// Arithmetic = the two-launch path's, rounding for rounding: x (fp16) -> fp32 -> leaky -> bf16 MFMA operand; fp32
+// accumulate; + b1, leaky, ONE rounding to bf16 (the stored xt of the two-launch path); fp32 accumulate; + b2 + x, one
+// rounding to fp16.  Only the fp32 summation order inside a conv differs (taps outer, channel groups inner).
+//
+// Layout.  MFMA v_mfma_f32_32x32x16_bf16 (cdna_hip_programming.md section 3): lane l = (r = l & 31, h = l >> 5) holds
+// A[row r][k = 8h + j], B[k = 8h + j][col r]; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h.  Rows = output channels,
+// columns = positions, k = 16 input channels of one tap.  LDS images are PLANES of 16-byte slots: plane q holds channels
+// 8q .. 8q + 7 of every staged position, so a B fragment is one ds_read_b128 per lane of 32 consecutive positions
+// (plane 2 cg + h), and a tap is a position offset.  Slots are rotated inside aligned blocks of 16 positions by the block
+// index (slot()): the staging writes -- lane = 8 consecutive positions, one write per position, i.e. a 128-byte lane stride --
+// would otherwise land 16 lanes on two banks; with the rotation they are conflict-free and a fragment read of 32
+// consecutive positions (which straddles two or three blocks) sees at most a two-way conflict.
+// Weights are packed ahead of time (vcv_resblock_pair_pack) as wp[conv][tap][cg][h][m][8]: an A fragment is one
+// ds_read_b128 of 32 consecutive rows.
+#include "common.h"
+#include "conv_tile.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+
+constexpr int NWAVE = 8;
+
+__device__ __forceinline__ int slot(int p) { return (p & ~15) | ((p + (p >> 4)) & 15); }
+
+struct PairArgs {
+  const unsigned short* x;   // fp16 [B, C, T]
+  const bf16x8* wp;          // packed weights of both convs
+  const float* b1;
+  const float* b2;
+  unsigned short* y;         // fp16 [B, C, T]
+  int B, T, dil, accumulate;
+  float post_scale, slope;
+  int ntile;                 // output tiles per batch element
+  int dbg;                   // VCVITS_PAIR_DBG (diagnostics): 1 raw conv2 sums, 2 xt read back, 3 staged leaky(x) read back
+};
+
+// geometry of one (C, K) instance
+template <int C, int K>
+struct Geo {
+  static constexpr int TM = C / 32;                      // m-tiles (all owned by every wave: B fragments are shared)
+  static constexpr int TNW = C == 32 ? 2 : 1;            // n-tiles per wave
+  static constexpr int N1 = 32 * NWAVE * TNW;            // xt positions a workgroup computes (conv1 columns)
+  static constexpr int H2 = (K - 1) / 2;
+  static constexpr int BN = (N1 - 2 * H2) & ~7;          // output positions per workgroup (16-byte rows)
+  static constexpr int NQ = C / 8;                       // planes per image
+  static constexpr int CG = C / 16;
+  static constexpr int WSLOTS = K * CG * 2 * C;          // 16-byte slots of one conv's packed weights
+  static constexpr int XT_SLOTS = N1 + 48;               // (the last conv2 tile reads up to K - 1 + 31 past its last valid column)
+  static constexpr bool BOTHW = (size_t)2 * WSLOTS * 16 <= 56 * 1024;  // both convs' weights resident at once
+};
+
+template <int C, int K>
+__host__ __device__ constexpr int xs_slots(int dil) {
+  // staged input positions: N1 + 2 h1 (+ up to 7 of round-down, rounded up to a block of 16, + one block of slack)
+  return ((Geo<C, K>::N1 + (K - 1) * dil + 7 + 15) & ~15) + 16;
+}
+
+// One conv of the pair on the MFMA pipe: acc[tm][tn] += sum over taps j and 16-channel groups cg of A(j, cg, tm) x B(j, cg, tn),
+// B = the image `img` (planes of `pitch` slots) at column (wave's tile column) + j * dstep + shift.
+// C = 32: the K * CG weight fragments of the conv stay in registers for the whole tile loop (88 VGPRs at K = 11): per
+// MFMA the wave then reads ONE 1 KB fragment from LDS instead of 1.5 -- at eight waves per CU the LDS read rate, not the
+// matrix pipe, was the bound.  C = 64 (two m-tiles: 56 - 88 fragments do not fit) reads them per step.
+template <int C, int K, int WHICH, int TM, int TNW>
+__device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* __restrict__ W,
+                                         const bf16x8* __restrict__ img, int pitch, int dstep, int shift, int wave, int l31,
+                                         int h) {
+  constexpr int CG = C / 16;
+  if constexpr (C == 32) {
+    bf16x8 a[K][CG];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int cg = 0; cg < CG; ++cg) a[j][cg] = W[((j * CG + cg) * 2 + h) * C + l31];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#pragma unroll
+      for (int cg = 0; cg < CG; ++cg) {
+        bf16x8 bb[TNW];
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) bb[tn] = img[(2 * cg + h) * pitch + slot((wave * TNW + tn) * 32 + l31 + j * dstep + shift)];
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][cg], bb[tn], acc[0][tn], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+#pragma unroll
+      for (int cg = 0; cg < CG; ++cg) {
+        bf16x8 a[TM], bb[TNW];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = W[((j * CG + cg) * 2 + h) * C + tm * 32 + l31];
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) bb[tn] = img[(2 * cg + h) * pitch + slot((wave * TNW + tn) * 32 + l31 + j * dstep + shift)];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// PERSISTENT workgroups: the grid is one workgroup per CU-slot; each loads the packed weights ONCE (where both convs' fit: at
+// K = 11 they are 45 KB -- more than the 36 KB of activations a tile reads, and the first version of this kernel, one
+// workgroup per tile, spent its time re-loading them and waiting on serialised phases: 2.5 ms per pair) and then walks tiles
+// tile0, tile0 + grid, ...  The global loads of the NEXT tile's input span are issued before the current tile's two convs and
+// land in registers while the matrix pipe works; they are converted and written to the LDS image after the current tile's
+// epilogue.  Staging task = (plane q, 8 consecutive positions) with q uniform per wave (the row's buffer descriptor is a
+// scalar operand: a per-lane q would put a waterfall loop around every load).
+template <int C, int K>
+__global__ void __launch_bounds__(64 * NWAVE)
+resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
+  using G = Geo<C, K>;
+  constexpr int TM = G::TM, TNW = G::TNW, N1 = G::N1, H2 = G::H2, BN = G::BN, NQ = G::NQ;
+  constexpr int WPQ = NWAVE / NQ;  // waves that share one plane's staging (C = 32: 2, C = 64: 1)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* Ws = reinterpret_cast<bf16x8*>(smem);                       // [1 or 2][WSLOTS]
+  bf16x8* Xs = Ws + (G::BOTHW ? 2 : 1) * G::WSLOTS;                     // [NQ][xs_n]   (later: the waves' epilogue tiles)
+  const int xs_bytes = NQ * xs_n * 16;
+  const int ep_bytes = NWAVE * 32 * 40 * 4;
+  bf16x8* XTs = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Xs) + (xs_bytes > ep_bytes ? xs_bytes : ep_bytes));  // [NQ][XT_SLOTS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int T = p.T, dil = p.dil;
+  const int h1 = (K - 1) * dil / 2;
+  const int npg = xs_n / 8;
+  const int sq = wave % NQ;                       // the plane this wave stages (wave-uniform)
+  const int spg = lane + 64 * (wave / NQ);        // ... and the lane's position group (npg <= 64 * WPQ: one task per lane)
+  const bool stask = spg < npg;
+  const float sl = p.slope;
+
+  u32x4 v[8];
+  auto issue = [&](int tile) {  // global loads of tile's input span -> v[]
+    const int b = tile / p.ntile, t0 = (tile - b * p.ntile) * BN;
+    const int ps8 = (t0 - H2 - h1) & ~7;
+    const int pos0 = ps8 + 8 * spg;  // global position of the lane's first element (a multiple of 8)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned short* row = p.x + ((size_t)b * C + (sq * 8 + e)) * (size_t)T;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, T * 2, 0x00020000);
+      // before the row: wraps -> out of range -> zeros (rows are multiples of 8 elements); a lane without a task: out of range too
+      unsigned voff = stask ? (unsigned)pos0 * 2u : 0xffffff00u;
+      asm volatile("" : "+v"(voff));
+      v[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    }
+  };
+  auto stage = [&]() {  // v[] -> leaky, bf16 -> the Xs image
+    if (!stask) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // position i of the lane = halfword i & 1 of dword i >> 1 of each channel's load (extracted from the dwords: a
+        // __builtin_bit_cast(_Float16, vec[i]) on a 16-bit vector ELEMENT expression compiled to element 0 for every i)
+        const unsigned short bits = (unsigned short)((i & 1) ? (v[e][i >> 1] >> 16) : (v[e][i >> 1] & 0xffffu));
+        const float f = (float)__builtin_bit_cast(_Float16, bits);
+        o[e] = (__bf16)fmaxf(f, f * sl);  // leaky (0 <= slope < 1), one rounding to the bf16 operand
+      }
+      Xs[sq * xs_n + slot(8 * spg + i)] = o;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= total_tiles) return;
+  issue(tile);
+  if (G::BOTHW)
+    for (int i = tid; i < 2 * G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[i];
+  stage();
+  __syncthreads();
+
+  for (;;) {
+    const int b = tile / p.ntile, t0 = (tile - b * p.ntile) * BN;
+    const int sh = (t0 - H2 - h1) & 7;
+    const int next = tile + (int)gridDim.x;
+    const bool more = next < total_tiles;
+    if (more) issue(next);  // in flight under this tile's two convs
+    if (!G::BOTHW) {        // conv1's weights (the two convs' do not fit together: re-loaded per tile, from L2)
+      for (int i = tid; i < G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[i];
+      __syncthreads();
+    }
+
+    // ---- conv1: xt[m][n], n in [0, N1): wave w owns n-tiles w * TNW .. ----
+    f32x16 acc[TM][TNW];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+    conv_mma<C, K, 0>(acc, Ws, Xs, xs_n, dil, sh, wave, l31, h);
+    // epilogue 1: + b1, leaky, bf16 -> XTs; columns outside [0, T) are the zero padding of conv2's input
+#pragma unroll
+    for (int tn = 0; tn < TNW; ++tn) {
+      const int n = (wave * TNW + tn) * 32 + l31;
+      const int gp = t0 - H2 + n;
+      const bool inside = gp >= 0 && gp < T;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {  // registers 4 qq .. 4 qq + 3: channels tm * 32 + 8 qq + 4 h + (0 .. 3)
+          us4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = tm * 32 + 8 * qq + 4 * h + r;
+            float val = acc[tm][tn][4 * qq + r] + p.b1[m];
+            val = fmaxf(val, val * sl);
+            o[r] = inside ? __builtin_bit_cast(unsigned short, (__bf16)val) : (unsigned short)0;
+          }
+          // plane = channels / 8 = tm * 4 + qq; the lane's four channels are the low (h = 0) or high (h = 1) half of the slot
+          us4* dst = reinterpret_cast<us4*>(XTs + (tm * 4 + qq) * G::XT_SLOTS + slot(n)) + h;
+          *dst = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (!G::BOTHW) {  // conv2's weights over conv1's
+      for (int i = tid; i < G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[G::WSLOTS + i];
+      __syncthreads();
+    }
+
+    // the epilogue's operands -- the residual x (L2: staged a tile ago) and, for a block's last pair, the accumulate target --
+    // are requested NOW, so their latency hides under conv2 instead of sitting in front of every store (measured on the 48 kHz
+    // decode: K = 3 1.71 -> 1.54 ms per launch, K = 7 2.01 -> 1.96; at K = 11 the 22 weight fragments and these 32 registers
+    // together cost more than the latency: 2.21 -> 2.57, so K = 11 loads them in the epilogue)
+    constexpr bool PRE = K <= 7;
+    us8 xres[TNW][TM][2], yacc[TNW][TM][2];
+    if constexpr (PRE)
+#pragma unroll
+    for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int m = tm * 32 + ps * 16 + (lane >> 2);
+          const int o = (wave * TNW + tn) * 32 + 8 * (lane & 3);
+          const bool ok = o < BN && t0 + o < T;
+          const size_t idx = ((size_t)b * C + m) * (size_t)T + (ok ? t0 + o : 0);
+          xres[tn][tm][ps] = *reinterpret_cast<const us8*>(p.x + idx);
+          if (p.accumulate) yacc[tn][tm][ps] = *reinterpret_cast<const us8*>(p.y + idx);
+        }
+
+    // ---- conv2: out[m][o], o in [0, BN): same tile ownership; xt column of (o, tap j) = o + j ----
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+    conv_mma<C, K, 1>(acc, Ws + (G::BOTHW ? G::WSLOTS : 0), XTs, G::XT_SLOTS, 1, 0, wave, l31, h);
+    // epilogue 2 through the wave's LDS tile (the Xs region: nobody reads it after conv1's barrier): rows of eight consecutive
+    // positions per lane, + b2 + x (fp16, re-read: L2), [y += post_scale * out], one rounding to fp16, 16-byte stores
+    {
+      float* Tl = reinterpret_cast<float*>(Xs) + wave * (32 * 40);
+      const float ps_ = p.post_scale != 0.f ? p.post_scale : 1.f;
+#pragma unroll
+      for (int tn = 0; tn < TNW; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if (p.dbg < 3)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Tl[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = acc[tm][tn][e];
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const int r = ps * 16 + (lane >> 2), c8 = lane & 3;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Tl + r * 40 + 8 * c8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Tl + r * 40 + 8 * c8 + 4);
+            const int m = tm * 32 + r;
+            const int o = (wave * TNW + tn) * 32 + 8 * c8;
+            const int t = t0 + o;
+            if (o >= BN || t >= T) continue;  // (BN and T are multiples of 8: a group of eight is all in or all out)
+            const size_t idx = ((size_t)b * C + m) * (size_t)T + t;
+            if (p.dbg) {
+              us8 out;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                float dv = i < 4 ? a0[i] : a1[i - 4];
+                if (p.dbg == 2) dv = (float)(reinterpret_cast<const __bf16*>(XTs + (m >> 3) * G::XT_SLOTS + slot(o + i + H2))[m & 7]);
+                if (p.dbg == 3) dv = (float)(reinterpret_cast<const __bf16*>(Xs + (m >> 3) * xs_n + slot(o + i + H2 + h1 + sh))[m & 7]);
+                out[i] = f32_to_us<2>(dv);
+              }
+              *reinterpret_cast<us8*>(p.y + idx) = out;
+              continue;
+            }
+            us8 xr;
+            if constexpr (PRE) xr = xres[tn][tm][ps];
+            else xr = *reinterpret_cast<const us8*>(p.x + idx);
+            float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            float yy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.accumulate) {
+              us8 y8;
+              if constexpr (PRE) y8 = yacc[tn][tm][ps];
+              else y8 = *reinterpret_cast<const us8*>(p.y + idx);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) yy[i] = us_to_f32(y8[i], 2);
+            }
+            const float bv = p.b2[m];
+            us8 out;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              float xv = val[i] + bv + us_to_f32(xr[i], 2);  // (through the helper: see stage())
+              xv = xv * ps_ + yy[i];
+              out[i] = f32_to_us<2>(xv);
+            }
+            *reinterpret_cast<us8*>(p.y + idx) = out;
+          }
+        }
+      }
+    }
+    if (!more) break;
+    __syncthreads();  // every wave's epilogue tile (the Xs region) is done
+    stage();          // the next tile's image
+    __syncthreads();
+    tile = next;
+  }
+}
+
+// fp32 [C][C][K] x 2 -> wp[conv][tap][cg][h][m][8] (bf16)
+__global__ void __launch_bounds__(256)
+resblock_pair_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ wp, int C, int K) {
+  const int per = K * (C / 16) * 2 * C;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * per) return;
+  const int conv = i / per;
+  int t = i - conv * per;
+  const int m = t % C; t /= C;
+  const int hh = t & 1; t >>= 1;
+  const int cg = t % (C / 16);
+  const int j = t / (C / 16);
+  const float* w = conv ? w2 : w1;
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (__bf16)w[((size_t)m * C + cg * 16 + hh * 8 + e) * K + j];
+  wp[i] = v;
+}
+
+template <int C, int K>
+size_t lds_bytes(int dil) {
+  using G = Geo<C, K>;
+  const size_t xs = (size_t)G::NQ * xs_slots<C, K>(dil) * 16, ep = (size_t)NWAVE * 32 * 40 * 4;
+  return (size_t)(G::BOTHW ? 2 : 1) * G::WSLOTS * 16 + (xs > ep ? xs : ep) + (size_t)G::NQ * G::XT_SLOTS * 16;
+}
+
+template <int C, int K>
+int launch(const VcvResPairArgs& a, hipStream_t st) {
+  using G = Geo<C, K>;
+  const size_t lds = lds_bytes<C, K>(a.dil);
+  if (lds > VCV_LDS_LIMIT) return VCV_EINVAL;
+  auto kern = resblock_pair_kernel<C, K>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VCV_EHIP;
+  PairArgs p;
+  p.x = (const unsigned short*)a.x; p.wp = (const bf16x8*)a.wp; p.b1 = a.b1; p.b2 = a.b2; p.y = (unsigned short*)a.y;
+  p.B = a.B; p.T = a.T; p.dil = a.dil; p.accumulate = a.accumulate; p.post_scale = a.post_scale; p.slope = a.slope;
+  p.ntile = vcv_cdiv(a.T, G::BN);
+  { const char* e = getenv("VCVITS_PAIR_DBG"); p.dbg = e ? atoi(e) : 0; }
+  const long long nblk = (long long)a.B * p.ntile;
+  if (nblk >= (1ll << 31)) return VCV_EINVAL;
+  // persistent: as many workgroups as the chip holds at this LDS footprint (256 CUs; two per CU where two fit)
+  const long long slots = 256 * (2 * lds <= VCV_LDS_LIMIT ? 2 : 1);
+  static const long long forced = [] { const char* e = getenv("VCVITS_PAIR_GRID"); return e ? atoll(e) : 0ll; }();
+  const long long grid = forced > 0 ? (forced < nblk ? forced : nblk) : (nblk < slots ? nblk : slots);
+  if (xs_slots<C, K>(a.dil) / 8 > 64 * (NWAVE / G::NQ)) return VCV_EINVAL;  // (one staging task per lane)
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWAVE), (unsigned)lds, st, p, xs_slots<C, K>(a.dil), (int)nblk);
+  return vcv_check_launch();
+}
+
+bool supported(int C, int K, int dil, int T) {
+  if ((C != 32 && C != 64) || (K != 3 && K != 7 && K != 11) || dil < 1 || dil > 5 || T < 64 || (T & 7)) return false;
+  // 64 channels with K >= 7: the two convs' weights (114 KB at K = 7) do not fit next to the images, and re-loading them per
+  // tile made the fused launch no faster than the two it replaces (3.5 vs 3.5 - 3.8 ms on the 48 kHz decode): left to those
+  static const bool all64 = getenv("VCVITS_PAIR_ALL64") != nullptr;
+  if (C == 64 && K > 3 && !all64) return false;
+  if ((long long)T * 2 >= (1ll << 31)) return false;
+  size_t lds = 0;
+  if (C == 32) lds = K == 3 ? lds_bytes<32, 3>(dil) : K == 7 ? lds_bytes<32, 7>(dil) : lds_bytes<32, 11>(dil);
+  else lds = K == 3 ? lds_bytes<64, 3>(dil) : K == 7 ? lds_bytes<64, 7>(dil) : lds_bytes<64, 11>(dil);
+  return lds <= VCV_LDS_LIMIT;
+}
+
+}  // namespace
+
+// Bytes of the packed weight buffer of a (C, K, dil, T) pair, or 0 when the fused kernel does not take the shape (the caller
+// runs the pair as two vcv_conv_bf16io_* launches).
+extern "C" int64_t vcv_resblock_pair_supported(int C, int K, int dil, int T) {
+  return supported(C, K, dil, T) ? (int64_t)2 * K * C * C * 2 : 0;
+}
+
+extern "C" int vcv_resblock_pair_pack(const float* w1, const float* w2, void* wp, int C, int K, void* stream) {
+  if (!w1 || !w2 || !wp || (C != 32 && C != 64) || K < 1 || K > 16) return VCV_EINVAL;
+  const int n = 2 * K * (C / 16) * 2 * C;
+  hipLaunchKernelGGL(resblock_pair_pack_kernel, dim3((unsigned)vcv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w1, w2,
+                     (bf16x8*)wp, C, K);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_resblock_pair_x16(const VcvResPairArgs* a, void* stream) {
+  if (!a || !a->x || !a->wp || !a->b1 || !a->b2 || !a->y || a->B <= 0 || !supported(a->C, a->K, a->dil, a->T)) return VCV_EINVAL;
+  if ((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->wp) & 15) || a->slope < 0.f || a->slope >= 1.f) return VCV_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->C == 32) {
+    if (a->K == 3) return launch<32, 3>(*a, st);
+    if (a->K == 7) return launch<32, 7>(*a, st);
+    return launch<32, 11>(*a, st);
+  }
+  if (a->K == 3) return launch<64, 3>(*a, st);
+  if (a->K == 7) return launch<64, 7>(*a, st);
+  return launch<64, 11>(*a, st);
+}

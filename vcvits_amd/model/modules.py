@@ -254,13 +254,26 @@ class ResBlock1(nn.Module):
         and the result is the fp32-activation path's, rounding for rounding."""
         n = len(self.convs1)
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
-            xt = ops.conv_forward_x16(x, c1.effective_weight(), c1.bias, pad=c1.padding, dil=c1.dilation, in_leaky=True,
+            w1, w2 = c1.effective_weight(), c2.effective_weight()
+            if (c1.bias is not None and c2.bias is not None and c2.dilation == 1 and c1.padding == (w1.shape[2] - 1) * c1.dilation // 2
+                    and c2.padding == (w2.shape[2] - 1) // 2 and (acc is None or acc.dtype == x.dtype)
+                    and ops.resblock_pair_supported(x, w1, w2, c1.dilation)):
+                # the 32- / 64-channel stages: the pair as ONE launch, the intermediate never leaves the CU (resblock_pair.hip)
+                if i < n - 1:
+                    x = ops.resblock_pair_x16(x, w1, c1.bias, w2, c2.bias, c1.dilation, slope=LRELU_SLOPE)
+                elif acc is None:
+                    acc = ops.resblock_pair_x16(x, w1, c1.bias, w2, c2.bias, c1.dilation, slope=LRELU_SLOPE, post_scale=scale)
+                else:
+                    acc = ops.resblock_pair_x16(x, w1, c1.bias, w2, c2.bias, c1.dilation, slope=LRELU_SLOPE, out=acc,
+                                                accumulate=True, post_scale=scale)
+                continue
+            xt = ops.conv_forward_x16(x, w1, c1.bias, pad=c1.padding, dil=c1.dilation, in_leaky=True,
                                       out_act=ACT_LEAKY, slope=LRELU_SLOPE, out_dtype=torch.bfloat16)
             if i < n - 1:
-                x = ops.conv_forward_x16(xt, c2.effective_weight(), c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
+                x = ops.conv_forward_x16(xt, w2, c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
                                          out_dtype=x.dtype)
             else:
-                acc = ops.conv_forward_x16(xt, c2.effective_weight(), c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
+                acc = ops.conv_forward_x16(xt, w2, c2.bias, pad=c2.padding, dil=c2.dilation, res=x,
                                            out=acc, accumulate=acc is not None, post_scale=scale, out_dtype=x.dtype)
         return acc
 

@@ -591,6 +591,55 @@ def convT_forward_x16(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.
     return out
 
 
+# ---- one conv pair of a ResBlock1 as ONE launch (resblock_pair.hip) ------------------------------------------------------------
+_PAIR_FUSED = [__import__("os").environ.get("VCVITS_PAIR_FUSED", "1") == "1"]
+
+
+def resblock_pair_supported(x, w1, w2, dil):
+    """True when the fused pair kernel takes (x fp16 [B, C, T], two [C, C, K] convs, c1's dilation)."""
+    if not _PAIR_FUSED[0] or x.dtype != torch.float16 or x.dim() != 3 or not x.is_contiguous():
+        return False
+    C, K = w1.shape[0], w1.shape[2]
+    if tuple(w1.shape) != (C, C, K) or tuple(w2.shape) != (C, C, K) or x.shape[1] != C:
+        return False
+    return lib().vcv_resblock_pair_supported(C, K, int(dil), x.shape[2]) > 0
+
+
+def resblock_pair_x16(x, w1, b1, w2, b2, dil, slope=0.1, out=None, accumulate=False, post_scale=0.0):
+    """out = conv2(leaky(conv1(leaky(x); w1, dil) + b1); w2) + b2 + x over fp16 activations in ONE launch (the intermediate,
+    rounded to bf16 exactly as the two-launch path stores it, stays in LDS).  With `out` given and accumulate=True:
+    out += post_scale * result (a block's last pair: the stage mean).  modules.ResBlock1.forward_x16 is the caller."""
+    from ._lib import VcvResPairArgs
+    x = _x16(x, "x")
+    B, C, T = x.shape
+    K = w1.shape[2]
+    w1, w2, b1, b2 = _f32c(w1), _f32c(w2), _f32c(b1), _f32c(b2)
+    # the packed weights live with the cached weight-norm buffer / parameter region that holds w1 (as the conv packs do:
+    # dropped when those weights change); weights outside any such buffer are packed per call (an address alone can be recycled)
+    ent = _stable_entry(w1.data_ptr())
+    if ent is not None and "dirty" in ent:
+        ent = None  # (a parameter region keys its packs on tensor versions: not worth it for a 45 KB pack)
+    key = ("pair", w1.data_ptr(), w2.data_ptr(), K)
+    wp = ent["packs"].get(key) if ent is not None else None
+    if wp is None:
+        nbytes = lib().vcv_resblock_pair_supported(C, K, int(dil), T)
+        wp = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+        check(lib().vcv_resblock_pair_pack(ptr(w1), ptr(w2), ptr(wp), C, K, stream()), "vcv_resblock_pair_pack")
+        if ent is not None:
+            ent["packs"][key] = wp
+    if out is None:
+        out = torch.empty_like(x)
+        accumulate = False
+    out = _x16(out, "out")
+    a = VcvResPairArgs()
+    a.x, a.wp, a.b1, a.b2, a.y = ptr(x), ptr(wp), ptr(b1), ptr(b2), ptr(out)
+    a.B, a.C, a.T, a.K, a.dil, a.accumulate = B, C, T, K, int(dil), 1 if accumulate else 0
+    a.post_scale, a.slope = float(post_scale), float(slope)
+    check(lib().vcv_resblock_pair_x16(ctypes.byref(a), stream()), "vcv_resblock_pair_x16")
+    LAUNCH_COUNTS["pair_fused"] = LAUNCH_COUNTS.get("pair_fused", 0) + 1
+    return out
+
+
 def conv_m1_x16(x, w, bias=None, pad=0, in_leaky=False, out_act=ACT_NONE, slope=0.1):
     """One-output-channel conv (stride 1, dilation 1) over a 16-bit [B, C, T] input -> fp32 [B, 1, Tout]."""
     x = _x16(x, "x")
