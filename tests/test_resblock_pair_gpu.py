@@ -32,7 +32,8 @@ def _cpu_reference(x, w1, b1, w2, b2, dil):
 
 
 @pytest.mark.parametrize("C,K,dil,T,B", [(32, 3, 1, 1000, 3), (32, 7, 3, 2056, 2), (32, 11, 5, 1504, 3), (32, 11, 1, 488, 2),
-                                         (64, 3, 5, 1000, 2), (64, 3, 1, 760, 3), (64, 3, 3, 256, 2)])
+                                         (64, 3, 5, 1000, 2), (64, 3, 1, 760, 3), (64, 3, 3, 256, 2),
+                                         (64, 7, 3, 760, 3), (64, 7, 5, 1248, 2), (64, 11, 5, 1000, 2), (64, 11, 1, 504, 3)])
 def test_fused_pair_equals_two_launches_and_the_cpu_arithmetic(gpu, C, K, dil, T, B):
     from vcvits_amd import ops
     from vcvits_amd._lib import ACT_LEAKY
@@ -75,10 +76,9 @@ def test_fused_pair_equals_two_launches_and_the_cpu_arithmetic(gpu, C, K, dil, T
 def test_fused_pair_declines_what_does_not_fit(gpu):
     from vcvits_amd import ops
     x = torch.zeros(1, 64, 512, dtype=torch.float16, device=gpu)
-    w = torch.zeros(64, 64, 11, device=gpu)
-    assert not ops.resblock_pair_supported(x, w, w, 5)          # 64 channels x 11 taps: the LDS images do not fit
-    w7 = torch.zeros(64, 64, 7, device=gpu)
-    assert not ops.resblock_pair_supported(x, w7, w7, 3)        # 64 x 7: weights re-loaded per tile -- left to the two launches
+    w = torch.zeros(64, 64, 5, device=gpu)
+    assert not ops.resblock_pair_supported(x, w, w, 1)          # kernel sizes 3 / 7 / 11 only
+    assert not ops.resblock_pair_supported(x, torch.zeros(64, 64, 11, device=gpu), torch.zeros(64, 64, 11, device=gpu), 7)  # dilation <= 5
     x2 = torch.zeros(1, 32, 500, dtype=torch.float16, device=gpu)  # rows of a multiple of eight elements only
     assert not ops.resblock_pair_supported(x2, torch.zeros(32, 32, 3, device=gpu), torch.zeros(32, 32, 3, device=gpu), 1)
     x3 = torch.zeros(1, 128, 512, dtype=torch.float16, device=gpu)

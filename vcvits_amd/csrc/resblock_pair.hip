@@ -67,6 +67,12 @@ struct Geo {
   static constexpr int WSLOTS = K * CG * 2 * C;          // 16-byte slots of one conv's packed weights
   static constexpr int XT_SLOTS = N1 + 48;               // (the last conv2 tile reads up to K - 1 + 31 past its last valid column)
   static constexpr bool BOTHW = (size_t)2 * WSLOTS * 16 <= 56 * 1024;  // both convs' weights resident at once
+  // otherwise (64 channels, K >= 7: 57 - 90 KB per conv) the weights are STREAMED: one slab = one tap of one conv
+  // ([cg][h][m]: CG * 2 * C slots = 8 KB at C = 64 -- exactly one 16-byte slot per thread of the workgroup) through a ring of
+  // NRING slabs, loaded two taps ahead into a register and written to the ring before the tap's barrier
+  static constexpr int SLAB = CG * 2 * C;
+  static constexpr int NRING = 4;
+  static constexpr int W_LDS_SLOTS = BOTHW ? 2 * WSLOTS : NRING * SLAB;
 };
 
 template <int C, int K>
@@ -81,7 +87,7 @@ __host__ __device__ constexpr int xs_slots(int dil) {
 // MFMA the wave then reads ONE 1 KB fragment from LDS instead of 1.5 -- at eight waves per CU the LDS read rate, not the
 // matrix pipe, was the bound.  C = 64 (two m-tiles: 56 - 88 fragments do not fit) reads them per step.
 template <int C, int K, int WHICH, int TM, int TNW>
-__device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* __restrict__ W,
+__device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* W, const bf16x8* __restrict__ wpg,
                                          const bf16x8* __restrict__ img, int pitch, int dstep, int shift, int wave, int l31,
                                          int h) {
   constexpr int CG = C / 16;
@@ -101,6 +107,33 @@ __device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* _
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][cg], bb[tn], acc[0][tn], 0, 0, 0);
       }
+    }
+  } else if constexpr (!Geo<C, K>::BOTHW) {
+    // streamed weights: W = the ring, wpg = the packed weights in global memory, WHICH * K = this conv's first slab
+    constexpr int SLAB = Geo<C, K>::SLAB, NR = Geo<C, K>::NRING;
+    static_assert(SLAB == 64 * NWAVE, "one 16-byte slot of a slab per thread");
+    const int tid = wave * 64 + l31 + 32 * h;
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+      const int sidx = WHICH * K + j;
+      bf16x8 wnext;
+      const bool pre = sidx + 2 < 2 * K;
+      if (pre) wnext = wpg[(sidx + 2) * SLAB + tid];
+      const bf16x8* Wj = W + (sidx & (NR - 1)) * SLAB;
+#pragma unroll
+      for (int cg = 0; cg < CG; ++cg) {
+        bf16x8 a[TM], bb[TNW];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = Wj[(cg * 2 + h) * C + tm * 32 + l31];
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) bb[tn] = img[(2 * cg + h) * pitch + slot((wave * TNW + tn) * 32 + l31 + j * dstep + shift)];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+      }
+      if (pre) const_cast<bf16x8*>(W)[((sidx + 2) & (NR - 1)) * SLAB + tid] = wnext;
+      __syncthreads();  // slab sidx + 2 is in place, slab sidx is free (all waves are past this tap)
     }
   } else {
 #pragma unroll 1
@@ -137,7 +170,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* Ws = reinterpret_cast<bf16x8*>(smem);                       // [1 or 2][WSLOTS]
-  bf16x8* Xs = Ws + (G::BOTHW ? 2 : 1) * G::WSLOTS;                     // [NQ][xs_n]   (later: the waves' epilogue tiles)
+  bf16x8* Xs = Ws + G::W_LDS_SLOTS;                                    // [NQ][xs_n]   (later: the waves' epilogue tiles)
   const int xs_bytes = NQ * xs_n * 16;
   const int ep_bytes = NWAVE * 32 * 40 * 4;
   bf16x8* XTs = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Xs) + (xs_bytes > ep_bytes ? xs_bytes : ep_bytes));  // [NQ][XT_SLOTS]
@@ -199,8 +232,9 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
     const int next = tile + (int)gridDim.x;
     const bool more = next < total_tiles;
     if (more) issue(next);  // in flight under this tile's two convs
-    if (!G::BOTHW) {        // conv1's weights (the two convs' do not fit together: re-loaded per tile, from L2)
-      for (int i = tid; i < G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[i];
+    if (!G::BOTHW) {        // streamed weights: the first two slabs of conv1 (the ring is free: the tile before ended with a barrier)
+      Ws[tid] = p.wp[tid];
+      Ws[G::SLAB + tid] = p.wp[G::SLAB + tid];
       __syncthreads();
     }
 
@@ -212,7 +246,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
       for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
-    conv_mma<C, K, 0>(acc, Ws, Xs, xs_n, dil, sh, wave, l31, h);
+    conv_mma<C, K, 0>(acc, Ws, p.wp, Xs, xs_n, dil, sh, wave, l31, h);
     // epilogue 1: + b1, leaky, bf16 -> XTs; columns outside [0, T) are the zero padding of conv2's input
 #pragma unroll
     for (int tn = 0; tn < TNW; ++tn) {
@@ -238,10 +272,6 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
       }
     }
     __syncthreads();
-    if (!G::BOTHW) {  // conv2's weights over conv1's
-      for (int i = tid; i < G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[G::WSLOTS + i];
-      __syncthreads();
-    }
 
     // the epilogue's operands -- the residual x (L2: staged a tile ago) and, for a block's last pair, the accumulate target --
     // are requested NOW, so their latency hides under conv2 instead of sitting in front of every store (measured on the 48 kHz
@@ -271,7 +301,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
       for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
-    conv_mma<C, K, 1>(acc, Ws + (G::BOTHW ? G::WSLOTS : 0), XTs, G::XT_SLOTS, 1, 0, wave, l31, h);
+    conv_mma<C, K, 1>(acc, Ws + (G::BOTHW ? G::WSLOTS : 0), p.wp, XTs, G::XT_SLOTS, 1, 0, wave, l31, h);
     // epilogue 2 through the wave's LDS tile (the Xs region: nobody reads it after conv1's barrier): rows of eight consecutive
     // positions per lane, + b2 + x (fp16, re-read: L2), [y += post_scale * out], one rounding to fp16, 16-byte stores
     {
@@ -362,7 +392,7 @@ template <int C, int K>
 size_t lds_bytes(int dil) {
   using G = Geo<C, K>;
   const size_t xs = (size_t)G::NQ * xs_slots<C, K>(dil) * 16, ep = (size_t)NWAVE * 32 * 40 * 4;
-  return (size_t)(G::BOTHW ? 2 : 1) * G::WSLOTS * 16 + (xs > ep ? xs : ep) + (size_t)G::NQ * G::XT_SLOTS * 16;
+  return (size_t)G::W_LDS_SLOTS * 16 + (xs > ep ? xs : ep) + (size_t)G::NQ * G::XT_SLOTS * 16;
 }
 
 template <int C, int K>
@@ -391,10 +421,11 @@ int launch(const VcvResPairArgs& a, hipStream_t st) {
 
 bool supported(int C, int K, int dil, int T) {
   if ((C != 32 && C != 64) || (K != 3 && K != 7 && K != 11) || dil < 1 || dil > 5 || T < 64 || (T & 7)) return false;
-  // 64 channels with K >= 7: the two convs' weights (114 KB at K = 7) do not fit next to the images, and re-loading them per
-  // tile made the fused launch no faster than the two it replaces (3.5 vs 3.5 - 3.8 ms on the 48 kHz decode): left to those
-  static const bool all64 = getenv("VCVITS_PAIR_ALL64") != nullptr;
-  if (C == 64 && K > 3 && !all64) return false;
+  // 64 channels with K >= 7: the two convs' weights (114 KB at K = 7) do not fit next to the images; re-loading them per tile
+  // made the fused launch no faster than the two it replaces (3.5 vs 3.5 - 3.8 ms on the 48 kHz decode), so they are streamed
+  // tap by tap through a ring under the MFMAs (conv_mma)
+  static const bool no_stream = getenv("VCVITS_PAIR_NO_STREAM") != nullptr;  // (A/B: leave 64 channels x K >= 7 to the two launches)
+  if (C == 64 && K > 3 && no_stream) return false;
   if ((long long)T * 2 >= (1ll << 31)) return false;
   size_t lds = 0;
   if (C == 32) lds = K == 3 ? lds_bytes<32, 3>(dil) : K == 7 ? lds_bytes<32, 7>(dil) : lds_bytes<32, 11>(dil);
