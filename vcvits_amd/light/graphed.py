@@ -63,6 +63,7 @@ ENABLED = [os.environ.get("VCVITS_GRAPHS", "1") == "1"]
 # the whole batch (both optimizer passes and their AdamW steps) as one graph: on by default (VCVITS_BATCH_GRAPHS=0 keeps
 # the eager loop with the graphed no-grad generator pass)
 BATCH_ENABLED = [os.environ.get("VCVITS_BATCH_GRAPHS", os.environ.get("VCVITS_STEP_GRAPHS", "1")) == "1"]
+DDP_GRAPHS = [os.environ.get("VCVITS_DDP_GRAPHS", "0") == "1"]  # record batches whose gradient all-reduces span real ranks
 MAX_ENTRIES = int(os.environ.get("VCVITS_GRAPH_ENTRIES", "4"))  # graphs kept per object (distinct batch shapes), LRU
 MAX_COUNTED = 256  # distinct shapes whose repeat counts are remembered
 
@@ -248,9 +249,15 @@ class GraphedBatch(_Recorder):
                 and not lib().vcv_prof_active() and ops.DROPOUT_TRACE[0] is None and ops.CAPTURING[0] is None):
             return False
         for o in (og, od):
-            # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step)
-            if getattr(o, "_ddp", False) and o._static_set is None:
-                return False
+            if getattr(o, "_ddp", False):
+                # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step) ...
+                if o._static_set is None:
+                    return False
+                # ... and, across REAL ranks, only on request (VCVITS_DDP_GRAPHS=1): the recorded collectives have run here on
+                # a forced one-rank group only (one GPU per box), a graph with forks costs the host 10 - 55 ms per launch on
+                # this ROCm -- about what the eager loop costs -- and a capture that misbehaves on one of eight ranks hangs all
+                if o.world > 1 and not DDP_GRAPHS[0]:
+                    return False
         return True
 
     def run(self, batch, extra=()):
