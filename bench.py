@@ -48,10 +48,10 @@ GFLOP_PER_UTT = {("base", "vocoder"): 400.0, ("base", "full"): 488.0, ("48k", "v
                  ("48k", "infer"): 770.0, ("base", "infer"): 788.0}
 # profiler classes of the library (csrc/prof.h) and the kernel families (rocprofv3 names) each one times
 PROF_CLASSES = ["conv_gemm_kernel (register-staged)", "conv_wgrad_kernel (register-staged)",
-                "packed-weight conv kernels: fwd + dgrad + convT (conv_x3_kernel, conv_pk_kernel<F32El | Bf16El>, conv_dma_kernel)",
+                "packed-weight conv kernels: fwd + dgrad + convT (conv_x3_kernel, conv_pk_kernel<F32El | Bf16El>, conv_dma_kernel, resblock_pair_kernel)",
                 "weight-gradient kernels (wgrad_dma_kernel, wgrad_bf16_kernel)",
                 "fused attention kernels (rel_attn_fwd / bwd_rows / bwd_cols)"]
-PROF_FAMILIES = [["conv_gemm_kernel"], ["conv_wgrad_kernel"], ["conv_x3_kernel", "conv_pk_kernel", "conv_dma_kernel"],
+PROF_FAMILIES = [["conv_gemm_kernel"], ["conv_wgrad_kernel"], ["conv_x3_kernel", "conv_pk_kernel", "conv_dma_kernel", "resblock_pair_kernel"],
                  ["wgrad_dma_kernel", "wgrad_bf16_kernel"], ["rel_attn_fwd_kernel", "rel_attn_bwd_rows_kernel", "rel_attn_bwd_cols_kernel"]]
 NCLS = len(PROF_CLASSES)
 
@@ -105,6 +105,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline-full", action="store_true",
                     help="skip the second CPU leg (SURVEY 8d's config 1: full model, B=2)")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch event timing")
+    ap.add_argument("--no-host-probe", action="store_true",
+                    help="skip the idle-device host-issue probe after the timed region (counter-collection passes: fewer steps)")
     ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)  # (internal: the CPU-baseline child process)
     ap.add_argument("--no-extra", action="store_true", help="skip the short configs[2] / configs[4] legs of the default run")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -353,7 +355,7 @@ def build_infer(cfg, B, T, dev):
     return step
 
 
-def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True, f32_split=None):
+def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True, f32_split=None, host_probe=True):
     """Build the workload, do `warmup` untimed steps, time exactly `steps` steps between barrier + synchronize on both
     sides, MAX over ranks.  Returns the pieces of the JSON line."""
     from vcvits_amd import _lib, configs, ops, synthetic
@@ -427,7 +429,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     # ahead of the GPU until the launch queue is full and then blocks at the device's pace (a replayed batch is ~1,000-1,800
     # queued packets), so the wall time per issue there measures back-pressure, not host work; both are reported.
     unloaded = {}
-    if module is not None:
+    if module is not None and host_probe:
         from vcvits_amd.light import graphed
 
         def issue_once():
@@ -682,7 +684,8 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
-    r = run_leg(a.config, a.workload, a.dtype, a.batch, a.frames, a.steps, a.warmup, dev, world, rank, prof=not a.no_prof)
+    r = run_leg(a.config, a.workload, a.dtype, a.batch, a.frames, a.steps, a.warmup, dev, world, rank, prof=not a.no_prof,
+                host_probe=not a.no_host_probe)
     line = make_line(r) if rank == 0 else None
     default_run = (world == 1 and a.config == "base" and a.workload == "vocoder" and a.dtype == "f32"
                    and a.batch is None and not a.no_extra)

@@ -2,9 +2,9 @@
 # Run on the GPU box (gpurun): rocprofv3 kernel trace + the two HBM-traffic PMC passes (each in its own run, per
 # MI355X_MICROARCH.md) of the bench workloads, an MFMA-busy PMC pass of the dominant kernels, raw CSVs under
 # gpurun_out/<tag>_*/..., condensed by tools/profile_summary.py / tools/pmc_busy_summary.py into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r4'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r5'
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 # every step under its own limit: SIGUSR1 first (bench.py dumps the Python stacks of all threads into the step's log),
 # SIGKILL 20 s later -- one stuck pass must not eat the whole call
 T="timeout -s USR1 -k 20"
@@ -18,12 +18,20 @@ run() {  # name, workload key, bench flags...
   rm -rf $out
   $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-extra "$@" > $out.trace.log 2>&1
   # (counter passes: eager launches only -- the discriminator step's graph replay is switched off, same kernels)
-  VCVITS_GRAPHS=0 $T 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-extra --no-prof "$@" > $out.fetch.log 2>&1
-  VCVITS_GRAPHS=0 $T 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-extra --no-prof "$@" > $out.write.log 2>&1
+  VCVITS_GRAPHS=0 $T 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps ${PMC_STEPS:-2} --warmup ${PMC_WARMUP:-4} --no-cpu-baseline --no-extra --no-prof --no-host-probe "$@" > $out.fetch.log 2>&1
+  VCVITS_GRAPHS=0 $T 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps ${PMC_STEPS:-2} --warmup ${PMC_WARMUP:-4} --no-cpu-baseline --no-extra --no-prof --no-host-probe "$@" > $out.write.log 2>&1
   python3 tools/profile_summary.py $out profiles/$name $key > $out.summary.log 2>&1
   rm -rf $out/*/*/*.db $out/*/*_kernel_trace.csv $out/*/*/*_kernel_trace.csv $out/*/*counter_collection.csv $out/*/*/*counter_collection.csv
   keep
 }
+if [ -n "${ONLY:-}" ]; then
+  case "$ONLY" in
+    full_bf16) run ${TAG}_full_bf16 base/full/bf16 --workload full --batch 32 --dtype bf16 ;;
+  esac
+  $T 400 python3 bench.py --dtype bf16 --workload full --batch 32 --steps 10 --warmup 5 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2.json 2>/dev/null
+  keep
+  exit 0
+fi
 run ${TAG}_f32 base/vocoder/f32
 run ${TAG}_bf16 base/vocoder/bf16 --dtype bf16
 run ${TAG}_full_bf16 base/full/bf16 --workload full --batch 32 --dtype bf16

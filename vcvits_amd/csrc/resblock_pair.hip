@@ -30,6 +30,7 @@
 // Weights are packed ahead of time (vcv_resblock_pair_pack) as wp[conv][tap][cg][h][m][8]: an A fragment is one
 // ds_read_b128 of 32 consecutive rows.
 #include "common.h"
+#include "prof.h"
 #include "conv_tile.h"
 
 namespace {
@@ -65,7 +66,7 @@ struct Geo {
   static constexpr int NQ = C / 8;                       // planes per image
   static constexpr int CG = C / 16;
   static constexpr int WSLOTS = K * CG * 2 * C;          // 16-byte slots of one conv's packed weights
-  static constexpr int XT_SLOTS = N1 + 48;               // (the last conv2 tile reads up to K - 1 + 31 past its last valid column)
+  static constexpr int XT_SLOTS = N1 + 16;               // (columns N1 .. N1 + K - 2 are read for discarded outputs only: never written)
   static constexpr bool BOTHW = (size_t)2 * WSLOTS * 16 <= 56 * 1024;  // both convs' weights resident at once
   // otherwise (64 channels, K >= 7: 57 - 90 KB per conv) the weights are STREAMED: one slab = one tap of one conv
   // ([cg][h][m]: CG * 2 * C slots = 8 KB at C = 64 -- exactly one 16-byte slot per thread of the workgroup) through a ring of
@@ -174,6 +175,10 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
   const int xs_bytes = NQ * xs_n * 16;
   const int ep_bytes = NWAVE * 32 * 40 * 4;
   bf16x8* XTs = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Xs) + (xs_bytes > ep_bytes ? xs_bytes : ep_bytes));  // [NQ][XT_SLOTS]
+  // the tile's x as it is in HBM (fp16, position-innermost rows of BN): the epilogue's residual operand.  Re-reading it from
+  // global memory cost a third HBM pass (rocprofv3 FETCH_SIZE: 5.1 GB read per launch against 1.97 GB of x + halo: the
+  // re-read missed L2 more often than not)
+  unsigned short* Xraw = reinterpret_cast<unsigned short*>(XTs + NQ * G::XT_SLOTS);  // [C][BN]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,8 +206,16 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
       v[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
     }
   };
-  auto stage = [&]() {  // v[] -> leaky, bf16 -> the Xs image
+  auto stage = [&](int tile) {  // v[] -> leaky, bf16 -> the Xs image; the raw central part -> Xraw
     if (!stask) return;
+    {
+      const int bb = tile / p.ntile, tt0 = (tile - bb * p.ntile) * BN;
+      const int o = 8 * spg - (tt0 - ((tt0 - H2 - h1) & ~7));  // output position of the lane's first element (a multiple of 8)
+      if (o >= 0 && o < BN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<u32x4*>(Xraw + (sq * 8 + e) * BN + o) = v[e];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       bf16x8 o;
@@ -223,7 +236,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
   issue(tile);
   if (G::BOTHW)
     for (int i = tid; i < 2 * G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[i];
-  stage();
+  stage(tile);
   __syncthreads();
 
   for (;;) {
@@ -273,26 +286,24 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
     }
     __syncthreads();
 
-    // the epilogue's operands -- the residual x (L2: staged a tile ago) and, for a block's last pair, the accumulate target --
-    // are requested NOW, so their latency hides under conv2 instead of sitting in front of every store (measured on the 48 kHz
-    // decode: K = 3 1.71 -> 1.54 ms per launch, K = 7 2.01 -> 1.96; at K = 11 the 22 weight fragments and these 32 registers
-    // together cost more than the latency: 2.21 -> 2.57, so K = 11 loads them in the epilogue)
+    // a block's last pair: the accumulate target is requested NOW, so its latency hides under conv2 (K <= 7; at K = 11 the
+    // 22 weight fragments + these registers cost more than the latency: measured 2.21 -> 2.57 ms, so K = 11 loads it late)
     constexpr bool PRE = K <= 7;
-    us8 xres[TNW][TM][2], yacc[TNW][TM][2];
+    us8 yacc[TNW][TM][2];
     if constexpr (PRE)
+      if (p.accumulate)
 #pragma unroll
-    for (int tn = 0; tn < TNW; ++tn)
+        for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const int m = tm * 32 + ps * 16 + (lane >> 2);
-          const int o = (wave * TNW + tn) * 32 + 8 * (lane & 3);
-          const bool ok = o < BN && t0 + o < T;
-          const size_t idx = ((size_t)b * C + m) * (size_t)T + (ok ? t0 + o : 0);
-          xres[tn][tm][ps] = *reinterpret_cast<const us8*>(p.x + idx);
-          if (p.accumulate) yacc[tn][tm][ps] = *reinterpret_cast<const us8*>(p.y + idx);
-        }
+            for (int ps = 0; ps < 2; ++ps) {
+              const int m = tm * 32 + ps * 16 + (lane >> 2);
+              const int o = (wave * TNW + tn) * 32 + 8 * (lane & 3);
+              const bool ok = o < BN && t0 + o < T;
+              const size_t idx = ((size_t)b * C + m) * (size_t)T + (ok ? t0 + o : 0);
+              yacc[tn][tm][ps] = *reinterpret_cast<const us8*>(p.y + idx);
+            }
 
     // ---- conv2: out[m][o], o in [0, BN): same tile ownership; xt column of (o, tap j) = o + j ----
 #pragma unroll
@@ -336,9 +347,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
               *reinterpret_cast<us8*>(p.y + idx) = out;
               continue;
             }
-            us8 xr;
-            if constexpr (PRE) xr = xres[tn][tm][ps];
-            else xr = *reinterpret_cast<const us8*>(p.x + idx);
+            const us8 xr = *reinterpret_cast<const us8*>(Xraw + m * BN + o);  // the residual, from the staged tile
             float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             float yy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.accumulate) {
@@ -363,7 +372,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
     }
     if (!more) break;
     __syncthreads();  // every wave's epilogue tile (the Xs region) is done
-    stage();          // the next tile's image
+    stage(next);      // the next tile's image
     __syncthreads();
     tile = next;
   }
@@ -392,7 +401,7 @@ template <int C, int K>
 size_t lds_bytes(int dil) {
   using G = Geo<C, K>;
   const size_t xs = (size_t)G::NQ * xs_slots<C, K>(dil) * 16, ep = (size_t)NWAVE * 32 * 40 * 4;
-  return (size_t)G::W_LDS_SLOTS * 16 + (xs > ep ? xs : ep) + (size_t)G::NQ * G::XT_SLOTS * 16;
+  return (size_t)G::W_LDS_SLOTS * 16 + (xs > ep ? xs : ep) + (size_t)G::NQ * G::XT_SLOTS * 16 + (size_t)C * G::BN * 2;
 }
 
 template <int C, int K>
@@ -415,7 +424,13 @@ int launch(const VcvResPairArgs& a, hipStream_t st) {
   static const long long forced = [] { const char* e = getenv("VCVITS_PAIR_GRID"); return e ? atoll(e) : 0ll; }();
   const long long grid = forced > 0 ? (forced < nblk ? forced : nblk) : (nblk < slots ? nblk : slots);
   if (xs_slots<C, K>(a.dil) / 8 > 64 * (NWAVE / G::NQ)) return VCV_EINVAL;  // (one staging task per lane)
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWAVE), (unsigned)lds, st, p, xs_slots<C, K>(a.dil), (int)nblk);
+  // per-launch events of bench.py's roofline object: the packed-weight conv class (the launch replaces two of its members)
+  const double flops = 2.0 * 2.0 * a.B * (double)C * C * K * (double)a.T;
+  const double abytes = 2.0 * (double)a.B * C * (double)a.T * (2 + (a.accumulate ? 1 : 0)) + 2.0 * 2.0 * C * C * K;
+  const int tag[12] = {a.B, 2, C, C, K, a.T, 1, 1, 1, 100 + a.dil, C * 1000 + G::BN, 16};
+  hipEvent_t ev0, ev1;
+  vcv_prof_events(VCV_PROF_CONV_DMA, flops, tag, 12, &ev0, &ev1, abytes, flops / VCV_PEAK_BF16_MFMA);
+  VCV_LAUNCH_EV(kern, dim3((unsigned)grid), dim3(64 * NWAVE), (unsigned)lds, st, ev0, ev1, p, xs_slots<C, K>(a.dil), (int)nblk);
   return vcv_check_launch();
 }
 
