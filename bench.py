@@ -61,7 +61,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "vcvits_amd", "csrc", "*.hip")) +
                     glob.glob(os.path.join(ROOT, "vcvits_amd", "csrc", "*.h")) +
-                    [os.path.join(ROOT, "include", "vcvits_hip.h"), os.path.join(ROOT, "vcvits_amd", "ops.py")]):
+                    [os.path.join(ROOT, "include", "vcvits_hip.h")] + glob.glob(os.path.join(ROOT, "vcvits_amd", "ops", "*.py"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

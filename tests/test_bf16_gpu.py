@@ -209,7 +209,7 @@ def test_infer_waveform_rms_bf16_48k(gpu, bf16_mode):
         z_o = O.flow_forward(sd, "n.flow", m_p + noise * torch.exp(logs_p), mask, g, True, C, H, 5, 1, 4)
         o_o = O.generator_forward(sd, "n.dec", z_o * mask)
     assert used >= 60, "only %d launches of the decoder ran on the bf16 kernels" % used
-    assert ops.LAUNCH_COUNTS["bf16io"] >= 76, "the decoder did not keep its activations in bf16"
+    assert ops.LAUNCH_COUNTS["bf16io"] + 2 * ops.LAUNCH_COUNTS.get("pair_fused", 0) >= 76, "the decoder did not keep its activations in bf16"
     assert _rms(z, z_o) <= 2e-2 * z_o.pow(2).mean().sqrt().item()  # flow output within bf16 rounding of the fp32 path
     sig = o_o.pow(2).mean().sqrt().item()
     r = _rms(o, o_o)
@@ -263,3 +263,40 @@ def test_grouped41_forward_bf16_operands(gpu):
                 ops.set_compute_dtype("f32")
             werr = float((wgot - wref).abs().max() / wref.abs().max())
             assert werr < (2e-5 if tf == ops.TF_NONE else tol), ("wgrad", B, G, Tin, tf, werr)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96, 3000, 1), (2, 48, 40, 3000, 3), (3, 32, 64, 2500, 5), (2, 36, 33, 2000, 7),
+                                   (2, 64, 32, 2200, 11), (2, 32, 32, 1800, 16), (2, 50, 64, 2000, 5)],
+                         ids=lambda s: "B%d-C%d-M%d-T%d-K%d" % s)
+def test_wgrad_bf16_split_reduction_every_finish_variant(gpu, bf16_mode, shape):
+    """The split-reduction finishing pass (wgrad_bf16_finish4_kernel: z-lane groups 4 / 8 / 16 / 32 x tap buckets
+    1 / 3 / 5 / 8 / 11 / 16, and the 4-byte kernel for channel counts that are not a multiple of 4) at forced split counts:
+    every count gives the fp32 CPU gradient of the rounded operands, and a count is bit-reproducible."""
+    from vcvits_amd import _lib
+    ops = bf16_mode
+    B, C, M, T, K = shape
+    rng = np.random.default_rng(B * 1000 + C * 10 + K)
+    t = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))
+    x, dy = t(B, C, T), t(B, M, T)
+    pad = K // 2 if K % 2 else 0
+    if not K % 2:
+        dy = dy[:, :, :T - K + 1].contiguous()
+    wq = torch.zeros(M, C, K, requires_grad=True)
+    ref = torch.autograd.grad(F.conv1d(rb(x), wq, None, padding=pad), wq, rb(dy))[0]
+    xg, dyg = x.to(gpu), dy.to(gpu)
+    L = _lib.lib()
+    try:
+        for z in (1, 3, 4, 7, 8, 13, 16, 29, 64):
+            L.vcv_wgrad_bf16_set_force(-1, z)
+            before = ops.LAUNCH_COUNTS["wgrad_bf16"]
+            got = ops.conv_wgrad(dyg, xg, (M, C, K), pad=pad)
+            assert ops.LAUNCH_COUNTS["wgrad_bf16"] == before + 1
+            assert rel(got, ref) < 2e-5, (z, rel(got, ref))
+            again = ops.conv_wgrad(dyg, xg, (M, C, K), pad=pad)
+            assert torch.equal(got, again), "split count %d is not bit-reproducible" % z
+            # accumulate onto an existing gradient with a scale
+            acc = got.clone()
+            ops.conv_wgrad(dyg, xg, (M, C, K), pad=pad, out=acc, alpha=0.5)
+            assert rel(acc, 1.5 * ref) < 2e-5, (z, "accumulate")
+    finally:
+        L.vcv_wgrad_bf16_set_force(-1, -1)

@@ -391,7 +391,7 @@ def test_captured_backward_regenerates_the_replays_dropout_mask(gpu):
             s = real_next()
             seeds.append(s)
             return s
-        ops.next_seed = recording
+        ops.replace("next_seed", recording)
         run()  # warm-up (plans, allocator)
         seeds.clear()
         graph = torch.cuda.CUDAGraph()
@@ -415,11 +415,11 @@ def test_captured_backward_regenerates_the_replays_dropout_mask(gpu):
             torch.cuda.synchronize()
             got = [t.clone() for t in outs]
             it = iter((s + k) % (1 << 64) for s in baked)
-            ops.next_seed = lambda: next(it)
+            ops.replace("next_seed", lambda: next(it))
             want = run()
             for a, b in zip(got, want):
                 assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
             assert float((got[1] == 0).float().mean()) > 0.2
     finally:
-        ops.next_seed = real_next
+        ops.replace("next_seed", real_next)
         L.vcv_set_seed_offset_ptr(None)

@@ -1,5 +1,5 @@
 """Condense a VCVITS_PARITY_STATS file (tests/golden_util.record_stats) into the summaries under profiles/:
-python tools/parity_summary.py gpurun_out/parity_all.txt profiles/r3_parity_stats"""
+python tools/parity_summary.py gpurun_out/parity_all.txt profiles/r5_parity_stats   (tools/suite_loop.sh records and condenses it)"""
 import collections
 import sys
 

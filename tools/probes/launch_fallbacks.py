@@ -21,13 +21,13 @@ def entry(w):
     e = orig_entry(w)
     cur["e"] = e
     return e
-ops._stable_entry = entry
+ops.replace("_stable_entry", entry)
 orig_launch = ops._launch_conv
-def launch(a, flip_w=None):
+def launch(a, flip_w=None, wt=None):
     cur["e"] = "unset"
     before = dict(ops.LAUNCH_COUNTS)
     n_packs = {id(e): len(e["packs"]) for e in ops._WN_CACHE.values()}
-    orig_launch(a, flip_w)
+    orig_launch(a, flip_w, wt)
     e = cur.get("e")
     fam = [k for k in ops.LAUNCH_COUNTS if ops.LAUNCH_COUNTS[k] != before.get(k, 0)]
     if e == "unset":
@@ -36,7 +36,7 @@ def launch(a, flip_w=None):
         stat[("NO ENTRY (plain weight)", tuple(fam), a.Cg, a.Mg, a.K, a.B, a.Tout, a.P, flip_w is not None)] += 1
     elif len(e["packs"]) != n_packs.get(id(e)):
         stat[("MISS in entry", tuple(fam), a.Cg, a.Mg, a.K, a.B, a.Tout, a.P, flip_w is not None)] += 1
-ops._launch_conv = launch
+ops.replace("_launch_conv", launch)
 for i in range(2):
     module.fit_batch(batches[i % 2])
 torch.cuda.synchronize()

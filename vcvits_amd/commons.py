@@ -1,5 +1,5 @@
 """Host-side helpers with the reference's names (vits/commons.py); the tensor work goes through
-the HIP kernels in ops.py."""
+the HIP kernels in ops/."""
 import torch
 
 from . import ops

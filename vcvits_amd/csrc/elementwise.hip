@@ -204,6 +204,48 @@ act_grad_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, 
   if (threadIdx.x == 0) unsafeAtomicAdd(db + c, red[0] + red[1] + red[2] + red[3]);
 }
 
+// the same over rows whose length is a multiple of 4, 16 bytes per access: a unit is 1024 floats = one float4 per thread,
+// four units (four dy + four y loads) in flight per thread
+__global__ void __launch_bounds__(256)
+act_grad_bias4_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ out,
+                      float* __restrict__ db, int B, int C, int T4, int tf, float slope, int nseg) {
+  const int c = blockIdx.x, seg = blockIdx.y;
+  const int nchunk = (T4 + 255) >> 8;
+  const int units = B * nchunk;
+  const int per = (units + nseg - 1) / nseg;
+  const int lo = seg * per;
+  const int hi = lo + per < units ? lo + per : units;
+  float s = 0.f;
+  for (int unit0 = lo; unit0 < hi; unit0 += 4) {
+    float4 dv[4], yv[4];
+    size_t idx[4];
+    bool in[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int unit = unit0 + q;
+      const int b = unit / nchunk, ch = unit - b * nchunk;
+      const int t = (ch << 8) + threadIdx.x;
+      in[q] = unit < hi && t < T4;
+      idx[q] = ((size_t)b * C + c) * (size_t)T4 + t;
+      dv[q] = in[q] ? dy[idx[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[q] = (in[q] && tf != VCV_TF_NONE) ? y[idx[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (in[q]) {
+        const float4 v = make_float4(vcv_tf_val(dv[q].x, tf, yv[q].x, slope), vcv_tf_val(dv[q].y, tf, yv[q].y, slope),
+                                     vcv_tf_val(dv[q].z, tf, yv[q].z, slope), vcv_tf_val(dv[q].w, tf, yv[q].w, slope));
+        out[idx[q]] = v;
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(db + c, red[0] + red[1] + red[2] + red[3]);
+}
+
 // y[b, c, t] = x[b, c, t] * mask[b, t]
 __global__ void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                 float* __restrict__ y, int C, int T, size_t n) {
@@ -484,8 +526,13 @@ extern "C" int vcv_act_grad_bias(const float* dy, const float* y, float* out, fl
   long long nseg = (2048 + C - 1) / C;
   if (nseg > units) nseg = units;
   if (nseg < 1 || vcv_get_deterministic()) nseg = 1;
-  hipLaunchKernelGGL(act_grad_bias_kernel, dim3(C, (unsigned)nseg), dim3(256), 0, ST, dy, y, out, dbias, B, C, T, tf, slope,
-                     (int)nseg);
+  static const bool scalar_only = getenv("VCVITS_ACT_GRAD_SCALAR") != nullptr;  // (A/B switch)
+  if (!scalar_only && (T & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(act_grad_bias4_kernel, dim3(C, (unsigned)nseg), dim3(256), 0, ST, (const float4*)dy, (const float4*)y,
+                       (float4*)out, dbias, B, C, T / 4, tf, slope, (int)nseg);
+  else
+    hipLaunchKernelGGL(act_grad_bias_kernel, dim3(C, (unsigned)nseg), dim3(256), 0, ST, dy, y, out, dbias, B, C, T, tf, slope,
+                       (int)nseg);
   return vcv_check_launch();
 }
 

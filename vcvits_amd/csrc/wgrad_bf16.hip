@@ -393,6 +393,88 @@ __global__ void __launch_bounds__(256) wgrad_bf16_finish_kernel(const float* __r
   }
 }
 
+// The same reduction with 16-byte slab reads and the slabs' loads of a thread all in flight at once (round 5: the kernel
+// above kept two 4-byte loads per thread outstanding and ran at ~2 TB/s -- 4-6 % of the bf16-mode steps).  A workgroup is
+// 32 groups of 8 lanes; a group reads the 32 c of one (k, m) row of a slab as eight float4.  The 32 groups are ZG z-lanes
+// x MR = 32 / ZG rows of m; a group walks the slabs z = zg, zg + ZG, ... (ZU of them per round) for all K taps, so a
+// thread has KB x ZU independent 16-byte loads outstanding.  z-lanes meet by xor-shuffles inside a wave (fixed tree), waves
+// through LDS, slabs in a fixed order: deterministic.  KB >= K (register accumulators); needs C % 4 == 0.
+template <int ZG, int KB>
+__global__ void __launch_bounds__(256) wgrad_bf16_finish4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
+                                                                 int C, int K, int Z, float alpha) {
+  constexpr int MR = 32 / ZG;
+  constexpr int ZU = KB >= 11 ? 1 : 16 / KB;
+  constexpr int P = ZG > 8 ? ZG / 8 : 1;  // partial sums per m row left after the in-wave tree
+  constexpr int ZW = ZG < 8 ? ZG : 8;     // z-lanes of one m row inside a wave
+  __shared__ float red[P * MR][KB][33];
+  const int t = threadIdx.x, l8 = t & 7, grp = t >> 3;
+  const int zg = grp % ZG, mr = grp / ZG;
+  const int m = blockIdx.y * MR + mr, cb = blockIdx.x * 32, c = cb + l8 * 4;
+  const size_t n = (size_t)M * C * K, kstride = (size_t)M * C;
+  float4 acc[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m < M && c < C) {
+    const float* base = slab + (size_t)m * C + c;
+    for (int z0 = zg; z0 < Z; z0 += ZG * ZU) {
+      float4 v[ZU][KB];
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        const int z = z0 + u * ZG;
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          v[u][k] = (z < Z && k < K) ? *(const float4*)(base + (size_t)z * n + (size_t)k * kstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < ZU; ++u)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          acc[k].x += v[u][k].x; acc[k].y += v[u][k].y; acc[k].z += v[u][k].z; acc[k].w += v[u][k].w;
+        }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    if (k < K) {
+#pragma unroll
+      for (int o = 8; o < 8 * ZW; o <<= 1) {
+        acc[k].x += __shfl_xor(acc[k].x, o, 64); acc[k].y += __shfl_xor(acc[k].y, o, 64);
+        acc[k].z += __shfl_xor(acc[k].z, o, 64); acc[k].w += __shfl_xor(acc[k].w, o, 64);
+      }
+      if ((zg & (ZW - 1)) == 0) {
+        float* r = &red[mr * P + (ZG > 8 ? zg >> 3 : 0)][k][l8 * 4];
+        r[0] = acc[k].x; r[1] = acc[k].y; r[2] = acc[k].z; r[3] = acc[k].w;
+      }
+    }
+  }
+  __syncthreads();
+  const int per = 32 * K;
+  for (int idx = t; idx < MR * per; idx += 256) {
+    const int r = idx / per, q = idx - r * per;
+    const int cc = q / K, k = q - cc * K;
+    const int mm = blockIdx.y * MR + r;
+    if (mm < M && cb + cc < C) {
+      float sum = red[r * P][k][cc];
+#pragma unroll
+      for (int p = 1; p < P; ++p) sum += red[r * P + p][k][cc];
+      dw[((size_t)mm * C + cb + cc) * K + k] += alpha * sum;
+    }
+  }
+}
+
+template <int ZG>
+void launch_finish4(const float* slab, float* dw, int M, int C, int K, int Z, float alpha, hipStream_t st) {
+  const dim3 grid((unsigned)vcv_cdiv(C, 32), (unsigned)vcv_cdiv(M, 32 / ZG)), block(256);
+#define WB_F4(kb) hipLaunchKernelGGL((wgrad_bf16_finish4_kernel<ZG, kb>), grid, block, 0, st, slab, dw, M, C, K, Z, alpha)
+  if (K <= 1) WB_F4(1);
+  else if (K <= 3) WB_F4(3);
+  else if (K <= 5) WB_F4(5);
+  else if (K <= 8) WB_F4(8);
+  else if (K <= 11) WB_F4(11);
+  else WB_F4(16);
+#undef WB_F4
+}
+
 int g_force_cand = -1, g_force_z = -1;  // tuning probe (tools/wgrad_variant_sweep.py): -1 = the library's choice
 
 constexpr int MAXT = 2;
@@ -469,7 +551,13 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes, NT * flops / VCV_PEAK_BF16_MFMA);
   VCV_LAUNCH_EV(kern, grid, block, (unsigned)lds, st, ev0, ev1, a, g, scratch);
-  if (g.Z <= 12)
+  static const bool finish_scalar = getenv("VCVITS_WGRAD_FINISH_SCALAR") != nullptr;  // (A/B switch: the 4-byte kernel)
+  if (!finish_scalar && (a.Cg & 3) == 0 && ((uintptr_t)scratch & 15) == 0) {
+    if (g.Z <= 4) launch_finish4<4>(scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha, st);
+    else if (g.Z <= 8) launch_finish4<8>(scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha, st);
+    else if (g.Z <= 16) launch_finish4<16>(scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha, st);
+    else launch_finish4<32>(scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha, st);
+  } else if (g.Z <= 12)
     hipLaunchKernelGGL(wgrad_bf16_finish_kernel<true>, dim3((unsigned)vcv_cdiv(a.Cg, 32), (unsigned)vcv_cdiv(a.Mg, 8)), dim3(256), 0,
                        st, (const float*)scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha);
   else

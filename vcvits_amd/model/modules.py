@@ -1,5 +1,5 @@
 """Building blocks with the reference's names and state_dict keys (vits/model/modules.py), whose
-forward/backward run on the HIP kernels behind ops.py."""
+forward/backward run on the HIP kernels behind ops/."""
 import torch
 from torch import nn
 
