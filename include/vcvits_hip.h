@@ -261,6 +261,12 @@ int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y,
  * K <= 16), y / dy [B,M,Tout,P].  Forward fuses bias + out_act; dgrad gives dx [B,1,Tin,P] (overwrites). */
 int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin, int Tout,
                     int P, int K, int stride, int dil, int pad, int out_act, float slope, void* stream);
+/* The same with y[b,m,t,p] *= leaky'(oaux[b,m,t,p]) in the epilogue (oaux may be NULL): the data gradient of a one-OUTPUT-
+ * channel conv is this launch with the flipped taps, and oaux the leaky-ReLU output the gradient flows back into
+ * (the pass the reference's autograd spends on LeakyReluBackward, discriminator.py:38,69; generator conv_post). */
+int vcv_conv_c1_fwd_masked(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B, int M,
+                           int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
+                           void* stream);
 int vcv_conv_c1_dgrad(const float* dy, const float* w, float* dx, int B, int M, int Tin, int Tout, int P, int K,
                       int stride, int dil, int pad, void* stream);
 /* One-frame pointwise layers (speaker conditioning `cond_layer` / `cond`: Conv1d(gin, M, 1) applied to g [B, gin, 1],

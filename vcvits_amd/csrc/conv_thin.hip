@@ -348,13 +348,14 @@ constexpr int C1_MMAX = 64;
 __global__ void __launch_bounds__(256)
 conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                    float* __restrict__ y, int M, int Tin, int Tout, int P, int K, int s, int d, int pad, int out_act,
-                   float slope) {
+                   float slope, int mch, const float* __restrict__ oaux) {
   __shared__ float ws[C1_MMAX * KMAX];
   __shared__ float bs[C1_MMAX];
-  // blockIdx.z: chunk of C1_MMAX output channels (wide one-input-channel layers, e.g. the data gradient of a
-  // 1024 -> 1 conv_post, which is a one-input-channel convolution with flipped taps)
-  const int mfull = M, m0 = blockIdx.z * C1_MMAX;
-  M = M - m0 < C1_MMAX ? M - m0 : C1_MMAX;
+  // blockIdx.z: chunk of mch <= C1_MMAX output channels (wide one-input-channel layers, e.g. the data gradient of a
+  // 1024 -> 1 conv_post, which is a one-input-channel convolution with flipped taps; narrow chunks when the position
+  // tiles alone leave the chip short of workgroups -- the layer is a write stream of M rows per position tile)
+  const int mfull = M, m0 = blockIdx.z * mch;
+  M = M - m0 < mch ? M - m0 : mch;
   w += (size_t)m0 * K;
   if (bias) bias += m0;
   for (int i = threadIdx.x; i < M * K; i += 256) ws[i] = w[i];
@@ -377,13 +378,17 @@ conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     xv[k] = (k < K && r >= 0 && r < Tin) ? xb[(size_t)r * P + pc] : 0.f;
   }
   float* yb = y + ((size_t)b * mfull + m0) * U + u;
+  // oaux (a data gradient's launch): the leaky-ReLU output this gradient flows back into -- its derivative in the epilogue
+  const float* ob = oaux ? oaux + ((size_t)b * mfull + m0) * U + u : nullptr;
   for (int m = mr; m < M; m += R) {
     float acc = bs[m];
     const float* wr = ws + m * K;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
       if (k < K) acc += wr[k] * xv[k];
-    yb[(size_t)m * U] = vcv_act(acc, out_act, slope);
+    acc = vcv_act(acc, out_act, slope);
+    if (ob) acc *= vcv_dleaky(ob[(size_t)m * U], slope);
+    yb[(size_t)m * U] = acc;
   }
 }
 
@@ -509,13 +514,28 @@ extern "C" int vcv_linear_t1_wgrad(const float* dy, const float* x, float* dw, i
   return vcv_check_launch();
 }
 
+extern "C" int vcv_conv_c1_fwd_masked(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B,
+                                      int M, int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act,
+                                      float slope, void* stream);
 extern "C" int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin,
                                int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
                                void* stream) {
+  return vcv_conv_c1_fwd_masked(x, w, bias, y, nullptr, B, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope, stream);
+}
+
+extern "C" int vcv_conv_c1_fwd_masked(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B,
+                                      int M, int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act,
+                                      float slope, void* stream) {
   if (!x || !w || !y || B <= 0 || M <= 0 || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || K > KMAX || stride <= 0)
     return VCV_EINVAL;
-  hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(vcv_cdiv(Tout * P, 256), B, vcv_cdiv(M, C1_MMAX)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                     y, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope);
+  // channels per workgroup: halve the chunk (64 .. 8) until the grid has ~2,048 workgroups
+  static const int force = getenv("VCVITS_C1_CHUNK") ? atoi(getenv("VCVITS_C1_CHUNK")) : 0;  // (A/B switch)
+  int mch = M < C1_MMAX ? M : C1_MMAX;
+  const long long tiles = (long long)vcv_cdiv(Tout * P, 256) * B;
+  while (mch > 8 && tiles * vcv_cdiv(M, mch) < 2048) mch = (mch + 1) / 2;
+  if (force > 0) mch = force < C1_MMAX ? force : C1_MMAX;
+  hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(vcv_cdiv(Tout * P, 256), B, vcv_cdiv(M, mch)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     y, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope, mch, oaux);
   return vcv_check_launch();
 }
 
