@@ -6,8 +6,7 @@ both signals share every weight, so they are stacked into ONE batch of 2B: each 
 weight-gradient reduction, is a single launch over both.  When the weights are frozen (G step,
 Lightning-1.x toggle_optimizer semantics) the two signals are stacked as well, and the backward of
 every conv is restricted to the generated half (`ops.grad_batch_start`), so no data-gradient work is
-issued for the real branch.  In the discriminator step proper (weights with gradients, inputs without) the
-pass runs inside `ops.premask_chain`: activation derivatives ride in the data-gradient epilogues."""
+issued for the real branch."""
 import torch
 
 
@@ -21,15 +20,7 @@ def run_pair(disc, y, y_hat):
     wants_wgrad = torch.is_grad_enabled() and any(p.requires_grad for p in disc.parameters())
     B = y.shape[0]
     if wants_wgrad or not (y_hat.requires_grad and torch.is_grad_enabled()):
-        from ... import ops
-        if wants_wgrad and not (y.requires_grad or y_hat.requires_grad):
-            # the discriminator step proper (vcvits.py:153-157: only the outputs enter the loss): the chain of leaky convs
-            # hands its gradients on with the activation derivative applied in the data-gradient epilogue, and the
-            # feature maps are recorded without gradient
-            with ops.premask_chain():
-                out, fmap = disc(torch.cat([y, y_hat], dim=0))
-        else:
-            out, fmap = disc(torch.cat([y, y_hat], dim=0))
+        out, fmap = disc(torch.cat([y, y_hat], dim=0))
         return out[:B], out[B:], [f[:B] for f in fmap], [f[B:] for f in fmap]
     # frozen weights, gradient wanted for y_hat only: still ONE stacked forward pass (wider GEMM tiles,
     # half the launches, weight norm computed once); the backward is told to skip the real half

@@ -411,29 +411,6 @@ class grad_batch_start:
         return False
 
 
-_PREMASK = [__import__("os").environ.get("VCVITS_PREMASK", "1") == "1"]  # (A/B switch)
-_PREMASK_CHAIN = [False]
-
-
-class premask_chain:
-    """Context (the discriminators' weight-gradient pass, model/discriminators/_pair.py): inside, a convolution whose input
-    is the leaky-ReLU output of another convolution applies that activation's derivative in the epilogue of its own
-    data-gradient launch (`out_tf = TF_DLEAKY` with its saved input as the mask -- the input IS the activation output, so
-    its sign is the pre-activation's) and tells the producer, whose backward then skips its activation-derivative pass
-    over the gradient (read dy, read y, write the masked copy) and takes its bias gradient from the weight-gradient
-    launch.  Valid only while that output has NO other consumer with a gradient: fmap_tap records detached maps inside
-    (the reference's discriminator step ignores the feature maps, vcvits.py:153-157)."""
-
-    def __enter__(self):
-        self.prev = _PREMASK_CHAIN[0]
-        _PREMASK_CHAIN[0] = _PREMASK[0]
-        return self
-
-    def __exit__(self, *exc):
-        _PREMASK_CHAIN[0] = self.prev
-        return False
-
-
 class FmapTap:
     """A feature map recorded inside grad_batch_start(b0): `real` = the leading b0 batch elements (no gradient),
     `fake` = the trailing ones (gradient flows through fmap_tap's node)."""
@@ -491,8 +468,6 @@ def fmap_tap(x):
         producer = fn if (fn is not None and getattr(fn, "tap_ok", False)) else None
         xp, tail = _TapFn.apply(x, b0, producer)
         return xp, FmapTap(x.detach()[:b0], tail)
-    if _PREMASK_CHAIN[0]:
-        return x, x.detach()  # (premask_chain: the pass-through must stay x's only consumer with a gradient)
     return x, x
 
 
@@ -510,11 +485,8 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv(in_act(x), w) + bias) + res      (act and res are mutually exclusive)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, transposed, link=None,
-                premask_src=None):
+    def forward(ctx, x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, transposed, link=None):
         ctx.link = link
-        ctx.premask_src = premask_src  # the conv node whose leaky output x is (premask_chain), or None
-        ctx.premasked = False          # set by this node's consumer when the gradient arrives already masked
         x, w = _f32c(x), _f32c(w)
         bias, res = _f32c(bias), _f32c(res)
         if out_act != ACT_NONE and res is not None:
@@ -549,12 +521,6 @@ class _ConvFn(torch.autograd.Function):
         # gradient of the output (the feature-matching loss's) can be summed inside that pass -- _TapFn leaves it in tap_add
         ctx.tap_ok = out_act != ACT_NONE and not (bias is not None and bias.requires_grad and not ctx.bt)
         ctx.tap_add = None
-        # (premask_chain) a consumer may hand this node its gradient with the activation derivative already applied
-        ctx.premask_ok = (_PREMASK_CHAIN[0] and out_act == ACT_LEAKY and not ctx.bt and not transposed and ctx.b0 == 0
-                          and _GRAD_B0[0] == 0)
-        if (ctx.bt or transposed or in_leaky or groups != 1 or _GRAD_B0[0] != 0
-                or (w.shape[0] == 1 and not (stride == 1 and w.shape[1] >= 16 and w.shape[2] <= 16))):
-            ctx.premask_src = None  # (this node's data gradient runs on a path without the masked epilogue)
         ctx.save_for_backward(x, w, y if out_act != ACT_NONE else None)
         return y
 
@@ -569,8 +535,6 @@ class _ConvFn(torch.autograd.Function):
         if ctx.link is not None and ctx.link[1] == "dst":
             link_dres, ctx.link[0].dres = ctx.link[0].dres, None
         dtf = _ACT_TO_DTF[out_act]
-        if ctx.premasked:
-            dtf, y = TF_NONE, None  # (premask_chain) the consumer's data-gradient epilogue applied this node's derivative
         if ctx.tap_add is not None and (dtf == TF_NONE or (ctx.has_bias and ctx.needs_input_grad[2] and not ctx.bt)):
             tap, ctx.tap_add = ctx.tap_add, None  # (not the plain activation-derivative branch after all: add it here)
             dy[tap[1]:].add_(tap[0])
@@ -620,19 +584,13 @@ class _ConvFn(torch.autograd.Function):
                 dw = _sunk(ctx.w_sink, dw)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = _sunk(ctx.b_sink, bias_grad(dy, slope=slope, out=ctx.b_sink[0] if ctx.b_sink is not None else None))
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             b0 = ctx.b0 if 0 < ctx.b0 < x.shape[0] else 0
             dys, ys, xs = (dy[b0:], (y[b0:] if y is not None else None), x[b0:]) if b0 else (dy, y, x)
             kw = dict(in_tf=dtf, xaux=ys, slope=slope)
             if in_leaky:
                 kw.update(out_tf=TF_DLEAKY, oaux=xs)
-            elif (ctx.premask_src is not None and b0 == 0 and dtf == TF_NONE and link_dres is None
-                  and getattr(ctx.premask_src, "premask_ok", False)):
-                # x is the producer's leaky output: its derivative goes into this launch's epilogue
-                kw.update(out_tf=TF_DLEAKY, oaux=xs, slope=ctx.premask_src.cfg[6])
-                ctx.premask_src.premasked = True
-                LAUNCH_COUNTS["premasked"] = LAUNCH_COUNTS.get("premasked", 0) + 1
             if link_dres is not None and not transposed:
                 kw["res"] = link_dres[b0:] if b0 else link_dres
                 link_dres = None
@@ -686,7 +644,7 @@ class _ConvFn(torch.autograd.Function):
                 ctx.link[0].dres = dy
             else:
                 dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 class _LinearT1Fn(torch.autograd.Function):
@@ -739,13 +697,8 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, in_leaky=False, ou
     if (x.dim() == 3 and x.shape[2] == 1 and w.dim() == 3 and w.shape[2] == 1 and groups == 1 and stride == 1 and pad == 0
             and not in_leaky and out_act == ACT_NONE and res is None and x.shape[0] <= 32 and w.shape[0] >= 32):
         return _LinearT1Fn.apply(x, w, bias)
-    src = None
-    if _PREMASK_CHAIN[0] and torch.is_grad_enabled() and x.requires_grad:
-        fn = x.grad_fn
-        if fn is not None and getattr(fn, "premask_ok", False):
-            src = fn
-    return _ConvFn.apply(x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, False, link, src)
+    return _ConvFn.apply(x, w, bias, res, stride, pad, dil, groups, in_leaky, out_act, slope, False, link)
 
 
 def conv_transpose1d(x, w, bias=None, stride=1, pad=0, in_leaky=False, out_act=ACT_NONE, slope=0.1):
-    return _ConvFn.apply(x, w, bias, None, stride, pad, 1, 1, in_leaky, out_act, slope, True, None, None)
+    return _ConvFn.apply(x, w, bias, None, stride, pad, 1, 1, in_leaky, out_act, slope, True, None)
