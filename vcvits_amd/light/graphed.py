@@ -319,7 +319,6 @@ class GraphedBatch(_Recorder):
         for o in (og, od):  # the {lr, step delta} records of the two recorded AdamW steps: allocated (and kept) outside the pool
             if o.hyper is None:
                 o.hyper = torch.zeros(2, device=dev, dtype=torch.int32)
-        skip_adamw = os.environ.get("VCVITS_DBG_NO_ADAMW", "0") == "1"
         state = {}
 
         def body(cap):
@@ -331,11 +330,7 @@ class GraphedBatch(_Recorder):
                     opt.zero_grad()
                     loss = m.training_step(static, 0, idx)
                     loss.backward()
-                    if skip_adamw:  # (debug A/B: the recorded batch without its optimizer steps)
-                        opt.finish_grad_sync()
-                        opt.captured_ranges = []
-                    else:
-                        opt.step()  # (finish_grad_sync inside: the all-reduce joins are part of the graph)
+                    opt.step()  # (finish_grad_sync inside: the all-reduce joins are part of the graph)
                     losses["g" if idx == 0 else "d"] = loss.detach()
                     state["touched_%s" % ("g" if idx == 0 else "d")] = bytes(opt._touched)
                     state["ranges_%s" % ("g" if idx == 0 else "d")] = list(opt.captured_ranges or [])

@@ -103,12 +103,6 @@ def set_bf16_activations(on):
 CAPTURING = _lib.CAPTURE
 
 
-_DBG_TABLE_NODES = __import__("os").environ.get("VCVITS_DBG_TABLE_NODES", "0") == "1"
-
-
-_DBG_NO_LOCAL_CACHE = __import__("os").environ.get("VCVITS_DBG_NO_LOCAL_CACHE", "0") == "1"
-
-
 def _upload_table(tab, dev):
     """int64 host table (numpy) -> device tensor.  Eager: through a pinned staging copy on the current stream.  While a
     launch sequence is being recorded (CAPTURING): the tensor is allocated now (its address is what the recorded launches
@@ -121,8 +115,8 @@ def _upload_table(tab, dev):
         return torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
     import numpy as np
     tab = np.ascontiguousarray(tab)
-    out = None if _DBG_TABLE_NODES else cap.table(tab, torch.int64, tab.shape)
-    if out is None:  # (table arena full, or the A/B switch: round 4's form -- a recorded copy node re-reading the host array)
+    out = cap.table(tab, torch.int64, tab.shape)
+    if out is None:  # (table arena full: round 4's form -- a recorded copy node re-reading the host array)
         out = torch.empty(tab.shape, device=dev, dtype=torch.int64)
         check(lib().vcv_upload_table(ptr(out), ctypes.c_void_p(tab.ctypes.data), tab.nbytes, stream()), "vcv_upload_table")
         cap.append(tab)

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from .._lib import (VcvConvArgs, check, lib, ptr, stream)
-from .core import (CAPTURING, LAUNCH_COUNTS, _COMPUTE, _DBG_NO_LOCAL_CACHE, _DBG_TABLE_NODES, _USE_PK, _USE_X3, _f32c,
+from .core import (CAPTURING, LAUNCH_COUNTS, _COMPUTE, _USE_PK, _USE_X3, _f32c,
                    _sink, _upload_table)
 
 
@@ -158,8 +158,6 @@ def _stable_entry(w_ptr):
             return e
     if _PARAM_REGIONS_ON[0]:
         regions = _PARAM_REGIONS
-        if cap is not None and _DBG_NO_LOCAL_CACHE:
-            return None
         if cap is not None:
             regions = cap.__dict__.get("regions")
             if regions is None:  # the capture's own view of the regions: nothing packed yet
@@ -240,7 +238,7 @@ def _replay_packs(key, ent):
     nwords = n * ctypes.sizeof(VcvPackJob) // 4 + 8
     cap = CAPTURING[0]
     table = None
-    if cap is not None and not _DBG_TABLE_NODES:
+    if cap is not None:
         # recorded: the job table is finalised on the host by the call below and copied into `table` (cut from the capture's
         # table arena, outside the graph's pool) once after the capture; the packs themselves are re-made at every replay
         host = (ctypes.c_char * (4 * nwords))()
@@ -292,7 +290,7 @@ def _wn_forward_all(vg, n):
     versions = tuple(t._version for t in vg)
     cap = CAPTURING[0]
     hit = _WN_CACHE.get(key) if _WN_CACHE_ON[0] else None
-    if hit is not None and (hit.get("cap") != (cap.id if cap is not None else None) or (cap is not None and _DBG_NO_LOCAL_CACHE)):
+    if hit is not None and (hit.get("cap") != (cap.id if cap is not None else None)):
         hit = None  # (an eager pass's entry inside a capture, or a capture's entry in eager execution: not this sequence's)
     if hit is not None and hit["versions"] == versions and all(r() is t for r, t in zip(hit["refs"], vg)):
         wbuf, norm = hit["wbuf"], hit["norm"]  # (identity: a recycled address is not the same parameter)
