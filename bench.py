@@ -391,6 +391,18 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, before the W warm-up steps: the batch graph is RECORDED here (light/graphed.py records a batch shape the third
+    # time it sees it) -- part of building the workload, like a compile step, so that a small W does not put the one-off
+    # capture inside the timed region; with the default W = 3 it changes nothing (the third warm-up step was the capture)
+    setup_steps = 0
+    if module is not None:
+        while setup_steps < 4:
+            bg = module.__dict__.get("_batch_graph")
+            if bg is not None and (bg.replays > 0 or not bg.applicable()):
+                break
+            run()
+            setup_steps += 1
+        sync()
     for _ in range(warmup):
         run()
     sync()
@@ -522,7 +534,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
         ops.set_f32_split(True, terms=6)
     torch.cuda.empty_cache()
     return {"arith": arith, "dt": dt, "roof": roof, "host_issue_ms": host["issue_ms"], "host": host, "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
-            "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world}
+            "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world, "setup_steps": setup_steps}
 
 
 def f32_arithmetic(ops, L):
@@ -585,6 +597,7 @@ def make_line(r):
                             "host_issue_ms_graph_replay_step": r["host"]["issue_ms_unloaded_graph_step"],
                             "host_issue_ms_eager_step": r["host"]["issue_ms_unloaded_eager_step"],
                             "hip_graph_replays_in_timed_steps": r["host"]["graph_replays"],
+                            "graph_recording_steps_before_warmup": r["setup_steps"],
                             "host_wall_ms_per_step_in_timed_region": round(r["host"]["wall_ms_in_timed_region"], 2),
                             "host_cpu_ms_per_step_in_timed_region": round(r["host"]["cpu_ms"], 2),
                             "library_launcher_calls_per_step": round(r["calls"], 1),
