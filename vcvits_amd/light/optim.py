@@ -38,6 +38,8 @@ def shutdown_flag_groups():
     _FLAG_GROUPS.clear()
 
 
+_LINEAR_CAPTURE = [os.environ.get("VCVITS_DDP_GRAPH_LINEAR", "1") == "1"]
+
 class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay 0.01 by default) over a flat buffer.
     Parameters are re-pointed at views of the buffer; `.grad` of every parameter is a permanent
@@ -168,7 +170,14 @@ class FlatAdamW(torch.optim.Optimizer):
     def _launch_bucket(self, b):
         view = self.grad[b["lo"]:b["hi"]]
         backend = dist.get_backend(self.pg)
-        if backend == "nccl":
+        if backend == "nccl" and ops.CAPTURING[0] is not None and _LINEAR_CAPTURE[0]:
+            # recorded into a HIP graph (light/graphed.py): the blocking form, which this torch launches on the CURRENT stream --
+            # the graph stays one linear chain (0.5 - 2.7 ms of host time per replay).  The async form runs on the process
+            # group's own stream: a fork and a join per bucket, and a graph with forks costs the host 10 - 70 ms per launch on
+            # this ROCm and ran slower than the eager loop.  Recorded, a bucket's all-reduce does not overlap
+            # the backward kernels that follow it; VCVITS_DDP_GRAPH_LINEAR=0 keeps the side stream.
+            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
+        elif backend == "nccl":
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._works.append((work, None))
         else:
