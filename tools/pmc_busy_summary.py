@@ -13,7 +13,7 @@ files = glob.glob(src + "/*counter_collection.csv") + glob.glob(src + "/*/*count
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in csv.DictReader(open(files[0])):
-    m = re.search(r"((?:conv|wgrad|rel_attn|grouped)\w*_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
+    m = re.search(r"((?:conv|wgrad|rel_attn|grouped|resblock)\w*_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
     if not m:
         continue
     n = m.group(1)

@@ -45,6 +45,11 @@ for sp in 6 0; do
   python3 tools/pmc_busy_summary.py gpurun_out/${TAG}_busy$sp profiles/${TAG}_mfma_busy_split$sp.txt "python3 tools/conv_layer_bench.py --reps 3 --only discP --split $sp" > /dev/null
   rm -rf gpurun_out/${TAG}_busy$sp
 done
+# ... of the inference decode (bf16-io convs and the fused ResBlock pairs)
+rm -rf gpurun_out/${TAG}_busyi
+$T 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_busyi -o m -- python3 bench.py --config 48k --workload infer --dtype bf16 --steps 1 --warmup 2 --no-cpu-baseline --no-extra --no-prof --no-host-probe > gpurun_out/${TAG}_busyi.log 2>&1
+python3 tools/pmc_busy_summary.py gpurun_out/${TAG}_busyi profiles/${TAG}_infer_mfma_busy.txt "python3 bench.py --config 48k --workload infer --dtype bf16 --steps 1 --warmup 2 --no-prof" > /dev/null
+rm -rf gpurun_out/${TAG}_busyi
 rm -rf gpurun_out/${TAG}_busya
 $T 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_busya -o m -- python3 tools/attn_bench.py --reps 3 > gpurun_out/${TAG}_busya.log 2>&1
 python3 tools/pmc_busy_summary.py gpurun_out/${TAG}_busya profiles/${TAG}_attn_mfma_busy.txt "python3 tools/attn_bench.py --reps 3" > /dev/null
