@@ -40,9 +40,12 @@ the addresses is still there and means the same.  That is enforced by constructi
     ones without a gradient sink) then forked the graph onto the null stream -- not a capturable stream -- and replays of
     the full model raced (wrong losses from the third replay on, a GPU memory fault once eager batches were interleaved);
   * data parallel: the bucket all-reduces the post-accumulate hooks launch while recording are part of the graph (RCCL
-    collectives are capturable; torch forks its communication stream off the capturing stream and `wait()` joins it), so
-    a replayed backward overlaps its all-reduces exactly as the eager one does.  Recording starts only after the
-    used-parameter set was frozen (FlatAdamW static mode: no host-side flag exchange left in the step);
+    collectives are capturable).  They are issued in the blocking form, which torch launches on the capturing stream
+    itself, so the graph stays a linear chain (light/optim.py: `_launch_bucket`; the async form forks torch's
+    communication stream off the capturing stream and `wait()` joins it -- a graph with forks costs the host 10 - 70 ms
+    per launch on this ROCm; VCVITS_DDP_GRAPH_LINEAR=0 selects it).  Recording starts only after the used-parameter set
+    was frozen (FlatAdamW static mode: no host-side flag exchange left in the step), and across real ranks only on
+    request (VCVITS_DDP_GRAPHS=1: measured on a forced one-rank group only);
   * the key of a graph holds the batch shapes, the arithmetic switches and the parameter-storage epoch
     (ops.GRAPH_EPOCH: a rebuilt optimizer, a replaced layer) -- a graph recorded for other storage is never replayed;
     entries are LRU-bounded (`MAX_ENTRIES`) and an evicted graph releases its pool;
