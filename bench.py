@@ -20,8 +20,8 @@ optimizer passes, AdamW included.  The other BASELINE configurations are reachab
          --master-port P bench.py --gpus N --steps K --warmup W
 
 The default invocation (N = 1, configs[1]) also times short legs of BASELINE configs[2] (full model, B = 32, bf16) and
-configs[4] (48 kHz inference, 64 x 10 s, bf16) after the main timed region and reports them under
-`config.extra_configs` (`--no-extra` skips them).
+configs[4] (48 kHz inference, 64 x 10 s, bf16) and of configs[3]'s per-rank workload (48 kHz full model, bf16, batch 16,
+one rank) after the main timed region and reports them under `config.extra_configs` (`--no-extra` skips them).
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (the dominant kernel family, timed
 with HIP events attached to each dispatch on the launch stream inside the timed region) and `cpu_baseline` (the CPU
@@ -660,6 +660,34 @@ def pin_rank_cpus(local_rank, local_world):
         return None
 
 
+def preflight(dev, world, rank):
+    """Before anything is built or timed on an N-rank run: every rank sees N devices and sits on its own, the RCCL group
+    moves one 1 MB all-reduce with the right sum, and all ranks agree on it.  A node that cannot do this fails HERE with a
+    message naming the rank and the reason, not minutes later inside the first gradient bucket."""
+    have = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if have < local_world:
+        raise SystemExit("bench.py preflight: rank %d sees %d GPU(s), the launch needs %d on this node" % (rank, have, local_world))
+    t = torch.full((262144,), float(rank + 1), device=dev, dtype=torch.float32)  # 1 MB
+    t0 = time.perf_counter()
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    want = world * (world + 1) / 2.0
+    got = float(t[0]), float(t[-1])
+    if got != (want, want):
+        raise SystemExit("bench.py preflight: rank %d: 1 MB all-reduce returned %r, expected %r" % (rank, got, want))
+    # every rank reports which device it holds; rank 0 checks that they are all different
+    ids = torch.zeros(world, device=dev, dtype=torch.int64)
+    ids[rank] = torch.cuda.current_device() + 1
+    dist.all_reduce(ids)
+    torch.cuda.synchronize()
+    if world == local_world and len(set(ids.tolist())) != world:
+        raise SystemExit("bench.py preflight: ranks share devices: %s" % ids.tolist())
+    if rank == 0:
+        sys.stderr.write("bench.py preflight: %d ranks, %d devices visible, 1 MB all-reduce ok (%.1f ms incl. RCCL init)\n"
+                         % (world, have, 1e3 * (time.perf_counter() - t0)))
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
@@ -697,6 +725,7 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
+        preflight(dev, world, rank)
     r = run_leg(a.config, a.workload, a.dtype, a.batch, a.frames, a.steps, a.warmup, dev, world, rank, prof=not a.no_prof,
                 host_probe=not a.no_host_probe)
     line = make_line(r) if rank == 0 else None
@@ -706,6 +735,9 @@ def main(argv=None):
         # BASELINE configs[2] and configs[4], a few steps each, so that the driver's line carries them too
         extra = {}
         legs = {"configs[2]": ("base", "full", "bf16", 32, None),
+                # configs[3]'s per-rank workload (48 kHz full model, bf16, per-GPU batch 16) on this ONE rank: what each of
+                # the eight ranks computes between its gradient all-reduces; the 8-GPU line itself is `--gpus 8`
+                "configs[3], one rank (per-GPU batch 16; no collective)": ("48k", "full", "bf16", 16, None),
                 "configs[4]": ("48k", "infer", "bf16", 64, None),
                 # the headline workload in the two other fp32 arithmetics the library offers
                 "configs[1], nine product terms (exact operands)": ("base", "vocoder", "f32", None, (True, 9)),

@@ -399,6 +399,10 @@ int vcv_resblock_pair_x16(const VcvResPairArgs* args, void* stream);
  * order: no atomics, no sort, no host read-back (torch's embedding_dense_backward sorts with thrust and reads the segment
  * count back -- not capturable into a HIP graph on this stack); accumulate: dW += instead of dW =. */
 int vcv_embedding_t_fwd(const void* idx, const float* W, float* y, int B, int T, int C, int rows, void* stream);
+/* ... with an error word: the number of positions whose index fell outside [0, rows) is ADDED onto *err (device int32, caller-
+ * owned; NULL: not counted).  The reference's nn.Embedding raises on such an index (content_encoder.py:40: emb_pitch;
+ * synthesizer_svc.py:68: emb_g); the host mirror reads the word at its check points and raises there. */
+int vcv_embedding_t_fwd_checked(const void* idx, const float* W, float* y, int B, int T, int C, int rows, int* err, void* stream);
 int vcv_embedding_t_bwd(const void* idx, const float* dy, float* dW, int B, int T, int C, int rows, int accumulate, void* stream);
 
 /* ---- torch.optim.AdamW step over a flat buffer (vcvits.py:247-257) ---- */
@@ -522,6 +526,14 @@ int vcv_kl_bwd(const float* zp, const float* mp, const float* lp, const float* m
  * (commons.py:48-54): y[b,c,s] = x[b,c,ids[b]*mul + s] ---- */
 int vcv_nearest_fwd(const float* x, float* y, int R, int Tin, int Tout, void* stream);
 int vcv_nearest_bwd(const float* dy, float* dx, int R, int Tin, int Tout, void* stream);
+/* ... with the index map of the batch's RAW padded sizes (raw: device int64[2] = {Tin_raw <= Tin or <= 0 for Tin itself,
+ * Tout_raw <= Tout}):
+ * y[r, to] = x[r, floor(to * Tin_raw / Tout_raw)] for to < Tout_raw, 0 beyond.  synthesizer_svc.py:82-83 interpolates padded
+ * content frames onto padded spectrogram frames, so the alignment depends on the batch's own maxima; a batch padded further
+ * to bucket multiples (vcvits_amd/data/collate.py) keeps that alignment by passing them here.  Read from device memory: a
+ * recorded batch replays with each batch's own pair. */
+int vcv_nearest_raw_fwd(const float* x, float* y, int R, int Tin, int Tout, const void* raw, void* stream);
+int vcv_nearest_raw_bwd(const float* dy, float* dx, int R, int Tin, int Tout, const void* raw, void* stream);
 int vcv_slice_fwd(const float* x, const int64_t* ids, int mul, float* y, int B, int C, int T, int S,
                   void* stream);
 int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float* dx, int B, int C, int T, int S,

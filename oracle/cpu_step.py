@@ -17,18 +17,21 @@ def _is_buffer(sd, k):
     return k.endswith(".weight_u") or (k.endswith(".weight_v") and k[:-1] + "orig" in sd)
 
 
-def _leaf_copy(sd):
-    return {k: v.detach().clone().float().requires_grad_(v.is_floating_point() and not _is_buffer(sd, k))
-            for k, v in sd.items()}
+def _leaf_copy(sd, dtype=torch.float32):
+    return {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone())
+            .requires_grad_(v.is_floating_point() and not _is_buffer(sd, k)) for k, v in sd.items()}
 
 
 class CpuTrainer:
-    def __init__(self, module_state_dict, hparams, periods, vocoder_only):
-        """module_state_dict: state_dict of the product VCVITS / VocoderGAN module (CPU tensors)."""
+    def __init__(self, module_state_dict, hparams, periods, vocoder_only, dtype=torch.float32):
+        """module_state_dict: state_dict of the product VCVITS / VocoderGAN module (CPU tensors).  dtype=torch.float64: the
+        same step in double precision -- the yardstick the fp64 ranking tests measure both fp32 implementations against
+        (tests/test_full_width_step_gpu.py)."""
         self.hp = hparams
         self.periods = list(periods)
         self.vocoder_only = vocoder_only
-        self.sd = _leaf_copy(module_state_dict)
+        self.dtype = dtype
+        self.sd = _leaf_copy(module_state_dict, dtype)
         g_keys = [k for k in self.sd if k.startswith("net_g.") and self.sd[k].requires_grad]
         d_keys = [k for k in self.sd if (k.startswith("net_period_d.") or k.startswith("net_scale_d."))
                   and self.sd[k].requires_grad]
@@ -39,7 +42,7 @@ class CpuTrainer:
         self.opt_d = torch.optim.AdamW(self.d_params, t["learning_rate"], betas=tuple(t["betas"]), eps=t["eps"])
         d = hparams["data"]
         self.melmat = torch.from_numpy(O.mel_filterbank(d["target_sampling_rate"], d["filter_length"],
-                                                        d["n_mel_channels"], d["mel_fmin"], d["mel_fmax"]))
+                                                        d["n_mel_channels"], d["mel_fmin"], d["mel_fmax"])).to(dtype)
         # dropout of the content encoder: None = identity; tests set a callable that multiplies by the masks the HIP
         # step drew (same elements dropped on both sides), consumed in the reference's call order
         self.drop = None
@@ -53,7 +56,7 @@ class CpuTrainer:
         m = self.hp["model"]
         prefix = "net_g" if self.vocoder_only else "net_g.dec"
         return O.generator_forward(self.sd, prefix, z, m["upsample_rates"], m["upsample_kernel_sizes"],
-                                   m["resblock_kernel_sizes"], m["resblock_dilation_sizes"])
+                                   m["resblock_kernel_sizes"], m["resblock_dilation_sizes"], resblock=m.get("resblock", "1"))
 
     def _generator_pass(self, batch):
         d, t, m = self.hp["data"], self.hp["train"], self.hp["model"]
@@ -91,7 +94,9 @@ class CpuTrainer:
         """One reference batch: G step on batch_g then D step on batch_d (same data; the random
         draws may differ between the two passes).  Returns the two losses."""
         t = self.hp["train"]
-        batch_d = batch_d or batch_g
+        cast = lambda b: {k: (v.to(self.dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+        batch_g = cast(batch_g)
+        batch_d = cast(batch_d) if batch_d is not None else batch_g
         for p in self.d_params:
             p.requires_grad_(False)
         for p in self.g_params:

@@ -292,10 +292,20 @@ def resblock1_forward(sd, prefix, x, kernel_size, dilations=(1, 3, 5)):
     return x
 
 
+def resblock2_forward(sd, prefix, x, kernel_size, dilations=(1, 3)):
+    """vits/model/modules.py:234-243 (ResBlock2.forward, x_mask=None): one weight-normed dilated conv per residual step."""
+    for i, d in enumerate(dilations):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = F.conv1d(xt, _wn_weight(sd, "%s.convs.%d" % (prefix, i)), _bias(sd, "%s.convs.%d" % (prefix, i)),
+                      dilation=d, padding=get_padding(kernel_size, d))
+        x = xt + x
+    return x
+
+
 def generator_forward(sd, prefix, x, upsample_rates=(8, 8, 4, 2), upsample_kernel_sizes=(16, 16, 4, 4),
-                      resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5),) * 3):
+                      resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5),) * 3, resblock="1"):
     """conv_pre k7 -> 4 x (leaky 0.1 -> weight-normed ConvTranspose1d ->
-    mean of 3 ResBlock1) -> leaky (default slope 0.01) -> conv_post k7 (no bias) -> tanh.  conv_pre / conv_post are
+    mean of 3 ResBlock1 (resblock="2": ResBlock2, hifi-gan config_v3 style)) -> leaky (default slope 0.01) -> conv_post k7 (no bias) -> tanh.  conv_pre / conv_post are
     read in whichever form the state_dict holds them (the original HiFi-GAN lineage weight-norms both and keeps
     conv_post's bias; the VITS lineage does neither)."""
     nk = len(resblock_kernel_sizes)
@@ -306,8 +316,8 @@ def generator_forward(sd, prefix, x, upsample_rates=(8, 8, 4, 2), upsample_kerne
                                stride=u, padding=(k - u) // 2)
         xs = None
         for j in range(nk):
-            r = resblock1_forward(sd, "%s.resblocks.%d" % (prefix, i * nk + j), x, resblock_kernel_sizes[j],
-                                  resblock_dilation_sizes[j])
+            rb = resblock1_forward if str(resblock) == "1" else resblock2_forward
+            r = rb(sd, "%s.resblocks.%d" % (prefix, i * nk + j), x, resblock_kernel_sizes[j], resblock_dilation_sizes[j])
             xs = r if xs is None else xs + r
         x = xs / nk
     x = F.leaky_relu(x)
@@ -389,12 +399,18 @@ def msd_forward(sd, prefix, y, y_hat, training=False):
 # ------------------------------------------------------------------------------------------------
 # losses
 # ------------------------------------------------------------------------------------------------
+def _f(t):
+    """`.float()` of the reference's losses (losses.py upcasts fp16 autocast outputs); a float64 run of the oracle -- the
+    yardstick of the fp64 ranking tests -- stays float64."""
+    return t if t.dtype == torch.float64 else t.float()
+
+
 def feature_loss(fmap_r, fmap_g):
     """vits/light/losses.py:4-12"""
     loss = 0
     for dr, dg in zip(fmap_r, fmap_g):
         for rl, gl in zip(dr, dg):
-            loss = loss + torch.mean(torch.abs(rl.float().detach() - gl.float()))
+            loss = loss + torch.mean(torch.abs(_f(rl).detach() - _f(gl)))
     return loss * 2
 
 
@@ -402,7 +418,7 @@ def discriminator_loss(disc_real_outputs, disc_generated_outputs):
     """vits/light/losses.py:14-27 (without the .item() logging lists)."""
     loss = 0
     for dr, dg in zip(disc_real_outputs, disc_generated_outputs):
-        loss = loss + torch.mean((1 - dr.float()) ** 2) + torch.mean(dg.float() ** 2)
+        loss = loss + torch.mean((1 - _f(dr)) ** 2) + torch.mean(_f(dg) ** 2)
     return loss
 
 
@@ -410,7 +426,7 @@ def generator_loss(disc_outputs):
     """vits/light/losses.py:29-38"""
     loss = 0
     for dg in disc_outputs:
-        loss = loss + torch.mean((1 - dg.float()) ** 2)
+        loss = loss + torch.mean((1 - _f(dg)) ** 2)
     return loss
 
 

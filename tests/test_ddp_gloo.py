@@ -262,3 +262,71 @@ def test_flag_exchange_stops_after_agreement_and_a_later_change_raises_on_every_
     assert c0 == c1 == [1, 2, 2, 3, 3] and f0 and f1, (c0, c1)
     assert e0 is not None and "static-graph" in e0 and "on this rank" not in e0, e0
     assert e1 is not None and "static-graph" in e1 and "on this rank" in e1, e1
+
+
+# ---- a recording pass is not a step: ranks that capture at different times stay in step ----------------------
+def _capture_skew_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcvits_amd import ops
+    from vcvits_amd.light.optim import FlatAdamW
+    FlatAdamW.CHECK_EVERY = 4
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+    opt = FlatAdamW(net.parameters(), 1e-2, bucket_mb=0.0003)
+    opt.broadcast_parameters()
+    g = torch.Generator().manual_seed(11 + rank)
+    record_at = {0: (3, 9), 1: (6,)}[rank]  # rank 0 records twice (an LRU re-capture), rank 1 once, at other steps
+    trace = []
+
+    def one_pass(recording):
+        x = torch.randn(4, 8, generator=g)
+        opt.zero_grad()
+        net(x).pow(2).mean().backward()
+        if recording:
+            # what GraphedBatch._capture does around its recording pass: the pass runs with CAPTURING set (nothing executes),
+            # host-side optimizer bookkeeping is snapshotted and restored, and the first replay counts the step
+            snap = opt.static_state()
+            ops.CAPTURING[0] = object()
+            try:
+                opt.finish_grad_sync()
+            finally:
+                ops.CAPTURING[0] = None
+            opt._static_steps, opt._violation, opt.flag_exchanges = snap
+            opt._synced = True
+            opt.static_check()  # the replay that executes the recorded pass
+        else:
+            opt.finish_grad_sync()
+
+    for step in range(12):
+        one_pass(step in record_at and opt._static_set is not None)
+        trace.append((opt._static_steps, opt.flag_exchanges))
+    out[rank] = trace
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_record_at_different_steps_count_the_same_static_steps():
+    """The periodic frozen-set check is a BLOCKING host collective: every rank must reach it at the same optimizer step.  A
+    pass that is only recorded into a HIP graph used to count as a step of its own (finish_grad_sync) on top of the replay
+    that executes it, so a rank that captured (or re-captured after an LRU eviction) ran one step ahead of its peers."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_capture_skew_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == out[1], (out[0], out[1])
+    steps = [s for s, _ in out[0]]
+    assert steps[-1] == 12 - 2 and steps == sorted(steps)  # frozen after STATIC_AFTER = 2 steps, one count per step since
+
+
+def test_checkpoint_refused_while_a_violation_is_pending():
+    """Between a rank's used-parameter set changing and the next periodic check the ranks may have stepped different
+    parameter sets: FlatAdamW.state_dict refuses to produce a checkpoint in that window."""
+    from vcvits_amd.light.optim import FlatAdamW
+    net = torch.nn.Linear(4, 2)
+    opt = FlatAdamW(net.parameters(), 1e-2)
+    opt.state_dict()
+    opt._violation = True
+    with pytest.raises(RuntimeError, match="used-parameter set changed"):
+        opt.state_dict()

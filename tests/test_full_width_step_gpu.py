@@ -13,7 +13,33 @@ from golden_util import close_kinked
 pytestmark = pytest.mark.gpu
 
 
-def _compare(module, trainer, batch, gpu, tol_loss=2e-4, tol_grad=5e-4):
+def _rank_against_f64(name, grads, ref32, ref64):
+    """Per tensor and per network: relative L2 distance to the float64 step of (a) the HIP step, (b) the torch-CPU fp32 step.
+    Appended to $VCVITS_RANK_STATS when set (profiles/r6_f64_ranking.txt); returns the rows."""
+    import os
+    rows = []
+    nets = {}
+    for k, r64 in ref64.items():
+        r64 = r64.double()
+        den = r64.norm().item() + 1e-300
+        eh = (grads[k].double() - r64).norm().item()
+        ec = (ref32[k].double() - r64).norm().item()
+        rows.append((k, r64.numel(), eh / den, ec / den))
+        n = nets.setdefault(k.split(".")[0], [0.0, 0.0, 0.0])
+        n[0] += eh * eh
+        n[1] += ec * ec
+        n[2] += den * den
+    path = os.environ.get("VCVITS_RANK_STATS")
+    if path:
+        with open(path, "a") as f:
+            for k, n, eh, ec in rows:
+                f.write("%s %s n=%d hip=%.3e cpu32=%.3e ratio=%.2f\n" % (name, k, n, eh, ec, eh / (ec + 1e-300)))
+            for net, (a, b, c) in nets.items():
+                f.write("%s NET %s hip=%.3e cpu32=%.3e ratio=%.2f\n" % (name, net, (a / c) ** 0.5, (b / c) ** 0.5, (a / (b + 1e-300)) ** 0.5))
+    return rows, {net: ((a / c) ** 0.5, (b / c) ** 0.5) for net, (a, b, c) in nets.items()}
+
+
+def _compare(module, trainer, batch, gpu, tol_loss=2e-4, tol_grad=5e-4, trainer64=None, name=""):
     lc = trainer.batch(batch)
     names = {id(p): n for n, p in module.named_parameters()}
     grads = {}
@@ -35,6 +61,12 @@ def _compare(module, trainer, batch, gpu, tol_loss=2e-4, tol_grad=5e-4):
         tops[kk.split(".")[0]] = max(tops.get(kk.split(".")[0], 0.0), float(v.abs().max()))
     for k, b in ref.items():
         close_kinked(k, grads[k], b, tol=tol_grad, floor=2e-6 * tops[k.split(".")[0]])
+    if trainer64 is not None:
+        l64 = trainer64.batch(batch)
+        ref64 = dict(trainer64.grads_g)
+        ref64.update(trainer64.grads_d)
+        rows, nets = _rank_against_f64(name, grads, ref, ref64)
+        return rows, nets, (out, lc, l64)
 
 
 @pytest.mark.parametrize("config", ["base", "48k"])
@@ -47,9 +79,11 @@ def test_vocoder_gan_full_width(gpu, config):
     periods = cfg["model"].get("multi_period_discriminator_periods") or DEFAULT_PERIODS
     module = VocoderGAN(**cfg)
     trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=True)
+    trainer64 = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=True, dtype=torch.float64)
     module = module.to(gpu)
     module.configure_optimizers()
-    _compare(module, trainer, synthetic.vocoder_batch(2, cfg["model"]["inter_channels"], seed=21), gpu)
+    _compare(module, trainer, synthetic.vocoder_batch(2, cfg["model"]["inter_channels"], seed=21), gpu, trainer64=trainer64,
+             name="vocoder/" + config)
 
 
 @pytest.mark.parametrize("config", ["base", "48k"])
@@ -67,6 +101,7 @@ def test_vcvits_full_width(gpu, config):
             if ".post." in n:
                 p.normal_(0.0, 0.02)  # zero-initialised coupling layers would be identities
     trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=False)
+    trainer64 = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, periods, vocoder_only=False, dtype=torch.float64)
     module = module.to(gpu)
     module.configure_optimizers()
     m = cfg["model"]
@@ -78,4 +113,4 @@ def test_vcvits_full_width(gpu, config):
     g = torch.Generator().manual_seed(23)
     batch["noise"] = torch.randn(2, m["inter_channels"], 96, generator=g)
     batch["ids_slice"] = torch.tensor([7, 41])
-    _compare(module, trainer, batch, gpu)
+    _compare(module, trainer, batch, gpu, trainer64=trainer64, name="full/" + config)

@@ -140,6 +140,21 @@ def test_resblock1(gpu, k):
     check_param_grads(g, m)
 
 
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_resblock2(gpu, k):
+    """ResBlock2 (vits/model/modules.py:225-247) against the golden captured from the reference class: forward, input
+    gradient and every parameter gradient at 1e-4."""
+    from vcvits_amd.model.modules import ResBlock2
+    g = load("resblock2_k%d.npz" % k)
+    m = build(ResBlock2(8, k, tuple(int(d) for d in g["dil"])), g["seed"], gpu)
+    x = T(g["x"], gpu, True)
+    y = m(x)
+    close("y", y, g["y"])
+    (y * T(g["r"], gpu)).sum().backward()
+    close("dx", x.grad, g["dx"])
+    check_param_grads(g, m)
+
+
 def _check_sums(g, tag, outs):
     for i, t in enumerate(outs):
         assert tuple(g["%s_shape_%d" % (tag, i)]) == tuple(t.shape)
@@ -277,6 +292,36 @@ def test_generator_two_resblocks_per_stage(gpu):
     close("dx", xg.grad, xc.grad)
     for n, p in gen.named_parameters():
         close("d" + n, p.grad, sdo["g." + n].grad, tol=2e-4)
+
+
+def test_generator_resblock2_vs_oracle(gpu):
+    """Generator(resblock="2") (hifi-gan config_v3 style: three ResBlock2 of two dilated convs per stage): HIP path vs the
+    oracle restatement whose ResBlock2 is pinned by resblock2_k*.npz, forward + every gradient."""
+    from oracle import vits_oracle as O
+    from vcvits_amd.model.generator import Generator
+    from vcvits_amd.model.modules import ResBlock2
+    ks, ds, ur, uk = [3, 5, 7], [[1, 2], [2, 6], [3, 12]], [8, 8, 4], [16, 16, 8]
+    gen = Generator(16, "2", ks, ds, ur, 64, uk)
+    assert all(isinstance(b, ResBlock2) for b in gen.resblocks)
+    sd = fill_state_dict(keys_shapes_of(gen), 13)
+    gen.load_state_dict(sd)
+    gen = gen.to(gpu)
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy(rng.standard_normal((2, 16, 12)).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((2, 1, 12 * 256)).astype(np.float32))
+    sdo = {"g." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xc = x.clone().requires_grad_(True)
+    yc = O.generator_forward(sdo, "g", xc, ur, uk, ks, ds, resblock="2")
+    (yc * r).sum().backward()
+    xg = x.clone().to(gpu).requires_grad_(True)
+    yg = gen(xg)
+    (yg * r.to(gpu)).sum().backward()
+    close("y", yg, yc.detach())
+    close("dx", xg.grad, xc.grad)
+    for n, p in gen.named_parameters():
+        close("d" + n, p.grad, sdo["g." + n].grad, tol=2e-4)
+    with torch.no_grad():  # the no-grad decode (infer / the D step's detached pass) takes the same block
+        close("y_nograd", gen(x.to(gpu)), yc.detach())
 
 
 def test_weight_cache_follows_parameter_changes(gpu):

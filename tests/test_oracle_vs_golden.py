@@ -98,6 +98,16 @@ def test_resblock1(k):
     close(O.resblock1_forward(sd, "r", T(g["x"]), k), g["y"])
 
 
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_resblock2(k):
+    """vits/model/modules.py:225-247, golden from the reference class (tools/make_goldens_resblock2.py)."""
+    from vcvits_amd.model.modules import ResBlock2
+    g = load("resblock2_k%d.npz" % k)
+    dil = tuple(int(d) for d in g["dil"])
+    sd = sd_for(ResBlock2(8, k, dil), g["seed"], "r")
+    close(O.resblock2_forward(sd, "r", T(g["x"]), k, dil), g["y"])
+
+
 def _check_sums(g, tag, outs):
     for i, t in enumerate(outs):
         assert tuple(g["%s_shape_%d" % (tag, i)]) == tuple(t.shape)

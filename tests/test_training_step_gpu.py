@@ -63,6 +63,25 @@ def test_vocoder_gan_batch(gpu):
          tol_grad=2e-2)
 
 
+def test_vocoder_gan_batch_resblock2(gpu):
+    """model.resblock = "2" (vits/model/modules.py:225-247: ResBlock2, two dilated convs per block) through a whole batch:
+    both losses and every parameter gradient of the G and D passes against the oracle trainer."""
+    from oracle.cpu_step import CpuTrainer
+    from vcvits_amd import synthetic
+    from vcvits_amd.light.vcvits import VocoderGAN
+    from vcvits_amd.model.modules import ResBlock2
+    torch.manual_seed(1)
+    cfg = small_cfg()
+    cfg["model"].update({"resblock": "2", "resblock_dilation_sizes": [[1, 3], [2, 6], [3, 12]]})
+    module = VocoderGAN(**cfg)
+    assert all(isinstance(b, ResBlock2) for b in module.net_g.resblocks)
+    assert "net_g.resblocks.11.convs.1.weight_g" in module.state_dict()
+    trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, [2, 3], vocoder_only=True)
+    module = module.to(gpu)
+    module.configure_optimizers()
+    _run(module, trainer, synthetic.vocoder_batch(2, 16, segment_size=4096, seed=6), gpu)
+
+
 def test_vocoder_gan_batch_spectral_norm(gpu):
     """use_spectral_norm=True through a whole batch: the discriminators' power-iteration vectors advance with each of the
     four forwards a batch runs them through (d(y), d(y_hat) in the generator step and again in the discriminator step),

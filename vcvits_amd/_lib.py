@@ -97,13 +97,13 @@ EXPORTS = [
     "vcv_wn_gate_fwd", "vcv_wn_gate_bwd", "vcv_row_sum", "vcv_wn_res_skip_fwd", "vcv_wn_res_skip_bwd",
     "vcv_split_sample_fwd", "vcv_split_sample_bwd", "vcv_coupling", "vcv_layernorm_c_fwd",
     "vcv_layernorm_c_bwd", "vcv_rel_softmax_fwd", "vcv_rel_value_fwd", "vcv_rel_softmax_bwd",
-    "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
+    "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_nearest_raw_fwd", "vcv_nearest_raw_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
     "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_conv_c1_fwd", "vcv_conv_c1_fwd_masked", "vcv_conv_c1_dgrad", "vcv_linear_t1_fwd", "vcv_linear_t1_dgrad", "vcv_linear_t1_wgrad", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
     "vcv_act_grad", "vcv_act_grad_add", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_loss_many_sum", "vcv_loss_many_grad", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_fwd_bf16", "vcv_grouped41_dgrad", "vcv_grouped41_dgrad_bf16", "vcv_grouped41_wgrad", "vcv_grouped41_wgrad_bf16",
     "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16", "vcv_act_grad_bias", "vcv_conv_pk_plan", "vcv_conv_pk_run",
     "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_rel_attn_bwd2", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause", "vcv_conv_x3_pack_job", "vcv_conv_pk_pack_job", "vcv_conv_bf16_pack_job", "vcv_pack_many", "vcv_upload_table",
     "vcv_conv_bf16io_plan", "vcv_conv_bf16io_run", "vcv_cast_f32_x16", "vcv_cast_x16_f32", "vcv_conv_m1_x16_fwd",
-    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force", "vcv_layernorm_c_bwd_scratch", "vcv_layernorm_c_bwd_ws", "vcv_resblock_pair_supported", "vcv_resblock_pair_pack", "vcv_resblock_pair_x16",
+    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_fwd_checked", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force", "vcv_layernorm_c_bwd_scratch", "vcv_layernorm_c_bwd_ws", "vcv_resblock_pair_supported", "vcv_resblock_pair_pack", "vcv_resblock_pair_x16",
 ]
 
 
@@ -157,6 +157,8 @@ _ARGTYPES = {
     "vcv_kl_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vcv_nearest_fwd": [_P, _P, _I, _I, _I, _P],
     "vcv_nearest_bwd": [_P, _P, _I, _I, _I, _P],
+    "vcv_nearest_raw_fwd": [_P, _P, _I, _I, _I, _P, _P],
+    "vcv_nearest_raw_bwd": [_P, _P, _I, _I, _I, _P, _P],
     "vcv_slice_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
     "vcv_slice_bwd": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
     "vcv_conv_m1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
@@ -216,6 +218,7 @@ _ARGTYPES = {
     "vcv_upload_table": [_P, _P, _L, _P],
     "vcv_pack_many_prepared": [ctypes.POINTER(VcvPackJob), _I, _P, _P],
     "vcv_embedding_t_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vcv_embedding_t_fwd_checked": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "vcv_embedding_t_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vcv_set_words": [_P, _I, _I, _I, _I, _I, _P],
     "vcv_adamw_dev": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _I, _P],

@@ -559,6 +559,41 @@ __global__ void nearest_bwd_kernel(const float* __restrict__ dy, float* __restri
   unsafeAtomicAdd(dx + r * Tin + ti, dy[i]);
 }
 
+// The same with the index map of OTHER sizes: raw[0] = Tin_raw <= Tin (<= 0: Tin itself), raw[1] = Tout_raw <= Tout (device
+// int64 pair).  A batch
+// whose padded lengths were rounded up to bucket multiples (data/collate.py: bucket_batch) keeps the alignment the
+// reference's own padding gives it -- F.interpolate(m_p, size=y_spec.shape[2]) maps PADDED content frames onto PADDED
+// spectrogram frames (synthesizer_svc.py:82-83), so the map depends on the batch's raw maxima, not on the bucket sizes:
+//   y[r, to] = x[r, floor(to * Tin_raw / Tout_raw)] for to < Tout_raw, 0 in the bucket padding beyond.
+// The sizes are read from device memory so that a recorded batch (light/graphed.py) replays with each batch's own pair.
+__global__ void nearest_raw_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Tin, int Tout,
+                                       const long long* __restrict__ raw, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int tir = raw[0] > 0 ? (int)raw[0] : Tin, tor = (int)raw[1];  // (raw[0] <= 0: the content side was not re-padded)
+  const int to = (int)(i % Tout);
+  const size_t r = i / Tout;
+  float v = 0.f;
+  if (to < tor && tir > 0 && tir <= Tin) {
+    int ti = (int)floorf((float)to * ((float)tir / (float)tor));
+    if (ti > tir - 1) ti = tir - 1;
+    v = x[r * Tin + ti];
+  }
+  y[i] = v;
+}
+__global__ void nearest_raw_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Tin, int Tout,
+                                       const long long* __restrict__ raw, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int tir = raw[0] > 0 ? (int)raw[0] : Tin, tor = (int)raw[1];  // (raw[0] <= 0: the content side was not re-padded)
+  const int to = (int)(i % Tout);
+  const size_t r = i / Tout;
+  if (to >= tor || tir <= 0 || tir > Tin) return;
+  int ti = (int)floorf((float)to * ((float)tir / (float)tor));
+  if (ti > tir - 1) ti = tir - 1;
+  unsafeAtomicAdd(dx + r * Tin + ti, dy[i]);
+}
+
 // y[b, c, s] = x[b, c, ids[b]*mul + s]  (0 beyond T), s < S
 __global__ void slice_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ ids, int mul,
                                  float* __restrict__ y, int C, int T, int S, size_t n) {
@@ -586,7 +621,8 @@ __global__ void slice_bwd_kernel(const float* __restrict__ dy, const int64_t* __
 // y[b, c, t] = W[idx[b, t], c]: the rows of a 32-frame tile are read along c (coalesced), transposed through LDS and written
 // along t (coalesced).  An index outside [0, rows) gives a zero column.
 __global__ __launch_bounds__(256) void embedding_t_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ W,
-                                                              float* __restrict__ y, int T, int C, int rows) {
+                                                              float* __restrict__ y, int T, int C, int rows,
+                                                              int* __restrict__ err) {
   extern __shared__ float tile[];  // [32][C + 1]
   const int b = blockIdx.y, t0 = blockIdx.x * 32;
   const int nt = min(32, T - t0);
@@ -594,7 +630,11 @@ __global__ __launch_bounds__(256) void embedding_t_fwd_kernel(const long long* _
   for (int e = threadIdx.x; e < nt * C; e += 256) {
     const int tt = e / C, c = e - tt * C;
     const long long r = idx[(size_t)b * T + t0 + tt];
-    tile[tt * ld + c] = (r >= 0 && r < rows) ? W[(size_t)r * C + c] : 0.f;
+    const bool ok = r >= 0 && r < rows;
+    tile[tt * ld + c] = ok ? W[(size_t)r * C + c] : 0.f;
+    // nn.Embedding fails loudly on such an index (content_encoder.py:40 / synthesizer_svc.py:68); a kernel cannot raise, so it
+    // counts the offending positions in the caller's flag word (read back by the host at its next check point)
+    if (!ok && c == 0 && err) atomicAdd(err, 1);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < nt * C; e += 256) {
@@ -953,6 +993,21 @@ extern "C" int vcv_nearest_bwd(const float* dy, float* dx, int R, int Tin, int T
   return vcv_check_launch();
 }
 
+extern "C" int vcv_nearest_raw_fwd(const float* x, float* y, int R, int Tin, int Tout, const void* raw, void* stream) {
+  const size_t n = (size_t)R * Tout;
+  if (!x || !y || !raw || n == 0 || Tin <= 0) return VCV_EINVAL;
+  hipLaunchKernelGGL(nearest_raw_fwd_kernel, g1(n), dim3(256), 0, ST, x, y, Tin, Tout, (const long long*)raw, n);
+  return vcv_check_launch();
+}
+
+extern "C" int vcv_nearest_raw_bwd(const float* dy, float* dx, int R, int Tin, int Tout, const void* raw, void* stream) {
+  const size_t n = (size_t)R * Tout;
+  if (!dy || !dx || !raw || n == 0 || Tin <= 0) return VCV_EINVAL;
+  if (vcv_zero_async(dx, sizeof(float) * (size_t)R * Tin, ST) != hipSuccess) return VCV_EHIP;
+  hipLaunchKernelGGL(nearest_raw_bwd_kernel, g1(n), dim3(256), 0, ST, dy, dx, Tin, Tout, (const long long*)raw, n);
+  return vcv_check_launch();
+}
+
 extern "C" int vcv_slice_fwd(const float* x, const int64_t* ids, int mul, float* y, int B, int C, int T, int S,
                              void* stream) {
   const size_t n = (size_t)B * C * S;
@@ -970,12 +1025,18 @@ extern "C" int vcv_slice_bwd(const float* dy, const int64_t* ids, int mul, float
   return vcv_check_launch();
 }
 
-extern "C" int vcv_embedding_t_fwd(const void* idx, const float* W, float* y, int B, int T, int C, int rows, void* stream) {
+extern "C" int vcv_embedding_t_fwd_checked(const void* idx, const float* W, float* y, int B, int T, int C, int rows, int* err,
+                                           void* stream) {
   if (!idx || !W || !y || B <= 0 || T <= 0 || C <= 0 || rows <= 0) return VCV_EINVAL;
   const size_t lds = sizeof(float) * 32 * (size_t)(C + 1);
   if (lds > 64 * 1024) return VCV_EINVAL;
-  hipLaunchKernelGGL(embedding_t_fwd_kernel, dim3(vcv_cdiv(T, 32), B), dim3(256), lds, ST, (const long long*)idx, W, y, T, C, rows);
+  hipLaunchKernelGGL(embedding_t_fwd_kernel, dim3(vcv_cdiv(T, 32), B), dim3(256), lds, ST, (const long long*)idx, W, y, T, C, rows,
+                     err);
   return vcv_check_launch();
+}
+
+extern "C" int vcv_embedding_t_fwd(const void* idx, const float* W, float* y, int B, int T, int C, int rows, void* stream) {
+  return vcv_embedding_t_fwd_checked(idx, W, y, B, T, C, rows, nullptr, stream);
 }
 
 extern "C" int vcv_embedding_t_bwd(const void* idx, const float* dy, float* dW, int B, int T, int C, int rows, int accumulate,

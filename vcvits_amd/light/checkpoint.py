@@ -97,6 +97,7 @@ def _torch_optim_state(module, opt, idx):
 def save_checkpoint(module, path: str) -> str:
     """Write `path` (e.g. .../checkpoints/last.ckpt) atomically, in the Lightning layout described above."""
     from .. import ops
+    ops.check_indices()  # (a run that looked up embedding rows outside their table trained on zeros: do not save it silently)
     ckpt = {
         "epoch": int(module.current_epoch),
         "global_step": int(module.global_step),

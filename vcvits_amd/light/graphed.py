@@ -48,7 +48,9 @@ the addresses is still there and means the same.  That is enforced by constructi
     request (VCVITS_DDP_GRAPHS=1: measured on a forced one-rank group only);
   * the key of a graph holds the batch shapes, the arithmetic switches and the parameter-storage epoch
     (ops.GRAPH_EPOCH: a rebuilt optimizer, a replaced layer) -- a graph recorded for other storage is never replayed;
-    entries are LRU-bounded (`MAX_ENTRIES`) and an evicted graph releases its pool;
+    entries are LRU-bounded by count (`MAX_ENTRIES`) AND by the memory their pools hold (`GRAPH_MEM_FRACTION` of the
+    device / `VCVITS_GRAPH_BYTES`); an evicted graph releases its pool; a capture that runs out of memory releases every
+    recorded graph of the object and is retried when the shape has repeated again (`MAX_OOM_RETRIES` times);
   * the per-launch profiler and the dropout trace of the tests force the eager pass (their events / lists are not
     capturable); any failure while recording disables the graph for that object (eager from then on).
 """
@@ -67,7 +69,13 @@ ENABLED = [os.environ.get("VCVITS_GRAPHS", "1") == "1"]
 # the eager loop with the graphed no-grad generator pass)
 BATCH_ENABLED = [os.environ.get("VCVITS_BATCH_GRAPHS", os.environ.get("VCVITS_STEP_GRAPHS", "1")) == "1"]
 DDP_GRAPHS = [os.environ.get("VCVITS_DDP_GRAPHS", "0") == "1"]  # record batches whose gradient all-reduces span real ranks
-MAX_ENTRIES = int(os.environ.get("VCVITS_GRAPH_ENTRIES", "4"))  # graphs kept per object (distinct batch shapes), LRU
+MAX_ENTRIES = int(os.environ.get("VCVITS_GRAPH_ENTRIES", "12"))  # graphs kept per object (distinct batch shapes), LRU
+# ... and the memory they may hold together: every recorded batch owns a private pool with the whole activation footprint of
+# its shape (plus a table arena and a weight-gradient arena), next to the eager working set.  Fraction of the device's
+# memory (default 0.4: 115 GB of the MI355X's 288) or VCVITS_GRAPH_BYTES in bytes; least-recently-used graphs go first.
+GRAPH_MEM_FRACTION = float(os.environ.get("VCVITS_GRAPH_MEM_FRACTION", "0.4"))
+GRAPH_BYTES = int(os.environ.get("VCVITS_GRAPH_BYTES", "0"))
+MAX_OOM_RETRIES = 3  # captures that ran out of memory before the object gives up recording (other failures: at once)
 MAX_COUNTED = 256  # distinct shapes whose repeat counts are remembered
 
 # Capture with the thread-local error mode: under the default ("global") any other thread's event query during the capture is
@@ -112,6 +120,8 @@ class _Recorder:
         self.entries, self.counts = OrderedDict(), OrderedDict()
         self.failed = False
         self.replays = self.captures = 0
+        self.ooms = 0        # captures that ran out of memory (each one releases every recorded graph and retries later)
+        self.evictions = 0   # graphs released for the entry count or the byte budget
 
     def _lookup(self, key):
         """The entry of `key` (moved to the young end), or None after counting one more sighting; True when the key has now
@@ -126,12 +136,27 @@ class _Recorder:
             self.counts.popitem(last=False)
         return None, n > self.warmup
 
+    @staticmethod
+    def _budget(dev):
+        if GRAPH_BYTES > 0:
+            return GRAPH_BYTES
+        try:
+            return int(GRAPH_MEM_FRACTION * torch.cuda.get_device_properties(dev).total_memory)
+        except Exception:  # noqa: BLE001
+            return 1 << 62
+
+    def held_bytes(self):
+        return sum(e.get("bytes", 0) for e in self.entries.values())
+
     def _store(self, key, ent):
         self.entries[key] = ent
         self.counts.pop(key, None)
-        while len(self.entries) > max(1, MAX_ENTRIES):
+        budget = self._budget(ent.get("device"))
+        # the newest entry always stays (a single shape larger than the budget still replays; it just never has company)
+        while len(self.entries) > 1 and (len(self.entries) > max(1, MAX_ENTRIES) or self.held_bytes() > budget):
             _k, old = self.entries.popitem(last=False)
             self._release(old)
+            self.evictions += 1
 
     @staticmethod
     def _release(ent):
@@ -154,6 +179,7 @@ class _Recorder:
         torch.cuda.empty_cache()  # (torch's capture entry does the same: done first so the segment snapshot below is final)
         cap = _lib.Capture(dev)
         seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        reserved0 = torch.cuda.memory_reserved(dev)  # (after empty_cache: what the capture reserves on top is its pool)
         graph = torch.cuda.CUDAGraph()
         ops.CAPTURING[0] = cap
         L.vcv_set_seed_offset_ptr(seed.data_ptr())
@@ -171,6 +197,17 @@ class _Recorder:
             cap.flush()  # device tables of the recorded launches: written once, before the first replay
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 -- whatever the capture tripped over: stay eager
+            oom = isinstance(e, torch.cuda.OutOfMemoryError) or "out of memory" in str(e).lower()
+            if oom and self.ooms < MAX_OOM_RETRIES:
+                # transient by nature (the eager working set, other graphs' pools): give back everything this object holds
+                # and let the shape be recorded again once it has repeated `warmup` more times -- do not latch `failed`
+                self.ooms += 1
+                graph = cap = None
+                self.drop()
+                torch.cuda.empty_cache()
+                sys.stderr.write("vcvits_amd: HIP-graph capture of the %s ran out of memory (%d of %d tries); recorded graphs "
+                                 "released, running eagerly for now\n" % (self.what, self.ooms, MAX_OOM_RETRIES))
+                return None
             self.failed = True
             sys.stderr.write("vcvits_amd: HIP-graph capture of the %s failed (%s: %s); running eagerly\n"
                              % (self.what, type(e).__name__, str(e)[:300]))
@@ -183,6 +220,7 @@ class _Recorder:
             if gc_was_on:
                 gc.enable()
         self.captures += 1
+        self.last_pool_bytes = max(0, torch.cuda.memory_reserved(dev) - reserved0)
         if cap.log:
             sys.stderr.write("vcvits_amd[capture %d]: %s recorded; %d external tensors held, %d device tables\n"
                              % (cap.id, self.what, len(cap.external), len(cap.keep)))
@@ -226,7 +264,8 @@ class GraphedNoGrad(_Recorder):
         if rec is None:
             return None
         graph, cap, seed, out = rec
-        ent = {"graph": graph, "inputs": static, "outputs": out, "seed": seed, "cap": cap}
+        ent = {"graph": graph, "inputs": static, "outputs": out, "seed": seed, "cap": cap, "device": dev,
+               "bytes": self.last_pool_bytes}
         self._store(key, ent)
         return ent
 
@@ -277,8 +316,11 @@ class GraphedBatch(_Recorder):
                 return None
         # the per-step scalars of the two recorded AdamW steps
         deltas = []
-        for opt, ranges in ((m.optim_g, ent["ranges_g"]), (m.optim_d, ent["ranges_d"])):
-            ds = {opt._pstep[i] + 1 - st for i, st in ranges}
+        for opt, idx, steps in ((m.optim_g, ent["idx_g"], ent["steps_g"]), (m.optim_d, ent["idx_d"], ent["steps_d"])):
+            ps = opt._pstep
+            # (over ALL touched parameters, not only the first of each recorded run: eager batches in between may have
+            # stepped part of a run, and the run's later parameters would then get the wrong bias correction silently)
+            ds = {ps[i] - s0 for i, s0 in zip(idx, steps)}
             if len(ds) > 1:
                 # eager batches in between stepped a different parameter set: the recorded runs' relative step counts no
                 # longer hold -- forget this graph (it is recorded again when the shape repeats)
@@ -350,18 +392,26 @@ class GraphedBatch(_Recorder):
 
         # the recorded passes advance host-side optimizer state as an executed pass would; the first replay (right after
         # the capture) is that pass's execution
-        snap = [(o, list(o._pstep), o.step_count) for o in (og, od)]
+        # (the data-parallel bookkeeping too: static-step count, pending violation, exchange counter -- a rank that records
+        # must stay in step with a rank that does not, or they reach the periodic blocking check at different steps)
+        snap = [(o, list(o._pstep), o.step_count, o.static_state()) for o in (og, od)]
         rec = self._record(dev, body)
-        for o, ps, sc in snap:
+        for o, ps, sc, st in snap:
             o._pstep, o.step_count = ps, sc
+            o._static_steps, o._violation, o.flag_exchanges = st
         if rec is None:
             return None
         graph, cap, seed, losses = rec
         cap.append(arena["buf"])
         ent = {"graph": graph, "inputs": static, "losses": losses, "seed": seed, "cap": cap, "logged": dict(m.logged),
+               "device": dev, "bytes": self.last_pool_bytes + 4 * int(arena["buf"].numel()),
                "touched_g": state["touched_g"], "touched_d": state["touched_d"],
                "ranges_g": state["ranges_g"], "ranges_d": state["ranges_d"],
                "idx_g": [i for i, t in enumerate(state["touched_g"]) if t],
                "idx_d": [i for i, t in enumerate(state["touched_d"]) if t]}
+        # the step count EVERY touched parameter had when the batch was recorded (the recorded AdamW launches bake `st` per
+        # run of parameters; a replay is valid only if all of them have advanced by the same amount since)
+        ent["steps_g"] = [og._pstep[i] for i in ent["idx_g"]]
+        ent["steps_d"] = [od._pstep[i] for i in ent["idx_d"]]
         self._store(key, ent)
         return ent

@@ -209,7 +209,11 @@ class FlatAdamW(torch.optim.Optimizer):
                 # so the violation is remembered and surfaced on EVERY rank at the next periodic check (static_check).
                 if bytes(self._touched) != self._static_set:
                     self._violation = True
-                self.static_check()
+                # (a pass that is only being RECORDED into a HIP graph is not a step yet: the first replay executes it and
+                # counts it -- counting here too made a rank that captured drift one step ahead of a rank that did not, and
+                # ranks that reach the blocking check at different steps deadlock against each other's collectives)
+                if ops.CAPTURING[0] is None:
+                    self.static_check()
                 return
             n = len(self._touched)
             # one MAX all-reduce of [flags, 1 - flags]: the first half is the OR over ranks, the second half NOT(AND) --
@@ -226,7 +230,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._static_set = bytes(self._touched)
 
     STATIC_AFTER = 2  # steps of cross-rank agreement before the used-parameter set is frozen
-    CHECK_EVERY = 64  # frozen set: every this many steps the ranks exchange one "my set changed" byte (host side)
+    # frozen set: every this many steps the ranks exchange one "my set changed" byte (host side, gloo: ~50 us).  Until the
+    # check a rank whose set changed steps a different parameter set than its peers, so the window is kept short and a
+    # checkpoint taken inside it is refused (state_dict); graph replays re-apply the RECORDED set and cannot see a change.
+    CHECK_EVERY = 8
 
     def static_check(self, steps=1):
         """Count `steps` optimizer steps under the frozen used-parameter set; every CHECK_EVERY of them all ranks exchange one
@@ -315,7 +322,16 @@ class FlatAdamW(torch.optim.Optimizer):
         e = max(epoch - 1, 0) if reference_stack else epoch
         self.set_lr(self.base_lr * (gamma ** e))
 
+    def static_state(self):
+        """(static steps counted, violation pending, flag exchanges): what a graph capture snapshots and restores around
+        its recording pass (light/graphed.py) and what the data-parallel tests compare across ranks."""
+        return self._static_steps, self._violation, self.flag_exchanges
+
     def state_dict(self):
+        if self._violation:
+            raise RuntimeError("FlatAdamW.state_dict: this rank's used-parameter set changed after it was frozen and the ranks "
+                               "have not compared notes yet (next periodic check): its parameters may have stepped differently "
+                               "from its peers', so a checkpoint now could be inconsistent across ranks")
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
                 "exp_avg_sq": self.exp_avg_sq.clone(), "param_steps": list(self._pstep)}
 

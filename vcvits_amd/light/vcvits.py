@@ -152,7 +152,8 @@ class VCVITS(_Base):
             y_spec_lengths = (y_wav_lengths / d.hop_length).long()
         y_hat, ids_slice, z_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \
             self.net_g(x_feat, x_lengths, x_pitch, x_pitch_lengths, y_spec, y_spec_lengths, sid=speakers,
-                       noise=batch.get("noise", None), ids_slice=batch.get("ids_slice", None), decoder_only=decoder_only)
+                       noise=batch.get("noise", None), ids_slice=batch.get("ids_slice", None), decoder_only=decoder_only,
+                       raw_sizes=batch.get("bucket_raw_sizes", None))
         with torch.no_grad():
             y = ops.slice_segments(y_wav, ids_slice, t.segment_size, d.hop_length)
             y_mel_slice = None if decoder_only else commons.slice_segments(y_mel, ids_slice, t.segment_size // d.hop_length)
@@ -252,6 +253,7 @@ class VCVITS(_Base):
                                               d.target_sampling_rate, d.hop_length, d.win_length, d.mel_fmin,
                                               d.mel_fmax)
         self.net_g.train()
+        ops.check_indices()  # (validation already reads results back: the out-of-range-index count rides along)
         writer = getattr(getattr(self, "logger", None), "experiment", None)
         if writer is not None:
             from .. import utils
@@ -340,7 +342,24 @@ class VCVITS(_Base):
         cur.wait_stream(s)
         return out
 
+    def _bucketed(self, batch):
+        """hparams.train.length_bucket_frames = N > 0: the batch's padded lengths rounded up to multiples of N frames
+        (data/collate.py: bucket_batch) so that variable-length batches hit recorded graphs; 0 / absent: as collated."""
+        t = self.hparams.train
+        n = (t.get("length_bucket_frames", 0) if hasattr(t, "get") else getattr(t, "length_bucket_frames", 0)) or 0
+        if n <= 0 or "y_wav_lengths" not in batch or "bucket_raw_sizes" in batch:  # (already bucketed by the collate)
+            return batch
+        from ..data.collate import bucket_batch, bucket_multiples
+        return bucket_batch(batch, bucket_multiples(self.hparams.data.hop_length, int(n)), self.hparams.data.hop_length)
+
     def _fit_batch(self, batch, batch_idx=0, after_backward=None):
+        out = self._fit_batch_inner(batch, batch_idx, after_backward)
+        if ops.CHECK_INDICES_EVERY_BATCH[0]:  # (VCVITS_CHECK_INDICES=1: a device sync per batch; default: at the check points)
+            ops.check_indices()
+        return out
+
+    def _fit_batch_inner(self, batch, batch_idx=0, after_backward=None):
+        batch = self._bucketed(batch)
         if after_backward is None:
             # the whole batch -- both passes and their AdamW steps -- replayed from ONE HIP graph once the batch shapes
             # repeat (light/graphed.py); None: run it eagerly (shapes still new, profiler active, graphs off)
@@ -372,6 +391,7 @@ class VCVITS(_Base):
     def on_epoch_end(self):
         """Lightning steps both epoch-interval schedulers at the end of every training epoch."""
         self._own_epoch += 1
+        ops.check_indices()
         self.scheduler_g.step()
         self.scheduler_d.step()
 

@@ -51,11 +51,11 @@ class SynthesizerSVC(nn.Module):
         return None
 
     def forward(self, x_wav, x_wav_lengths, x_pitch, x_pitch_lengths, y_spec, y_spec_lengths, sid=None,
-                noise=None, ids_slice=None, decoder_only=False):
+                noise=None, ids_slice=None, decoder_only=False, raw_sizes=None):
         """`noise` / `ids_slice` optionally inject the two random draws (parity tests).  decoder_only: compute only what
         `o` depends on -- posterior encoder, slice, decoder -- and return None for the prior-side results: the reference's
         discriminator step runs this whole forward under no_grad and keeps `y_hat.detach()` alone (vcvits.py:119,153), so
-        its content encoder and flow are dead work there."""
+        its content encoder and flow are dead work there.  raw_sizes: see data/collate.py: bucket_batch."""
         g = self._g(sid)
         if decoder_only:
             x_mask = m_p = logs_p = z_p = None
@@ -64,8 +64,9 @@ class SynthesizerSVC(nn.Module):
             x, m_p, logs_p, x_mask = self.enc_p(x_wav, x_wav_lengths, x_pitch, x_pitch_lengths)
             z, m_q, logs_q, y_mask = self.enc_q(y_spec, y_spec_lengths, g=g, noise=noise)
             z_p = self.flow(z, y_mask, g=g)
-            m_p = ops.interpolate_nearest(m_p, y_spec.shape[2])
-            logs_p = ops.interpolate_nearest(logs_p, y_spec.shape[2])
+            # (raw_sizes: a length-bucketed batch keeps the alignment of its own un-bucketed padding, data/collate.py)
+            m_p = ops.interpolate_nearest(m_p, y_spec.shape[2], raw_sizes)
+            logs_p = ops.interpolate_nearest(logs_p, y_spec.shape[2], raw_sizes)
         if ids_slice is None:
             z_slice, ids_slice = commons.rand_slice_segments(z, y_spec_lengths, self.segment_size)
         else:

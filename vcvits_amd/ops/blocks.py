@@ -338,8 +338,69 @@ class _NearestFn(torch.autograd.Function):
         return dx, None
 
 
-def interpolate_nearest(x, size):
+class _NearestRawFn(torch.autograd.Function):
+    """_NearestFn with the index map of the batch's raw padded sizes (device int64 pair), zeros in the bucket padding."""
+
+    @staticmethod
+    def forward(ctx, x, tout, raw):
+        x = _f32c(x)
+        B, C, Tin = x.shape
+        y = torch.empty((B, C, tout), device=x.device, dtype=torch.float32)
+        check(lib().vcv_nearest_raw_fwd(ptr(x), ptr(y), B * C, Tin, tout, ptr(raw), stream()), "vcv_nearest_raw_fwd")
+        ctx.tin = Tin
+        ctx.save_for_backward(raw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (raw,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C, Tout = dy.shape
+        dx = torch.empty((B, C, ctx.tin), device=dy.device, dtype=torch.float32)
+        check(lib().vcv_nearest_raw_bwd(ptr(dy), ptr(dx), B * C, ctx.tin, Tout, ptr(raw), stream()), "vcv_nearest_raw_bwd")
+        return dx, None, None
+
+
+def interpolate_nearest(x, size, raw_sizes=None):
+    """F.interpolate(x, size=(size,), mode="nearest") along T.  raw_sizes (device int64 [2] = the batch's un-bucketed padded
+    (Tin, Tout), data/collate.py: bucket_batch): the index map of THOSE sizes, zeros beyond Tout_raw."""
+    if raw_sizes is not None:
+        if raw_sizes.dtype != torch.int64 or raw_sizes.numel() != 2 or raw_sizes.device != x.device:
+            raise RuntimeError("interpolate_nearest: raw_sizes must be an int64 [2] tensor on x's device")
+        return _NearestRawFn.apply(x, int(size), raw_sizes.contiguous())
     return _NearestFn.apply(x, int(size))
+
+
+# Out-of-range embedding indices: nn.Embedding (the reference's emb_pitch / emb_g) raises on one; the kernel zero-fills the
+# column and COUNTS the position in a per-device int32 word, which check_indices() reads back (a device sync: called at check
+# points -- validation, checkpoint save, epoch end -- or after every batch with VCVITS_CHECK_INDICES=1) and raises on.
+_INDEX_ERR = {}
+CHECK_INDICES_EVERY_BATCH = [__import__("os").environ.get("VCVITS_CHECK_INDICES", "0") == "1"]
+
+
+def _index_err_word(dev):
+    w = _INDEX_ERR.get(dev)
+    if w is None:
+        w = _INDEX_ERR[dev] = torch.zeros(1, device=dev, dtype=torch.int32)  # (lives as long as the process: graphs bake it)
+    return w
+
+
+def index_errors(reset=True):
+    """Number of embedding lookups with an index outside their table since the last reset (synchronises the device)."""
+    n = 0
+    for w in _INDEX_ERR.values():
+        n += int(w.item())
+        if reset:
+            w.zero_()
+    return n
+
+
+def check_indices():
+    n = index_errors()
+    if n:
+        raise IndexError("vcvits_amd: %d embedding lookup(s) used an index outside the table (pitch bin >= the pitch table's "
+                         "rows, speaker id >= n_speakers?) -- nn.Embedding raises on these; the HIP kernel read them as zero "
+                         "rows" % n)
 
 
 class _EmbeddingTFn(torch.autograd.Function):
@@ -353,7 +414,8 @@ class _EmbeddingTFn(torch.autograd.Function):
         B, T = idx.shape
         rows, C = W.shape
         y = torch.empty((B, C, T), device=W.device, dtype=torch.float32)
-        check(lib().vcv_embedding_t_fwd(ptr(idx), ptr(W), ptr(y), B, T, C, rows, stream()), "vcv_embedding_t_fwd")
+        check(lib().vcv_embedding_t_fwd_checked(ptr(idx), ptr(W), ptr(y), B, T, C, rows, ptr(_index_err_word(W.device)), stream()),
+              "vcv_embedding_t_fwd_checked")
         ctx.w_sink = _sink(W)
         ctx.shape = (B, T, C, rows)
         ctx.save_for_backward(idx)
