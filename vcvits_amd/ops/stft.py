@@ -130,11 +130,17 @@ class _MelLogFn(torch.autograd.Function):
     def backward(ctx, dy):
         w, yf = ctx.saved_tensors
         dy = _f32c(dy)
+        # the log-clamp derivative as its own streaming pass over the [n_mel, frames] gradient (a few hundred KB), then a
+        # PLAIN data gradient: the packed-weight kernels take no derivative mask on their input, so the fused form fell to the
+        # register-staged kernel (76 us for 0.27 GFLOP in the step; the split-operand kernel does the same GEMM in ~10)
+        dyf = _to_bt(dy) if ctx.bt else dy
+        dye = torch.empty_like(dyf)
+        check(lib().vcv_act_grad(ptr(dyf), ptr(yf), ptr(dye), _lib.TF_DLOGCLAMP, ctx.clamp, dyf.numel(), stream()), "vcv_act_grad")
         if ctx.bt:
             B, C, T = ctx.xshape
-            dx = _from_bt(conv_dgrad(_to_bt(dy), w, (1, C, T, B), in_tf=_lib.TF_DLOGCLAMP, xaux=yf, slope=ctx.clamp))
+            dx = _from_bt(conv_dgrad(dye, w, (1, C, T, B)))
         else:
-            dx = conv_dgrad(dy, w, ctx.xshape, in_tf=_lib.TF_DLOGCLAMP, xaux=yf, slope=ctx.clamp)
+            dx = conv_dgrad(dye, w, ctx.xshape)
         return dx, None, None
 
 
