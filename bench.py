@@ -108,6 +108,8 @@ def parse(argv=None):
     ap.add_argument("--no-host-probe", action="store_true",
                     help="skip the idle-device host-issue probe after the timed region (counter-collection passes: fewer steps)")
     ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)  # (internal: the CPU-baseline child process)
+    ap.add_argument("--varlen", type=int, default=0, metavar="FRAMES",
+                    help="--workload full: a stream of variable-length batches, padded lengths bucketed to multiples of FRAMES")
     ap.add_argument("--no-extra", action="store_true", help="skip the short configs[2] / configs[4] legs of the default run")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend (gloo only with --dry-run: launcher test on a CPU-only host)")
@@ -355,7 +357,30 @@ def build_infer(cfg, B, T, dev):
     return step
 
 
-def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True, f32_split=None, host_probe=True):
+def varlen_batches(cfg, B, n, seed, dev):
+    """`n` collate-shaped batches of the full-model workload whose utterance lengths vary (spectrogram frames uniform in
+    [256, 384], content frames 0.53 of them -- SURVEY 8d's 384 / 204 at the top), each padded to ITS OWN longest utterance as
+    the reference collate does (vits/data/collate.py:133-190): raw shapes practically never repeat."""
+    from vcvits_amd import synthetic
+    m, hop = cfg["model"], cfg["data"]["hop_length"]
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        ty = torch.randint(256, 385, (B,), generator=g)
+        tx = (ty.float() * 0.53).long().clamp(min=8)
+        b = synthetic.full_batch(B, m["hubert_channels"], t_y=int(ty.max()), t_x=int(tx.max()), seed=seed + 1 + i)
+        for r in range(B):
+            b["y_wav_lengths"][r] = int(ty[r]) * hop
+            b["y_wav_values"][r, :, int(ty[r]) * hop:] = 0.0
+            b["x_hubert_features_lengths"][r] = b["x_pitch_lengths"][r] = int(tx[r])
+            b["x_hubert_features_values"][r, :, int(tx[r]):] = 0.0
+            b["x_pitch_values"][r, int(tx[r]):] = 0
+        out.append({k: v.to(dev) for k, v in b.items()})
+    return out
+
+
+def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, rank, prof=True, f32_split=None, host_probe=True,
+            varlen=0):
     """Build the workload, do `warmup` untimed steps, time exactly `steps` steps between barrier + synchronize on both
     sides, MAX over ranks.  Returns the pieces of the JSON line."""
     from vcvits_amd import _lib, configs, ops, synthetic
@@ -373,6 +398,8 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     if infer:
         run = build_infer(cfg, B, frames, dev)
     else:
+        if varlen:
+            cfg["train"]["length_bucket_frames"] = int(varlen)  # (data/collate.py: padded lengths rounded up to multiples)
         module = (VocoderGAN if workload == "vocoder" else VCVITS)(**cfg).to(dev)
         module.train()
         module.configure_optimizers()
@@ -380,10 +407,13 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
         module.optim_d.broadcast_parameters()
         make = synthetic.vocoder_batch if workload == "vocoder" else synthetic.full_batch
         width = m["inter_channels"] if workload == "vocoder" else m["hubert_channels"]
-        batches = [make(B, width, seed=1234 + 17 * rank + i, device=dev) for i in range(2)]
+        if varlen:
+            batches = varlen_batches(cfg, B, 16, 4321 + 17 * rank, dev)
+        else:
+            batches = [make(B, width, seed=1234 + 17 * rank + i, device=dev) for i in range(2)]
 
         def run(i=[0]):
-            module.fit_batch(batches[i[0] % 2])
+            module.fit_batch(batches[i[0] % len(batches)])
             i[0] += 1
 
     def sync():
@@ -395,7 +425,13 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     # time it sees it) -- part of building the workload, like a compile step, so that a small W does not put the one-off
     # capture inside the timed region; with the default W = 3 it changes nothing (the third warm-up step was the capture)
     setup_steps = 0
-    if module is not None:
+    if module is not None and varlen:
+        # every bucketed shape of the stream is seen (and recorded on its third sighting) before the warm-up: three rounds
+        for _ in range(3 * len(batches)):
+            run()
+            setup_steps += 1
+        sync()
+    elif module is not None:
         while setup_steps < 4:
             bg = module.__dict__.get("_batch_graph")
             if bg is not None and (bg.replays > 0 or not bg.applicable()):
@@ -523,9 +559,18 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
                     "kernel_source_hash": kernel_source_hash(),
                     "other_kernels": [c for c in fams if c is not dom]}
     periods = m.get("multi_period_discriminator_periods") or DEFAULT_PERIODS
+    vstats = None
+    if varlen and bg is not None:
+        vstats = {"bucket_frames": int(varlen), "batches_in_stream": len(batches),
+                  "distinct_raw_shapes": len({tuple(b["y_wav_values"].shape) + tuple(b["x_pitch_values"].shape) for b in batches}),
+                  "recorded_graphs": len(bg.entries), "graph_pool_bytes": bg.held_bytes(), "captures": bg.captures,
+                  "evictions": bg.evictions, "out_of_memory_captures": bg.ooms}
     if module is not None:
         module.optim_g.close()
         module.optim_d.close()
+        module.drop_graphs()  # (the recorded batches own the activation footprint of their shapes: give it back before the next leg)
+        batches = None
+    bg = None
     del run, module
     ops.invalidate_weights()
     ops.set_compute_dtype("f32")
@@ -533,7 +578,7 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
     if f32_split is not None:
         ops.set_f32_split(True, terms=6)
     torch.cuda.empty_cache()
-    return {"arith": arith, "dt": dt, "roof": roof, "host_issue_ms": host["issue_ms"], "host": host, "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
+    return {"varlen": vstats, "arith": arith, "dt": dt, "roof": roof, "host_issue_ms": host["issue_ms"], "host": host, "calls": calls, "B": B, "cfg": cfg, "periods": periods, "config": config, "workload": workload,
             "dtype": dtype, "frames": frames, "steps": steps, "warmup": warmup, "world": world, "setup_steps": setup_steps}
 
 
@@ -604,6 +649,10 @@ def make_line(r):
                             "arithmetic": (r["arith"] if dtype == "f32" else
                                            "bf16 MFMA operands, fp32 accumulate, fp32 master weights / losses / optimizer")},
                  "roofline": r["roof"]})
+    if r.get("varlen"):
+        line["config"]["variable_length_stream"] = r["varlen"]
+        line["config"]["workload"] += ("; 16 batches of VARIABLE utterance lengths (256-384 frames), padded lengths bucketed to "
+                                       "multiples of %d frames (train.length_bucket_frames)" % r["varlen"]["bucket_frames"])
     return line
 
 
@@ -618,6 +667,7 @@ def short(line):
             "host_issue_ms_graph_replay_step": line["config"].get("host_issue_ms_graph_replay_step"),
             "hip_graph_replays_in_timed_steps": line["config"].get("hip_graph_replays_in_timed_steps"),
             "library_launcher_calls_per_step": line["config"]["library_launcher_calls_per_step"],
+            **({"variable_length_stream": line["config"]["variable_length_stream"]} if "variable_length_stream" in line["config"] else {}),
             "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "frac", "traffic", "traffic_source",
                                                   "avg_launch_us", "launches_per_step", "share_of_step_time",
                                                   "algorithmic_bytes_per_launch")} if roof else None}
@@ -727,7 +777,7 @@ def main(argv=None):
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
         preflight(dev, world, rank)
     r = run_leg(a.config, a.workload, a.dtype, a.batch, a.frames, a.steps, a.warmup, dev, world, rank, prof=not a.no_prof,
-                host_probe=not a.no_host_probe)
+                host_probe=not a.no_host_probe, varlen=a.varlen if a.workload == "full" else 0)
     line = make_line(r) if rank == 0 else None
     default_run = (world == 1 and a.config == "base" and a.workload == "vocoder" and a.dtype == "f32"
                    and a.batch is None and not a.no_extra)
@@ -739,11 +789,18 @@ def main(argv=None):
                 # the eight ranks computes between its gradient all-reduces; the 8-GPU line itself is `--gpus 8`
                 "configs[3], one rank (per-GPU batch 16; no collective)": ("48k", "full", "bf16", 16, None),
                 "configs[4]": ("48k", "infer", "bf16", 64, None),
+                # configs[2] on batches as a real filelist gives them: variable utterance lengths, each batch padded to its own
+                # longest by the reference collate; bucketed to 64-frame multiples so that shapes repeat and batches replay
+                "configs[2], variable-length batches (256-384 frames, bucketed to 64)": ("base", "full", "bf16", 32, None),
                 # the headline workload in the two other fp32 arithmetics the library offers
                 "configs[1], nine product terms (exact operands)": ("base", "vocoder", "f32", None, (True, 9)),
                 "configs[1], fp32-input MFMA kernels (fmaf chain, no operand splitting)": ("base", "vocoder", "f32", None, (False, None))}
         for key, (c, w, dt_, b, split) in legs.items():
             try:
+                if key.startswith("configs[2], variable"):
+                    ln = make_line(run_leg(c, w, dt_, b, 938, 16, 3, dev, 1, 0, prof=not a.no_prof, varlen=64))
+                    extra[key] = short(ln)
+                    continue
                 # (10 timed steps after 3 warm-ups, like the headline leg: with 4 + 2 the first-time packs / plans /
                 # allocator growth of a fresh model were still inside the timed region on some boxes)
                 ln = make_line(run_leg(c, w, dt_, b, 938, 10, 3, dev, 1, 0, prof=not a.no_prof, f32_split=split))

@@ -19,7 +19,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from golden_util import close_kinked, fill_state_dict, keys_shapes_of, record_stats
+from golden_util import close_kinked, fill_state_dict, keys_shapes_of, rank_against_f64, record_stats
 
 pytestmark = pytest.mark.gpu
 
@@ -248,6 +248,7 @@ def test_config1_vocoder_step_B16_vs_oracle_f32(gpu):
     cfg = configs.base()
     module = VocoderGAN(**cfg)
     trainer = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, DEFAULT_PERIODS, vocoder_only=True)
+    trainer64 = CpuTrainer(copy.deepcopy(module.state_dict()), cfg, DEFAULT_PERIODS, vocoder_only=True, dtype=torch.float64)
     module = module.to(gpu)
     module.configure_optimizers()
     batch = synthetic.vocoder_batch(16, cfg["model"]["inter_channels"], seed=1234)
@@ -271,6 +272,12 @@ def test_config1_vocoder_step_B16_vs_oracle_f32(gpu):
         tops[kk.split(".")[0]] = max(tops.get(kk.split(".")[0], 0.0), float(v.abs().max()))
     for k, b in ref.items():
         close_kinked("cfg1-B16/" + k, grads[k], b, tol=5e-4, floor=2e-6 * tops[k.split(".")[0]])
+    # the same batch through the oracle in FLOAT64: the HIP step is no further from it than torch-CPU fp32 is
+    # (golden_util.rank_against_f64: symmetric assertions, profiles/r6_f64_ranking.txt)
+    trainer64.batch(batch)
+    ref64 = dict(trainer64.grads_g)
+    ref64.update(trainer64.grads_d)
+    rank_against_f64("cfg1-B16", grads, ref, ref64)
 
 
 def test_config4_inference_B64_rows(gpu):

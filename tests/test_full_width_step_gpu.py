@@ -3,68 +3,15 @@ against the CPU oracle trainer -- both losses and every parameter gradient of bo
 reduced-width version of the same comparison is tests/test_training_step_gpu.py; this one exercises the tile
 variants, split reductions and grouped kernels the real channel counts select (a base-width B = 2 oracle batch costs
 about a second of host time on the GPU box).  Each batch is also run through the oracle in FLOAT64, and both fp32 steps are ranked
-by their distance to it (_rank_against_f64)."""
+by their distance to it (golden_util.rank_against_f64)."""
 import copy
 
 import pytest
 import torch
 
-from golden_util import close_kinked
+from golden_util import close_kinked, rank_against_f64
 
 pytestmark = pytest.mark.gpu
-
-
-def _rank_against_f64(name, grads, ref32, ref64):
-    """Ranking against float64 (verdict r5 #6): is the HIP step any further from the truth than torch-CPU fp32 is?
-
-    Per tensor and per network: relative L2 distance to the float64 oracle step of (a) the HIP step, (b) the torch-CPU fp32
-    oracle step (tensors whose gradient is analytically ~0 get an absolute floor from their network's largest gradient).
-    What the MI355X shows (profiles/r6_f64_ranking.txt, 2,722 tensors of four full-width batches): the two fp32 steps are
-    statistically the SAME distance from float64 -- median hip / cpu32 ratio 0.44 .. 2.2 per batch, each side has whole
-    sub-networks at ~2e-4 where the other sits at 3e-7 (ONE leaky-ReLU kink flipped on that side: a pre-activation within
-    fp32 rounding of zero), worst tensor 4.4e-3 (HIP) / 3.5e-3 (CPU fp32), worst network 1.1e-4 / 1.1e-4.  A per-tensor
-    "HIP <= 2 x CPU" cannot hold for ANY pair of fp32 implementations (CPU fp32 fails it against HIP on 43 .. 374 tensors per
-    batch, HIP against CPU on 35 .. 256), so the assertions are the symmetric ones:
-      * every tensor within 1e-2 of float64 (relative L2; observed worst 4.4e-3 HIP / 3.5e-3 CPU fp32) -- a wrong tile or a
-        dropped term is 1e-1 and up;
-      * every network's whole gradient within 5e-4;
-      * HIP's count of tensors further than 1e-4 from float64 at most twice CPU fp32's count plus 5 % of the tensors;
-      * median hip / cpu32 ratio <= 3.
-    Rows are appended to $VCVITS_RANK_STATS when set."""
-    import os
-    import statistics
-    tops = {}
-    for k, v in ref64.items():
-        tops[k.split(".")[0]] = max(tops.get(k.split(".")[0], 0.0), float(v.abs().max()))
-    rows, nets = [], {}
-    for k, r64 in ref64.items():
-        r64 = r64.double()
-        den = r64.norm().item() + 2e-6 * tops[k.split(".")[0]] * r64.numel() ** 0.5
-        eh = (grads[k].double() - r64).norm().item()
-        ec = (ref32[k].double() - r64).norm().item()
-        rows.append((k, r64.numel(), eh / den, ec / den))
-        n = nets.setdefault(k.split(".")[0], [0.0, 0.0, 0.0])
-        n[0] += eh * eh
-        n[1] += ec * ec
-        n[2] += r64.norm().item() ** 2
-    nets = {net: ((a / c) ** 0.5, (b / c) ** 0.5) for net, (a, b, c) in nets.items()}
-    path = os.environ.get("VCVITS_RANK_STATS")
-    if path:
-        with open(path, "a") as f:
-            for k, n, eh, ec in rows:
-                f.write("%s %s n=%d hip=%.3e cpu32=%.3e ratio=%.2f\n" % (name, k, n, eh, ec, eh / (ec + 1e-300)))
-            for net, (a, b) in nets.items():
-                f.write("%s NET %s hip=%.3e cpu32=%.3e ratio=%.2f\n" % (name, net, a, b, a / (b + 1e-300)))
-    for k, n, eh, ec in rows:
-        assert eh <= 1e-2, "%s %s: HIP gradient %.3e from float64 (CPU fp32: %.3e)" % (name, k, eh, ec)
-    for net, (a, b) in nets.items():
-        assert a <= 5e-4, "%s %s: whole gradient %.3e from float64 (CPU fp32: %.3e)" % (name, net, a, b)
-    far_h = sum(1 for _, _, eh, _ in rows if eh > 1e-4)
-    far_c = sum(1 for _, _, _, ec in rows if ec > 1e-4)
-    assert far_h <= 2 * far_c + 0.05 * len(rows), (name, far_h, far_c, len(rows))
-    med = statistics.median(eh / (ec + 1e-30) for _, _, eh, ec in rows)
-    assert med <= 3.0, (name, med)
-    return rows, nets
 
 
 def _compare(module, trainer, batch, gpu, tol_loss=2e-4, tol_grad=5e-4, trainer64=None, name=""):
@@ -93,7 +40,7 @@ def _compare(module, trainer, batch, gpu, tol_loss=2e-4, tol_grad=5e-4, trainer6
         l64 = trainer64.batch(batch)
         ref64 = dict(trainer64.grads_g)
         ref64.update(trainer64.grads_d)
-        rows, nets = _rank_against_f64(name, grads, ref, ref64)
+        rows, nets = rank_against_f64(name, grads, ref, ref64)
         for a, b32, b64, n in zip((out["g"], out["d"]), lc, l64, ("loss_g", "loss_d")):
             # the losses against float64: HIP no further than 4 x torch-CPU fp32 (+ 2e-6 relative: one fp32 rounding of the sum)
             eh, ec = abs(float(a) - float(b64)), abs(float(b32) - float(b64))

@@ -335,9 +335,14 @@ def test_graphed_batch_records_the_bucket_all_reduces(gpu):
         torch.manual_seed(5)
         sd = copy.deepcopy(VocoderGAN(**cfg).state_dict())
         batch = {k: v.to(gpu) for k, v in synthetic.vocoder_batch(2, 16, segment_size=4096, seed=3).items()}
+        from vcvits_amd.light import optim as optim_mod
         res = {}
-        for mode in (False, True):
-            graphed.set_step_enabled(mode)
+        # eager, then the recorded batch in its two collective-carrying forms: "segments" (default: three graphs, the
+        # all-reduces issued eagerly between their replays) and "linear" (one graph, the all-reduces recorded)
+        for mode in (False, "segments", "linear"):
+            graphed.set_step_enabled(bool(mode))
+            if mode:
+                optim_mod.DDP_GRAPH_MODE[0] = mode
             mod = VocoderGAN(**cfg)
             mod.load_state_dict(sd)
             mod = mod.to(gpu)
@@ -352,12 +357,20 @@ def test_graphed_batch_records_the_bucket_all_reduces(gpu):
                 sg = mod.__dict__["_batch_graph"]
                 # (recording waits for the frozen used-parameter set: two steps of agreement, then three sightings)
                 assert not sg.failed and sg.replays >= 4, (sg.failed, sg.replays)
+                ent = next(iter(sg.entries.values()))
+                assert bool(ent["segments"]) == (mode == "segments")
+                assert (len(ent["graph"]) == 3) if mode == "segments" else not isinstance(ent["graph"], (list, tuple))
+                # the eager passes before the recording left the order their hooks issued the buckets in
+                assert sorted(mod.optim_d._bucket_order) == list(range(len(mod.optim_d._buckets)))
             mod.optim_g.close()
             mod.optim_d.close()
-        for (g0, d0), (g1, d1) in zip(res[False], res[True]):
-            assert abs(g0 - g1) <= 5e-5 * abs(g0) and abs(d0 - d1) <= 5e-5 * abs(d0), (res[False], res[True])
+        for mode in ("segments", "linear"):
+            for (g0, d0), (g1, d1) in zip(res[False], res[mode]):
+                assert abs(g0 - g1) <= 5e-5 * abs(g0) and abs(d0 - d1) <= 5e-5 * abs(d0), (mode, res[False], res[mode])
     finally:
         graphed.set_step_enabled(True)
+        from vcvits_amd.light import optim as optim_mod
+        optim_mod.DDP_GRAPH_MODE[0] = "segments"
         os.environ.pop("VCVITS_FORCE_DDP", None)
         shutdown_flag_groups()
         dist.destroy_process_group()

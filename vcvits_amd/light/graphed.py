@@ -39,13 +39,16 @@ the addresses is still there and means the same.  That is enforced by constructi
     and captured on a side stream: every autograd accumulation (LayerNorm / embedding / relative-position parameters: the
     ones without a gradient sink) then forked the graph onto the null stream -- not a capturable stream -- and replays of
     the full model raced (wrong losses from the third replay on, a GPU memory fault once eager batches were interleaved);
-  * data parallel: the bucket all-reduces the post-accumulate hooks launch while recording are part of the graph (RCCL
-    collectives are capturable).  They are issued in the blocking form, which torch launches on the capturing stream
-    itself, so the graph stays a linear chain (light/optim.py: `_launch_bucket`; the async form forks torch's
-    communication stream off the capturing stream and `wait()` joins it -- a graph with forks costs the host 10 - 70 ms
-    per launch on this ROCm; VCVITS_DDP_GRAPH_LINEAR=0 selects it).  Recording starts only after the used-parameter set
-    was frozen (FlatAdamW static mode: no host-side flag exchange left in the step), and across real ranks only on
-    request (VCVITS_DDP_GRAPHS=1: measured on a forced one-rank group only);
+  * data parallel (round 6): the batch is recorded as THREE graphs sharing one pool -- [G pass] [AdamW(G) + D pass]
+    [AdamW(D)] -- and the bucket all-reduces are issued eagerly between their replays, in the blocking form, on the same
+    stream, in the order the eager loop issues them (light/optim.py: DDP_GRAPH_MODE "segments").  No RCCL kernel is inside
+    a graph, the chain stays linear, a rank that replays and a rank that still runs eagerly issue the same collectives in
+    the same order, and the host's work per batch is three replays + ~20 collective calls instead of ~1,500 launcher
+    calls.  What this form gives up is the overlap of a bucket's all-reduce with the rest of the backward pass (the eager
+    loop's side stream): across eight ranks that is the all-reduce time of ~0.5 GB of gradients over xGMI per batch.  The
+    round-5 forms stay selectable: one graph with the collectives recorded in the blocking form ("linear") or on torch's
+    communication stream ("fork": a graph with forks costs the host 10 - 70 ms per launch on this ROCm).  Recording starts
+    only after the used-parameter set was frozen (FlatAdamW static mode: no host-side flag exchange left in the step);
   * the key of a graph holds the batch shapes, the arithmetic switches and the parameter-storage epoch
     (ops.GRAPH_EPOCH: a rebuilt optimizer, a replaced layer) -- a graph recorded for other storage is never replayed;
     entries are LRU-bounded by count (`MAX_ENTRIES`) AND by the memory their pools hold (`GRAPH_MEM_FRACTION` of the
@@ -68,7 +71,9 @@ ENABLED = [os.environ.get("VCVITS_GRAPHS", "1") == "1"]
 # the whole batch (both optimizer passes and their AdamW steps) as one graph: on by default (VCVITS_BATCH_GRAPHS=0 keeps
 # the eager loop with the graphed no-grad generator pass)
 BATCH_ENABLED = [os.environ.get("VCVITS_BATCH_GRAPHS", os.environ.get("VCVITS_STEP_GRAPHS", "1")) == "1"]
-DDP_GRAPHS = [os.environ.get("VCVITS_DDP_GRAPHS", "0") == "1"]  # record batches whose gradient all-reduces span real ranks
+# record batches whose gradient all-reduces span real ranks: on by default in the segmented form (optim.DDP_GRAPH_MODE: the
+# collectives stay OUTSIDE the graphs); the one-graph forms ("linear" / "fork": RCCL kernels recorded) only on request
+DDP_GRAPHS = [os.environ.get("VCVITS_DDP_GRAPHS", "1") == "1"]
 MAX_ENTRIES = int(os.environ.get("VCVITS_GRAPH_ENTRIES", "12"))  # graphs kept per object (distinct batch shapes), LRU
 # ... and the memory they may hold together: every recorded batch owns a private pool with the whole activation footprint of
 # its shape (plus a table arena and a weight-gradient arena), next to the eager working set.  Fraction of the device's
@@ -172,7 +177,9 @@ class _Recorder:
         self.counts.clear()
 
     def _record(self, dev, body):
-        """Run `body(cap)` under a stream capture; returns (graph, cap, result) or None after a failure."""
+        """Run `body(cap)` under a stream capture; returns (graph, cap, seed, result) or None after a failure.  `body` may be
+        a LIST of callables: each is recorded into a graph of its own, all sharing one private pool (torch: graphs that share
+        a pool must replay in the order they were captured -- GraphedBatch.run does); returns ([graphs], cap, seed, [results])."""
         L = lib()
         torch.cuda.synchronize()
         gc_was_on = _no_gc_during_capture()
@@ -191,8 +198,18 @@ class _Recorder:
         cur = torch.cuda.current_stream(dev)
         cap_stream = cur if cur.cuda_stream != 0 else None
         try:
-            with torch.cuda.graph(graph, stream=cap_stream, capture_error_mode=CAPTURE_ERROR_MODE):
-                out = body(cap)
+            if isinstance(body, (list, tuple)):
+                graphs, outs = [], []
+                for k, seg in enumerate(body):
+                    g = graph if k == 0 else torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=None if k == 0 else graphs[0].pool(), stream=cap_stream,
+                                          capture_error_mode=CAPTURE_ERROR_MODE):
+                        outs.append(seg(cap))
+                    graphs.append(g)
+                graph, out = graphs, outs
+            else:
+                with torch.cuda.graph(graph, stream=cap_stream, capture_error_mode=CAPTURE_ERROR_MODE):
+                    out = body(cap)
             torch.cuda.synchronize()
             cap.flush()  # device tables of the recorded launches: written once, before the first replay
             torch.cuda.synchronize()
@@ -300,6 +317,9 @@ class GraphedBatch(_Recorder):
                 # this ROCm -- about what the eager loop costs -- and a capture that misbehaves on one of eight ranks hangs all
                 if o.world > 1 and not DDP_GRAPHS[0]:
                     return False
+                from .optim import DDP_GRAPH_MODE
+                if o.world > 1 and DDP_GRAPH_MODE[0] != "segments" and os.environ.get("VCVITS_DDP_GRAPHS") != "1":
+                    return False  # (recorded RCCL kernels across real ranks: explicit request only)
         return True
 
     def run(self, batch, extra=()):
@@ -336,7 +356,17 @@ class GraphedBatch(_Recorder):
         for k, v in batch.items():
             ent["inputs"][k].copy_(v)
         ent["seed"].add_(1)
-        ent["graph"].replay()
+        if ent.get("segments"):
+            # [G pass] -> all-reduce G's buckets -> [AdamW(G) + D pass] -> all-reduce D's buckets -> [AdamW(D)]: three replays
+            # and the bucket collectives in between, everything on this one stream in order (blocking form: no fork, no join)
+            g0, g1, g2 = ent["graph"]
+            g0.replay()
+            m.optim_g.allreduce_buckets_now()
+            g1.replay()
+            m.optim_d.allreduce_buckets_now()
+            g2.replay()
+        else:
+            ent["graph"].replay()
         # host-side effects of the two passes
         for opt, touched, idx in ((m.optim_g, ent["touched_g"], ent["idx_g"]), (m.optim_d, ent["touched_d"], ent["idx_d"])):
             ps = opt._pstep
@@ -390,12 +420,68 @@ class GraphedBatch(_Recorder):
                     p.requires_grad_(True)
             return losses
 
+        from .optim import DDP_GRAPH_MODE
+        segments = bool(getattr(og, "_ddp", False) or getattr(od, "_ddp", False)) and DDP_GRAPH_MODE[0] == "segments"
+
+        def seg_bodies():
+            """The same batch as three recordings: the gradient all-reduces (not recorded: FlatAdamW._launch_bucket returns
+            at once while recording in this mode) run eagerly between their replays."""
+            losses = {}
+            old_arena = [None]
+
+            def seg_g(cap):
+                old_arena[0] = ops.arena_swap(arena)
+                m._toggle(0)
+                og.zero_grad()
+                loss = m.training_step(static, 0, 0)
+                loss.backward()
+                losses["g"] = loss.detach()
+
+            def seg_d(cap):
+                og.step()
+                state["touched_g"], state["ranges_g"] = bytes(og._touched), list(og.captured_ranges or [])
+                m._toggle(1)
+                od.zero_grad()
+                loss = m.training_step(static, 0, 1)
+                loss.backward()
+                losses["d"] = loss.detach()
+
+            def seg_end(cap):
+                try:
+                    od.step()
+                    state["touched_d"], state["ranges_d"] = bytes(od._touched), list(od.captured_ranges or [])
+                    ops.wgrad_arena_reset()
+                    if ops._ARENA.get("buf") is not arena["buf"]:
+                        cap.append(ops._ARENA.get("buf"))
+                finally:
+                    restore()
+                return losses
+
+            def restore():
+                if old_arena[0] is not None:
+                    ops.arena_swap(old_arena[0])
+                    old_arena[0] = None
+                for p in og.params:
+                    p.requires_grad_(True)
+                for p in od.params:
+                    p.requires_grad_(True)
+            return [seg_g, seg_d, seg_end], restore
+
         # the recorded passes advance host-side optimizer state as an executed pass would; the first replay (right after
         # the capture) is that pass's execution
         # (the data-parallel bookkeeping too: static-step count, pending violation, exchange counter -- a rank that records
         # must stay in step with a rank that does not, or they reach the periodic blocking check at different steps)
         snap = [(o, list(o._pstep), o.step_count, o.static_state()) for o in (og, od)]
-        rec = self._record(dev, body)
+        if segments:
+            bodies, restore = seg_bodies()
+            try:
+                rec = self._record(dev, bodies)
+            finally:
+                restore()  # (a failure between two segments must not leave the recording arena / the toggles behind)
+            if rec is not None:
+                rec = (rec[0], rec[1], rec[2], rec[3][-1])
+        else:
+            rec = self._record(dev, body)
         for o, ps, sc, st in snap:
             o._pstep, o.step_count = ps, sc
             o._static_steps, o._violation, o.flag_exchanges = st
@@ -404,7 +490,7 @@ class GraphedBatch(_Recorder):
         graph, cap, seed, losses = rec
         cap.append(arena["buf"])
         ent = {"graph": graph, "inputs": static, "losses": losses, "seed": seed, "cap": cap, "logged": dict(m.logged),
-               "device": dev, "bytes": self.last_pool_bytes + 4 * int(arena["buf"].numel()),
+               "device": dev, "bytes": self.last_pool_bytes + 4 * int(arena["buf"].numel()), "segments": segments,
                "touched_g": state["touched_g"], "touched_d": state["touched_d"],
                "ranges_g": state["ranges_g"], "ranges_d": state["ranges_d"],
                "idx_g": [i for i, t in enumerate(state["touched_g"]) if t],

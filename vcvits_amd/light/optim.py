@@ -38,7 +38,15 @@ def shutdown_flag_groups():
     _FLAG_GROUPS.clear()
 
 
-_LINEAR_CAPTURE = [os.environ.get("VCVITS_DDP_GRAPH_LINEAR", "1") == "1"]
+# How a RECORDED batch (light/graphed.py) carries its gradient all-reduces:
+#   "segments" (default)  the batch is three graphs -- [G pass] [AdamW(G) + D pass] [AdamW(D)] -- and the bucket all-reduces are
+#                         issued EAGERLY between the replays, blocking form, on the same stream: nothing of RCCL is inside a
+#                         graph, the chain stays linear, the host issues three replays and ~20 collectives per batch
+#   "linear"              one graph with the all-reduces recorded in the blocking form (round 5)
+#   "fork"                one graph with the async form on torch's communication stream (forks and joins in the graph)
+DDP_GRAPH_MODE = [os.environ.get("VCVITS_DDP_GRAPH_MODE",
+                                 "segments" if os.environ.get("VCVITS_DDP_GRAPH_LINEAR") is None else
+                                 ("linear" if os.environ.get("VCVITS_DDP_GRAPH_LINEAR") == "1" else "fork"))]
 
 class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay 0.01 by default) over a flat buffer.
@@ -88,6 +96,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self._works = []
         self._buckets = []
+        self._bucket_order, self._order_now = None, []
         self._synced = False
         # VCVITS_FORCE_DDP=1 keeps the bucket hooks / collectives active in a 1-rank group (used to exercise
         # the RCCL path on a single-GPU box)
@@ -138,7 +147,7 @@ class FlatAdamW(torch.optim.Optimizer):
             last = i == len(self.params) - 1
             if count >= cap or last:
                 end = self.offsets[i] + p.numel()
-                self._buckets.append({"lo": start, "hi": end, "n": i - cur_first + 1, "ready": 0})
+                self._buckets.append({"lo": start, "hi": end, "n": i - cur_first + 1, "ready": 0, "i": len(self._buckets)})
                 start, count, cur_first = end, 0, i + 1
         self._bucket_of = bucket_of
 
@@ -167,10 +176,27 @@ class FlatAdamW(torch.optim.Optimizer):
             ops.unregister_grad_sink(p)
         ops.unregister_param_region(self.flat)
 
+    def bucket_views(self):
+        """The bucket all-reduces of one backward pass as (view of the flat gradient buffer) in the order the last EAGER pass
+        issued them (hook order, then the leftovers of finish_grad_sync): what a segmented recorded batch issues between
+        its replays, so that a rank that replays and a rank that still runs eagerly line their collectives up."""
+        order = self._bucket_order if self._bucket_order and sorted(self._bucket_order) == list(range(len(self._buckets))) \
+            else list(range(len(self._buckets)))
+        return [self.grad[self._buckets[i]["lo"]:self._buckets[i]["hi"]] for i in order]
+
+    def allreduce_buckets_now(self):
+        """Average every bucket across the group, blocking form on the current stream (segmented replay)."""
+        for view in self.bucket_views():
+            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
+
     def _launch_bucket(self, b):
         view = self.grad[b["lo"]:b["hi"]]
         backend = dist.get_backend(self.pg)
-        if backend == "nccl" and ops.CAPTURING[0] is not None and _LINEAR_CAPTURE[0]:
+        if ops.CAPTURING[0] is not None and DDP_GRAPH_MODE[0] == "segments":
+            return  # (recorded in segments: the all-reduces run eagerly between the replays -- GraphedBatch.run)
+        if ops.CAPTURING[0] is None:
+            self._order_now.append(b["i"])
+        if backend == "nccl" and ops.CAPTURING[0] is not None and DDP_GRAPH_MODE[0] == "linear":
             # recorded into a HIP graph (light/graphed.py): the blocking form, which this torch launches on the CURRENT stream --
             # the graph stays one linear chain (0.5 - 2.7 ms of host time per replay).  The async form runs on the process
             # group's own stream: a fork and a join per bucket, and a graph with forks costs the host 10 - 70 ms per launch on
@@ -199,6 +225,8 @@ class FlatAdamW(torch.optim.Optimizer):
             if view is not None:
                 view.div_(self.world)
         self._works = []
+        if ops.CAPTURING[0] is None:
+            self._bucket_order, self._order_now = self._order_now, []
         # A parameter one rank used and another did not (a batch-dependent conditioning path) still received the
         # averaged gradient everywhere: every rank must apply the same update, so the "received a gradient" flags are
         # OR-ed across the group (torch DDP reduces its used-parameter bitmap for the same reason).
