@@ -267,6 +267,11 @@ int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y,
 int vcv_conv_c1_fwd_masked(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B, int M,
                            int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
                            void* stream);
+/* ... with the taps of every weight row read in reverse order (flip_taps != 0): the data gradient of a one-OUTPUT-channel conv
+ * (the discriminators' conv_post, discriminator.py:39,61) is a one-input-channel convolution of dy with the flipped taps */
+int vcv_conv_c1_fwd_flip(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B, int M, int Tin,
+                         int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope, int flip_taps,
+                         void* stream);
 int vcv_conv_c1_dgrad(const float* dy, const float* w, float* dx, int B, int M, int Tin, int Tout, int P, int K,
                       int stride, int dil, int pad, void* stream);
 /* One-frame pointwise layers (speaker conditioning `cond_layer` / `cond`: Conv1d(gin, M, 1) applied to g [B, gin, 1],
@@ -581,6 +586,13 @@ int vcv_set_seed_offset_ptr(const void* dev_u64); /* non-NULL: the FORWARD dropo
 const void* vcv_get_seed_offset_ptr(void);
 int vcv_set_deterministic(int on);
 int vcv_get_deterministic(void);
+
+/* ---- tuning table (csrc/tuning.h): the library's A/B switches and tuning probes, one int per key, defaults = the measured
+ * choices.  Initialised once from the environment variable VCVITS_TUNING="key=value,key=value" (plus VCVITS_DETERMINISTIC=1);
+ * readable / writable at run time.  Not part of the reference's interface: the reference has no kernels to tune.
+ * Returns VCV_EINVAL for an unknown key. */
+int vcv_tuning_set(const char* key, int value);
+int vcv_tuning_get(const char* key, int* value);
 
 #ifdef __cplusplus
 }

@@ -113,3 +113,52 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
         assert len(sizes) > 10, "no kernel metadata found in %s" % obj
         assert max(sizes) == 0, "%s: a kernel uses %d bytes of scratch per lane" % (name, max(sizes))
+
+
+def test_tuning_table_roundtrip_and_environment():
+    """csrc/tuning.h: one table of kernel switches -- readable / writable through the C ABI, initialised from ONE environment
+    variable (VCVITS_TUNING="key=value,..."); every key the host lists exists in the library, unknown keys are refused."""
+    import ctypes
+    import subprocess
+    import sys
+    from vcvits_amd import _lib, tuning
+    L = _lib.lib()
+    for k in tuning.KERNEL_KEYS:
+        v = ctypes.c_int(-12345)
+        assert L.vcv_tuning_get(k.encode(), ctypes.byref(v)) == 0 and v.value != -12345, k
+    assert L.vcv_tuning_get(b"no_such_key", ctypes.byref(ctypes.c_int())) != 0
+    assert L.vcv_tuning_set(b"no_such_key", 1) != 0
+    old = tuning.kernel_get("thin_wgrad_wgs")
+    tuning.kernel_set("thin_wgrad_wgs", 777)
+    assert tuning.kernel_get("thin_wgrad_wgs") == 777
+    tuning.kernel_set("thin_wgrad_wgs", old)
+    assert tuning.kernel_get("deterministic") == L.vcv_get_deterministic()
+    # a fresh process: the environment variable sets the table, the defaults hold for everything else
+    code = ("from vcvits_amd import tuning; print(tuning.kernel_get('pk_x4'), tuning.kernel_get('wgrad_tile'), "
+            "tuning.kernel_get('x3_terms'), tuning.kernel_get('deterministic'), tuning.kernel_get('pk_vec'))")
+    import os
+    env = dict(os.environ, VCVITS_TUNING="pk_x4=0,wgrad_tile=3,x3_terms=9,bogus=1", VCVITS_DETERMINISTIC="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout.split() == ["0", "3", "9", "1", "1"], r.stdout
+    assert "unknown key 'bogus'" in r.stderr
+
+
+def test_no_stray_environment_reads():
+    """Every VCVITS_* environment variable is declared in vcvits_amd/tuning.py's registry (host side) or is VCVITS_TUNING /
+    VCVITS_DETERMINISTIC (the two the library reads): no module consults os.environ / getenv on its own."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stray = []
+    for d, _, files in os.walk(os.path.join(root, "vcvits_amd")):
+        for f in files:
+            p = os.path.join(d, f)
+            if f.endswith(".py") and f not in ("tuning.py", "build_ext.py"):
+                if re.search(r"os\.environ|getenv", open(p).read()):
+                    stray.append(os.path.relpath(p, root))
+            if f.endswith((".hip", ".h")) and f not in ("version.hip", "tuning.h"):
+                if "getenv" in open(p).read():
+                    stray.append(os.path.relpath(p, root))
+    assert not stray, stray

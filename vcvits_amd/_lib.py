@@ -9,7 +9,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VCVITS_HIP_LIB") or os.path.join(_HERE, "csrc", "libvcvits_hip.so")  # (env: A/B builds)
+from . import tuning  # noqa: E402
+
+LIB_PATH = tuning.text("VCVITS_HIP_LIB", "", "path of another build of libvcvits_hip.so (A/B builds)") or \
+    os.path.join(_HERE, "csrc", "libvcvits_hip.so")
 
 VCV_OK = 0
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 2, 3, 4
@@ -98,12 +101,12 @@ EXPORTS = [
     "vcv_split_sample_fwd", "vcv_split_sample_bwd", "vcv_coupling", "vcv_layernorm_c_fwd",
     "vcv_layernorm_c_bwd", "vcv_rel_softmax_fwd", "vcv_rel_value_fwd", "vcv_rel_softmax_bwd",
     "vcv_kl_fwd", "vcv_kl_bwd", "vcv_nearest_fwd", "vcv_nearest_bwd", "vcv_nearest_raw_fwd", "vcv_nearest_raw_bwd", "vcv_slice_fwd", "vcv_slice_bwd",
-    "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_conv_c1_fwd", "vcv_conv_c1_fwd_masked", "vcv_conv_c1_dgrad", "vcv_linear_t1_fwd", "vcv_linear_t1_dgrad", "vcv_linear_t1_wgrad", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
+    "vcv_dropout", "vcv_prof_begin", "vcv_prof_end", "vcv_prof_dump", "vcv_conv_m1_fwd", "vcv_conv_c1_fwd", "vcv_conv_c1_fwd_masked", "vcv_conv_c1_fwd_flip", "vcv_conv_c1_dgrad", "vcv_linear_t1_fwd", "vcv_linear_t1_dgrad", "vcv_linear_t1_wgrad", "vcv_thin_wgrad", "vcv_weight_flip_transpose",
     "vcv_act_grad", "vcv_act_grad_add", "vcv_weight_norm_many_fwd", "vcv_weight_norm_many_bwd", "vcv_loss_many_sum", "vcv_loss_many_grad", "vcv_conv_dma_workspace", "vcv_conv_dma", "vcv_conv_dma_plan", "vcv_conv_dma_run", "vcv_stft_complex_fwd", "vcv_istft", "vcv_grouped41_fwd", "vcv_grouped41_fwd_bf16", "vcv_grouped41_dgrad", "vcv_grouped41_dgrad_bf16", "vcv_grouped41_wgrad", "vcv_grouped41_wgrad_bf16",
     "vcv_prior_sample", "vcv_prof_bytes", "vcv_conv_bf16_plan", "vcv_conv_bf16_run", "vcv_wgrad_bf16_scratch", "vcv_wgrad_bf16", "vcv_act_grad_bias", "vcv_conv_pk_plan", "vcv_conv_pk_run",
     "vcv_conv_x3_plan", "vcv_conv_x3_run", "vcv_conv_x3_set_terms", "vcv_conv_x3_get_terms", "vcv_conv_x3_set_all", "vcv_wgrad_x3_scratch", "vcv_wgrad_x3", "vcv_rel_attn_supported", "vcv_rel_attn_fwd", "vcv_rel_attn_bwd", "vcv_rel_attn_bwd2", "vcv_set_deterministic", "vcv_get_deterministic", "vcv_prof_roof", "vcv_prof_pause", "vcv_conv_x3_pack_job", "vcv_conv_pk_pack_job", "vcv_conv_bf16_pack_job", "vcv_pack_many", "vcv_upload_table",
     "vcv_conv_bf16io_plan", "vcv_conv_bf16io_run", "vcv_cast_f32_x16", "vcv_cast_x16_f32", "vcv_conv_m1_x16_fwd",
-    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_embedding_t_fwd", "vcv_embedding_t_fwd_checked", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force", "vcv_layernorm_c_bwd_scratch", "vcv_layernorm_c_bwd_ws", "vcv_resblock_pair_supported", "vcv_resblock_pair_pack", "vcv_resblock_pair_x16",
+    "vcv_prof_active", "vcv_set_seed_offset_ptr", "vcv_get_seed_offset_ptr", "vcv_pack_many_prepared", "vcv_adamw_dev", "vcv_set_words", "vcv_tuning_set", "vcv_tuning_get", "vcv_embedding_t_fwd", "vcv_embedding_t_fwd_checked", "vcv_embedding_t_bwd", "vcv_conv_x3_set_variant", "vcv_wgrad_bf16_set_force", "vcv_layernorm_c_bwd_scratch", "vcv_layernorm_c_bwd_ws", "vcv_resblock_pair_supported", "vcv_resblock_pair_pack", "vcv_resblock_pair_x16",
 ]
 
 
@@ -164,6 +167,7 @@ _ARGTYPES = {
     "vcv_conv_m1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vcv_conv_c1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vcv_conv_c1_fwd_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vcv_conv_c1_fwd_flip": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "vcv_linear_t1_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vcv_linear_t1_dgrad": [_P, _P, _P, _I, _I, _I, _P],
     "vcv_linear_t1_wgrad": [_P, _P, _P, _I, _I, _I, _P],
@@ -217,6 +221,8 @@ _ARGTYPES = {
     "vcv_pack_many": [ctypes.POINTER(VcvPackJob), _I, _P, _P],
     "vcv_upload_table": [_P, _P, _L, _P],
     "vcv_pack_many_prepared": [ctypes.POINTER(VcvPackJob), _I, _P, _P],
+    "vcv_tuning_set": [ctypes.c_char_p, _I],
+    "vcv_tuning_get": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "vcv_embedding_t_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vcv_embedding_t_fwd_checked": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "vcv_embedding_t_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -254,8 +260,9 @@ class Capture:
     VCVITS_CHECK_PTRS=1 prints every distinct external tensor with the call site that handed it over (the audit the
     round-4 memory fault called for: an address baked into a captured launch that no longer exists)."""
     _next_id = [1]
+    LOG = tuning.flag("VCVITS_CHECK_PTRS", False, "graph capture: list every external tensor a recorded launch bakes, audit the device tables")
 
-    TABLE_BYTES = int(float(os.environ.get("VCVITS_GRAPH_TABLE_MB", "16")) * (1 << 20))
+    TABLE_BYTES = int(tuning.number("VCVITS_GRAPH_TABLE_MB", 16.0, "device-table arena of a recorded launch sequence, MB") * (1 << 20))
 
     def __init__(self, device=None):
         self.id = Capture._next_id[0]
@@ -264,7 +271,7 @@ class Capture:
         self.table_arena, self.table_off = None, 0
         if device is not None and torch.cuda.is_available():
             self.table_arena = torch.zeros(self.TABLE_BYTES, device=device, dtype=torch.uint8)
-        self.log = os.environ.get("VCVITS_CHECK_PTRS", "0") == "1"
+        self.log = Capture.LOG
         self._starts, self._ends = [], []
         if device is not None and torch.cuda.is_available():
             segs = sorted((s["address"], s["address"] + s["total_size"]) for s in torch.cuda.memory_snapshot()

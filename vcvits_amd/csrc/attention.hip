@@ -1287,7 +1287,7 @@ extern "C" int vcv_rel_attn_fwd(const float* q, const float* k, const float* v, 
 #endif
   // T <= 512: one wave per 32 query rows, scores in registers (rel_attn_fwd_rows_kernel); VCVITS_ATTN_ROWS=0 keeps the
   // workgroup-per-tile kernel
-  static const bool rows_on = [] { const char* e = getenv("VCVITS_ATTN_ROWS"); return !(e && e[0] == '0'); }();
+  const bool rows_on = vcv_tuning().attn_rows != 0;
   // (T <= 256: the 8 x 16 score registers of a query; a 16-tile instance spills ~500 registers and measured slower than the
   // workgroup-per-tile kernel at T = 500, so longer sequences stay there)
   if (rows_on && T <= 256 && (dk == 32 || dk == 64) && 2 * w + 1 <= RELP) {
@@ -1341,7 +1341,7 @@ extern "C" int vcv_rel_attn_bwd2(const float* q, const float* k, const float* v,
 #endif
   a.dS = dS, a.dq = dq, a.dk_ = dk_out, a.dv = dv, a.dembk = dembk, a.dembv = dembv;
   a.B = B, a.H = H, a.dk = dk, a.T = T, a.w = w, a.TP = ((T + 63) & ~63) + 2, a.qscale = qscale, a.pdrop = pdrop, a.seed = seed;
-  static const bool rows_on = [] { const char* e = getenv("VCVITS_ATTN_ROWS"); return !(e && e[0] == '0'); }();
+  const bool rows_on = vcv_tuning().attn_rows != 0;
   if (rows_on && out && T <= 256 && (dk == 32 || dk == 64) && 2 * w + 1 <= RELP) {
     void (*kr)(const AttnArgs);
     void (*kc)(const AttnArgs);

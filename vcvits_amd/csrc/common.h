@@ -1,5 +1,6 @@
 // common.h -- shared device helpers for the gfx950 kernels of libvcvits_hip.so
 #pragma once
+#include "tuning.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -51,15 +52,14 @@ static inline int vcv_check_launch() {
 static inline int vcv_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Zero `bytes` (a multiple of 4) at p on `stream` with a KERNEL.  The launchers used hipMemsetAsync; inside a stream capture
-// that records a memset NODE, and VCVITS_ZERO_MEMSET=1 keeps it (A/B: light/graphed.py's replays).
+// that records a memset NODE, and tuning key zero_memset = 1 keeps it (A/B: light/graphed.py's replays).
 static __global__ void vcv_zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) p[i] = 0u;
 }
 static inline hipError_t vcv_zero_async(void* p, size_t bytes, hipStream_t st) {
-  static const bool use_memset = [] { const char* e = getenv("VCVITS_ZERO_MEMSET"); return e && e[0] == '1'; }();
-  if (use_memset || (bytes & 3) || ((uintptr_t)p & 3)) return hipMemsetAsync(p, 0, bytes, st);
+  if (vcv_tuning().zero_memset || (bytes & 3) || ((uintptr_t)p & 3)) return hipMemsetAsync(p, 0, bytes, st);
   const size_t n = bytes / 4;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) pack_many_kernel(const VcvPackJob* __rest
 static int pack_many_impl(VcvPackJob* jobs, int n, void* table_dev, void* stream, bool upload) {
   if (!jobs || n <= 0 || !table_dev) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_tile = getenv("VCVITS_PACK_NO_TILE") != nullptr;
+  const bool no_tile = !vcv_tuning().pack_tile;
   constexpr size_t TILE_LDS_MAX = 40 * 1024;
   auto tile_lds = [](const VcvPackJob& j) {
     return sizeof(float) * (size_t)(j.mode == 0 ? PK_RT * ((16 * j.K) | 1) : 16 * ((PK_RT * j.K) | 1));
@@ -220,7 +220,7 @@ static int pack_many_impl(VcvPackJob* jobs, int n, void* table_dev, void* stream
   for (int i = 0; i < n; ++i) {
     VcvPackJob& j = jobs[i];
     if (!j.w || !j.wp || j.total <= 0 || j.kind < 0 || j.kind > 2) return VCV_EINVAL;
-    static const bool no_tile2 = getenv("VCVITS_PACK_NO_TILE_BF16") != nullptr;
+    const bool no_tile2 = !vcv_tuning().pack_tile_bf16;
     const bool tile = (j.kind == 0 || (j.kind == 2 && !no_tile2 && j.BKC % 16 == 0 && j.mode <= 2)) && !no_tile &&
                       j.BM % PK_RT == 0 && tile_lds(j) <= TILE_LDS_MAX && j.total % ((int64_t)j.JA * 2 * j.BM) == 0;
     j.reserved = tile ? 1 : 0;

@@ -404,7 +404,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int NS = 
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
   g.vec = 0;
-  static const int xcd_remap = getenv("VCVITS_NO_XCD_REMAP") ? 0 : 1;
+  const int xcd_remap = vcv_tuning().xcd_remap;
   // nothing to share when a column tile has one workgroup (measured: the re-deal alone costs the 64 x 10 s decode 11 %:
   // eight XCDs walking eight far-apart regions of the tensor instead of one)
   g.xcd = xcd_remap && g.nmt * (g.phases > 1 ? g.phases : 1) > 1;
@@ -464,8 +464,8 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // producers beat 256 of the plain 128x128 tile; the phased data gradients (two taps per staged span: staging-bound),
   // the stride-3 layers (three times the span per position: 105 -> 87 TFLOP/s with four producers) and the
   // 128x320 / 128x128 twins measured slower and keep every wave staging
-  static const bool no_ws = getenv("VCVITS_PK_NO_WS") != nullptr;
-  static const bool ws_bf16 = getenv("VCVITS_PK_WS_BF16") != nullptr;  // (experiment switch)
+  const bool no_ws = !vcv_tuning().pk_ws;
+  const bool ws_bf16 = vcv_tuning().pk_ws_bf16 != 0;  // (experiment switch)
   if (ok && !no_ws && a.Mg >= 128 && (EL::ESZ == 4 || ws_bf16) && nph == 1 && a.s == 1) {
     Plan p2;
     if (pl.variant == 0 && make_plan<EL>(a, 128, 256, 8, p2, 4)) pl = p2, pl.variant = 12;
@@ -477,7 +477,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   // +0-3 %, the bf16 conv class 264 -> 287 TFLOP/s in the step; only the 32-row phased data gradients (128 -> 32
   // channels: 39 -> 36) and the bf16 launches with <= 64 input channels (278 -> 252 on the 64-channel k7 layers: two
   // workgroups per CU there, and the 32 staged floats per task cost registers) lose and keep dword loads
-  static const bool no_x4 = getenv("VCVITS_PK_NO_X4") != nullptr;
+  const bool no_x4 = !vcv_tuning().pk_x4;
   if (ok && (IO & 1)) {
     // bf16 activations: always 16-byte loads of eight positions (the only loader of a bf16 `x`)
     Plan p2;
@@ -505,7 +505,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     }
   }
   // 16-byte epilogue through LDS: output rows contiguous in the column index, room for a 32 x 40 float tile per MFMA wave
-  static const bool no_vec = getenv("VCVITS_PK_NO_VEC") != nullptr;
+  const bool no_vec = !vcv_tuning().pk_vec;
   pl.g.vec = (!no_vec && nph == 1 && a.os == 1 && a.oo == 0 && (!a.mask || a.P == 1) &&
               (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
   // bf16 `y`: the 16-byte stores carry eight columns: rows of a multiple of eight elements, 16-byte aligned tensors

@@ -348,7 +348,7 @@ constexpr int C1_MMAX = 64;
 __global__ void __launch_bounds__(256)
 conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                    float* __restrict__ y, int M, int Tin, int Tout, int P, int K, int s, int d, int pad, int out_act,
-                   float slope, int mch, const float* __restrict__ oaux) {
+                   float slope, int mch, const float* __restrict__ oaux, int flip) {
   __shared__ float ws[C1_MMAX * KMAX];
   __shared__ float bs[C1_MMAX];
   // blockIdx.z: chunk of mch <= C1_MMAX output channels (wide one-input-channel layers, e.g. the data gradient of a
@@ -358,7 +358,9 @@ conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   M = M - m0 < mch ? M - m0 : mch;
   w += (size_t)m0 * K;
   if (bias) bias += m0;
-  for (int i = threadIdx.x; i < M * K; i += 256) ws[i] = w[i];
+  // (flip: taps in reverse order -- the data gradient of a one-OUTPUT-channel conv reads its [C, K] weight rows backwards;
+  // done here while staging instead of by a flipped copy made with a launch of its own, 28 of them per training step)
+  for (int i = threadIdx.x; i < M * K; i += 256) ws[i] = flip ? w[i - (i % K) + (K - 1 - i % K)] : w[i];
   for (int i = threadIdx.x; i < M; i += 256) bs[i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int U = Tout * P;
@@ -517,6 +519,9 @@ extern "C" int vcv_linear_t1_wgrad(const float* dy, const float* x, float* dw, i
 extern "C" int vcv_conv_c1_fwd_masked(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B,
                                       int M, int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act,
                                       float slope, void* stream);
+extern "C" int vcv_conv_c1_fwd_flip(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B,
+                                    int M, int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act,
+                                    float slope, int flip_taps, void* stream);
 extern "C" int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int M, int Tin,
                                int Tout, int P, int K, int stride, int dil, int pad, int out_act, float slope,
                                void* stream) {
@@ -526,10 +531,16 @@ extern "C" int vcv_conv_c1_fwd(const float* x, const float* w, const float* bias
 extern "C" int vcv_conv_c1_fwd_masked(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B,
                                       int M, int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act,
                                       float slope, void* stream) {
+  return vcv_conv_c1_fwd_flip(x, w, bias, y, oaux, B, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope, 0, stream);
+}
+
+extern "C" int vcv_conv_c1_fwd_flip(const float* x, const float* w, const float* bias, float* y, const float* oaux, int B,
+                                    int M, int Tin, int Tout, int P, int K, int stride, int dil, int pad, int out_act,
+                                    float slope, int flip_taps, void* stream) {
   if (!x || !w || !y || B <= 0 || M <= 0 || Tin <= 0 || Tout <= 0 || P <= 0 || K <= 0 || K > KMAX || stride <= 0)
     return VCV_EINVAL;
   // channels per workgroup: halve the chunk (64 .. 8) until the grid has ~2,048 workgroups
-  static const int force = getenv("VCVITS_C1_CHUNK") ? atoi(getenv("VCVITS_C1_CHUNK")) : 0;  // (A/B switch)
+  const int force = vcv_tuning().c1_chunk;  // (A/B switch)
   int mch = M < C1_MMAX ? M : C1_MMAX;
   const long long tiles = (long long)vcv_cdiv(Tout * P, 256) * B;
   // (measured, kernel-only: the 1 -> 32 first layers 19.8 -> 16.7 us, the pooled 1 -> 16 ones 15.2 -> 11.2; rows shorter
@@ -538,7 +549,7 @@ extern "C" int vcv_conv_c1_fwd_masked(const float* x, const float* w, const floa
   while (mch > floor_ch && tiles * vcv_cdiv(M, mch) < 2048) mch = (mch + 1) / 2;
   if (force > 0) mch = force < C1_MMAX ? force : C1_MMAX;
   hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(vcv_cdiv(Tout * P, 256), B, vcv_cdiv(M, mch)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                     y, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope, mch, oaux);
+                     y, M, Tin, Tout, P, K, stride, dil, pad, out_act, slope, mch, oaux, flip_taps ? 1 : 0);
   return vcv_check_launch();
 }
 
@@ -565,7 +576,7 @@ extern "C" int vcv_conv_m1_fwd(const float* x, const float* w, const float* bias
     while (splits < 64 && (long long)nt * B * splits < 1024 && C / (splits * 2) >= 8) splits *= 2;
   }
   if (vcv_get_deterministic()) splits = 1;  // (the channel-range splits meet in fp32 atomics)
-  static const bool no_lds = getenv("VCVITS_M1_NO_LDS") != nullptr;
+  const bool no_lds = !vcv_tuning().m1_lds;
   const long long halo = (long long)(K - 1) * dil * P;
   const bool lds = stride == 1 && halo <= 256 && !no_lds && (long long)Tin * P < (1ll << 31);
   if (lds) {
@@ -608,7 +619,7 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
     return VCV_EINVAL;
   if ((a_tf >= VCV_TF_DLEAKY && !aaux) || (b_tf >= VCV_TF_DLEAKY && !baux)) return VCV_EINVAL;
   if ((long long)Ta * P >= (1ll << 31) || (long long)Tb * P >= (1ll << 31)) return VCV_EINVAL;
-  static const bool no_pairs = getenv("VCVITS_C1_WGRAD_NO_PAIRS") != nullptr;
+  const bool no_pairs = !vcv_tuning().c1_wgrad_pairs;
   // (stride 1 only: with a stride the x index is not linear in the flattened position and the two-level loop it
   // needs measured slower than the row-per-workgroup kernel on the period discriminators' 1 -> 32 k5 s3 layers)
   if (C == 1 && s == 1 && M * K <= 256 && a_tf == VCV_TF_NONE && b_tf == VCV_TF_NONE && !vcv_get_deterministic() &&
@@ -636,7 +647,7 @@ extern "C" int vcv_thin_wgrad(const float* a, const float* bsh, const float* aau
   const int bper = vcv_cdiv(B, splits);
   // long rows: also split the positions so that the grid has a few thousand workgroups of >= 1024 positions
   const int U = Ta * P;
-  static const int wg_target = getenv("VCVITS_THIN_WGRAD_WGS") ? atoi(getenv("VCVITS_THIN_WGRAD_WGS")) : 2048;
+  const int wg_target = vcv_tuning().thin_wgrad_wgs > 0 ? vcv_tuning().thin_wgrad_wgs : 2048;
   long long usplit = wg_target / ((long long)M * C * vcv_cdiv(B, bper));
   if (usplit > U / 1024) usplit = U / 1024;
   if (usplit < 1 || det) usplit = 1;

@@ -370,7 +370,7 @@ extern "C" int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream) {
   if (a.b_tf >= VCV_TF_DLEAKY && !a.baux) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int N = a.Cg * a.K;
-  static const bool use_dma = !(getenv("VCVITS_WGRAD_DMA") && getenv("VCVITS_WGRAD_DMA")[0] == '0');
+  const bool use_dma = vcv_tuning().wgrad_dma != 0;
   if (a.dbias && (a.a_tf != VCV_TF_NONE || a.G != 1)) return VCV_EINVAL;
   if (use_dma) {
     const int rcd = vcv_wgrad_dma_try(a, st);
@@ -460,7 +460,7 @@ extern "C" int vcv_bias_grad(const float* dy, const float* aux, float* dbias, in
   if (!dy || !dbias || B <= 0 || C <= 0 || T <= 0) return VCV_EINVAL;
   if (tf >= VCV_TF_DLEAKY && !aux) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static const bool rows_on = [] { const char* e = getenv("VCVITS_BIAS_ROWS"); return !(e && e[0] == '0'); }();
+  const bool rows_on = vcv_tuning().bias_rows != 0;
   if (rows_on && T <= 1024 && T % 4 == 0 && (long long)B * (T / 4) <= 256 * 64) {
     hipLaunchKernelGGL(bias_grad_rows_kernel<true>, dim3(C), dim3(256), 0, st, dy, aux, dbias, B, C, T, tf, slope, accumulate);
     return vcv_check_launch();

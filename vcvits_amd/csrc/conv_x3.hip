@@ -405,7 +405,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
   if (pl.lds_bytes > VCV_LDS_LIMIT) return false;
   g.ks = 1;
   g.vec = 0;
-  static const int xcd_remap = getenv("VCVITS_NO_XCD_REMAP") ? 0 : 1;
+  const int xcd_remap = vcv_tuning().xcd_remap;
   // nothing to share when a column tile has one workgroup (measured: the re-deal alone costs the 64 x 10 s decode 11 %:
   // eight XCDs walking eight far-apart regions of the tensor instead of one)
   g.xcd = xcd_remap && g.nmt * (g.phases > 1 ? g.phases : 1) > 1;
@@ -416,7 +416,7 @@ bool make_plan(const VcvConvArgs& a, int BM, int BN, int NW, Plan& pl, int nring
 
 // variants: 0: 128x256 (8 MFMA waves of 2x2 tiles)   1: 128x128 (8 waves of 2x1)   2: 256x128 (8 waves of 2x2)   3: 64x256 (8 waves of 1x2)
 //           4: 64x128 (8 waves of 1x1)   5: 32x256 (8 waves of 1x1)   6: 64x512 (8 waves of 1x4)
-int g_force_variant = [] { const char* e = getenv("VCVITS_X3_VARIANT"); return e ? atoi(e) : -1; }();  // tuning probe: -1 = choose
+#define g_force_variant (vcv_tuning().x3_variant)  // tuning probe: -1 = choose
 int g_force_js = -1, g_force_ks = -1;
 
 bool choose(const VcvConvArgs& a, Plan& pl) {
@@ -434,7 +434,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
       pl.g.ks = g_force_ks;
       pl.scratch_floats = (size_t)g_force_ks * a.B * a.Mg * U;
     }
-    static const bool no_vec0 = getenv("VCVITS_PK_NO_VEC") != nullptr;
+    const bool no_vec0 = !vcv_tuning().pk_vec;
     pl.g.vec = (!no_vec0 && nph0 == 1 && a.os == 1 && a.oo == 0 && (!a.mask || a.P == 1) &&
                 (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
     return true;
@@ -459,7 +459,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     // 64 x 512 (8 waves of 1 x 4 tiles: 15 fragment reads per 24 MFMAs instead of 9 per 12) where 64 x 256 needs more than one
     // round of 256 workgroups and the wider tile still fills the chip: the generator's 64-channel layers ran two full
     // rounds, each with its own 4 us prologue and 6 us store burst (tools/probes/x3_stamps.py)
-    static const bool no_v6 = getenv("VCVITS_X3_NO_V6") != nullptr;
+    const bool no_v6 = !vcv_tuning().x3_v6;
     if (!no_v6 && nph == 1 && blocks(64, 256) > 256 && blocks(64, 512) >= 192 && eff(64, 512) >= eff(64, 256) - 0.02 &&
         make_plan(a, 64, 512, 8, pl))
       pl.variant = 6, ok = true;
@@ -470,7 +470,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
   }
   if (!ok) return false;
   // two taps per stage where the doubled weight ring fits (128-row tiles, K >= 2): half the barriers per MFMA
-  static const bool no_js2 = getenv("VCVITS_X3_NO_JS2") != nullptr;
+  const bool no_js2 = !vcv_tuning().x3_js2;
   if (!no_js2 && (pl.variant == 0 || pl.variant == 1) && vcv_cdiv(a.K, nph) >= 2) {
     Plan p2;
     if (make_plan(a, pl.BM, pl.BN, pl.NW, p2, NRING_DEF, 2)) { p2.variant = pl.variant; pl = p2; }
@@ -481,7 +481,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
     // the split that costs the fewest (rounds of 256 workgroups) x (channel groups per workgroup): rounding to the nearest
     // count put 288 and 260 workgroups -- a second round for 32 and for 4 of them -- on two of DiscriminatorS's last layers
     long long ks = 1, best = (long long)1 << 60;
-    static const bool old_ks = getenv("VCVITS_X3_OLD_KS") != nullptr;
+    const bool old_ks = vcv_tuning().x3_old_ks != 0;
     for (long long c = 2; c <= pl.g.nch / 2; ++c) {
       // (+ 3: a workgroup's prologue and epilogue cost about three channel groups of a 128-row tile; + c: the finishing pass reads c slabs)
       const long long cost = ((nb * c + 255) / 256) * ((pl.g.nch + c - 1) / c + 3) * 64 + c;
@@ -494,7 +494,7 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
       pl.scratch_floats = (size_t)ks * a.B * a.Mg * U;
     }
   }
-  static const bool no_vec = getenv("VCVITS_PK_NO_VEC") != nullptr;
+  const bool no_vec = !vcv_tuning().pk_vec;
   pl.g.vec = (!no_vec && nph == 1 && a.os == 1 && a.oo == 0 && (!a.mask || a.P == 1) &&
               (size_t)pl.NW * 32 * 40 * 4 <= pl.lds_bytes) ? 1 : 0;
   return true;
@@ -504,8 +504,8 @@ bool choose(const VcvConvArgs& a, Plan& pl) {
 // profiles/r3_x3_vs_f64.txt) the six- and nine-term results have the same error to three digits, 2e-7 .. 1e-6 of the
 // output scale -- the error of the fp32 accumulation order, as large for the fp32-input MFMA kernel -- because each left
 // out term is below 2^-24 of its product while one accumulator rounding is 2^-24 of the whole running sum.
-int g_all = getenv("VCVITS_X3_ALL") != nullptr ? 1 : 0;
-int g_terms = [] { const char* e = getenv("VCVITS_X3_TERMS"); return e && atoi(e) == 9 ? 9 : 6; }();
+#define g_all (vcv_tuning().x3_all)
+#define g_terms (vcv_tuning().x3_terms)
 
 template <int NTERM, int TM, int TN, int WM, int WN, int NRING = NRING_DEF, int JS = 1>
 int launch(const VcvConvArgs& a, const Plan& pl, char* wp, float* part, int flip, bool pack_valid, hipStream_t st) {

@@ -498,7 +498,7 @@ extern "C" int vcv_act_grad_add(const float* dy, const float* add, const float* 
                                 void* stream) {
   if (!dy || !y || !out || n <= 0 || tf < VCV_TF_DLEAKY) return VCV_EINVAL;
   const bool vec = (n & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out | (uintptr_t)add) & 15) == 0;
-  static const bool scalar_only = getenv("VCVITS_ACT_GRAD_SCALAR") != nullptr;  // (A/B switch)
+  const bool scalar_only = !vcv_tuning().act_grad_vec;  // (A/B switch)
   if (vec && !scalar_only) {
     const size_t n4 = (size_t)n / 4;
     if (add)
@@ -526,7 +526,7 @@ extern "C" int vcv_act_grad_bias(const float* dy, const float* y, float* out, fl
   long long nseg = (2048 + C - 1) / C;
   if (nseg > units) nseg = units;
   if (nseg < 1 || vcv_get_deterministic()) nseg = 1;
-  static const bool scalar_only = getenv("VCVITS_ACT_GRAD_SCALAR") != nullptr;  // (A/B switch)
+  const bool scalar_only = !vcv_tuning().act_grad_vec;  // (A/B switch)
   if (!scalar_only && (T & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0)
     hipLaunchKernelGGL(act_grad_bias4_kernel, dim3(C, (unsigned)nseg), dim3(256), 0, ST, (const float4*)dy, (const float4*)y,
                        (float4*)out, dbias, B, C, T / 4, tf, slope, (int)nseg);

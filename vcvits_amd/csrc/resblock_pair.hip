@@ -416,12 +416,12 @@ int launch(const VcvResPairArgs& a, hipStream_t st) {
   p.x = (const unsigned short*)a.x; p.wp = (const bf16x8*)a.wp; p.b1 = a.b1; p.b2 = a.b2; p.y = (unsigned short*)a.y;
   p.B = a.B; p.T = a.T; p.dil = a.dil; p.accumulate = a.accumulate; p.post_scale = a.post_scale; p.slope = a.slope;
   p.ntile = vcv_cdiv(a.T, G::BN);
-  { const char* e = getenv("VCVITS_PAIR_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = vcv_tuning().pair_dbg;
   const long long nblk = (long long)a.B * p.ntile;
   if (nblk >= (1ll << 31)) return VCV_EINVAL;
   // persistent: as many workgroups as the chip holds at this LDS footprint (256 CUs; two per CU where two fit)
   const long long slots = 256 * (2 * lds <= VCV_LDS_LIMIT ? 2 : 1);
-  static const long long forced = [] { const char* e = getenv("VCVITS_PAIR_GRID"); return e ? atoll(e) : 0ll; }();
+  const long long forced = vcv_tuning().pair_grid;
   const long long grid = forced > 0 ? (forced < nblk ? forced : nblk) : (nblk < slots ? nblk : slots);
   if (xs_slots<C, K>(a.dil) / 8 > 64 * (NWAVE / G::NQ)) return VCV_EINVAL;  // (one staging task per lane)
   // per-launch events of bench.py's roofline object: the packed-weight conv class (the launch replaces two of its members)
@@ -439,7 +439,7 @@ bool supported(int C, int K, int dil, int T) {
   // 64 channels with K >= 7: the two convs' weights (114 KB at K = 7) do not fit next to the images; re-loading them per tile
   // made the fused launch no faster than the two it replaces (3.5 vs 3.5 - 3.8 ms on the 48 kHz decode), so they are streamed
   // tap by tap through a ring under the MFMAs (conv_mma)
-  static const bool no_stream = getenv("VCVITS_PAIR_NO_STREAM") != nullptr;  // (A/B: leave 64 channels x K >= 7 to the two launches)
+  const bool no_stream = !vcv_tuning().pair_stream;  // (A/B: leave 64 channels x K >= 7 to the two launches)
   if (C == 64 && K > 3 && no_stream) return false;
   if ((long long)T * 2 >= (1ll << 31)) return false;
   size_t lds = 0;

@@ -761,7 +761,7 @@ extern "C" int vcv_stft_mag_fwd(const float* y, const float* window, const float
   if (F <= 0) return VCV_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long frames = (long long)B * F;
-  static const bool old_form = getenv("VCVITS_STFT_RADIX2") != nullptr;  // (A/B switch: the 256-threads-per-frame radix-2 form)
+  const bool old_form = !vcv_tuning().stft_wave;  // (A/B switch: the 256-threads-per-frame radix-2 form)
   if (!old_form) {
     // one wavefront per frame (stft_mag_fwd_wave_kernel): few frames -> one frame per workgroup; more -> wider output rows
     if (frames <= 1024) return launch_fwd_wave<1, 1>(y, window, twiddle, mag, B, T, F, hop, pad, reflect, eps, st);

@@ -773,7 +773,7 @@ extern "C" int vcv_layernorm_c_fwd(const float* x, const float* y, const float* 
                                    float* out, float* mean, float* rstd, int B, int C, int T, float eps,
                                    void* stream) {
   if (!x || !gamma || !beta || !out || !mean || !rstd || B <= 0 || C <= 0 || T <= 0) return VCV_EINVAL;
-  static const bool regs_on = [] { const char* e = getenv("VCVITS_LN_REGS"); return !(e && e[0] == '0'); }();
+  const bool regs_on = vcv_tuning().ln_regs != 0;
   if (regs_on && C == 256)
     hipLaunchKernelGGL(layernorm_c_fwd_regs_kernel<64>, dim3(vcv_cdiv(T, 64), B), dim3(256), 0, ST, x, y, gamma, beta, out, mean, rstd, T, eps);
   else if (regs_on && C == 128)
@@ -860,7 +860,7 @@ layernorm_c_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict_
 
 // Workspace floats vcv_layernorm_c_bwd_ws wants for (B, C, T): 0 = none (the atomics form).
 extern "C" int64_t vcv_layernorm_c_bwd_scratch(int B, int C, int T) {
-  static const bool regs_on = [] { const char* e = getenv("VCVITS_LN_REGS"); return !(e && e[0] == '0'); }();
+  const bool regs_on = vcv_tuning().ln_regs != 0;
   if (!regs_on || (C != 128 && C != 256) || B <= 0 || T <= 0) return 0;
   return (int64_t)vcv_cdiv(T, 64) * B * 2 * C;
 }

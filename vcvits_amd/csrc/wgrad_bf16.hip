@@ -484,9 +484,9 @@ struct Cfg { int WM, WC, WU, KT; };
 
 bool geometry(const VcvWgradArgs& a, const Cfg& c, WbGeom& g, size_t& lds, int PL = 1) {
   const int BU = PL == 1 ? BU64 : 32;
-  // producer waves for the bf16 launches too (round 3: 163 -> 176 TFLOP/s in the bf16 step); VCVITS_WGRAD_BF16_NO_WS keeps
+  // producer waves for the bf16 launches too (round 3: 163 -> 176 TFLOP/s in the bf16 step); tuning key wgrad_bf16_ws = 0 keeps
   // every wave staging
-  static const bool ws1 = getenv("VCVITS_WGRAD_BF16_NO_WS") == nullptr;
+  const bool ws1 = vcv_tuning().wgrad_bf16_ws != 0;
   const bool ws = PL == 3 || ws1;
   const int NS = ws ? 4 : c.WM * c.WC * c.WU, maxt = ws ? MAXT_WS : MAXT;  // staging waves, tasks each
   const int BM = 32 * c.WM, BC = 32 * c.WC, NW = c.WM * c.WC * c.WU;
@@ -539,7 +539,7 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   }
   g.Z = (int)Z;
   void (*kern)(const VcvWgradArgs, const WbGeom, float*);
-  static const bool ws1 = getenv("VCVITS_WGRAD_BF16_NO_WS") == nullptr;
+  const bool ws1 = vcv_tuning().wgrad_bf16_ws != 0;
   if constexpr (NT == 1) kern = ws1 ? wgrad_bf16_kernel<WM, WC, WU, KT, MAXT_WS, NT, 4, BU64> : wgrad_bf16_kernel<WM, WC, WU, KT, MAXT, NT>;
   else kern = wgrad_bf16_kernel<WM, WC, WU, KT, MAXT_WS, NT, 4, 32>;  // 4 producer waves, 32-position stages
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -551,7 +551,7 @@ int launch(const VcvWgradArgs& a, const WbGeom& g0, size_t lds, float* scratch, 
   hipEvent_t ev0, ev1;
   vcv_prof_events(VCV_PROF_WGRAD_DMA, flops, tag, 12, &ev0, &ev1, abytes, NT * flops / VCV_PEAK_BF16_MFMA);
   VCV_LAUNCH_EV(kern, grid, block, (unsigned)lds, st, ev0, ev1, a, g, scratch);
-  static const bool finish_scalar = getenv("VCVITS_WGRAD_FINISH_SCALAR") != nullptr;  // (A/B switch: the 4-byte kernel)
+  const bool finish_scalar = !vcv_tuning().wgrad_finish_vec;  // (A/B switch: the 4-byte kernel)
   if (!finish_scalar && (a.Cg & 3) == 0 && ((uintptr_t)scratch & 15) == 0) {
     if (g.Z <= 4) launch_finish4<4>(scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha, st);
     else if (g.Z <= 8) launch_finish4<8>(scratch, a.dw, a.Mg, a.Cg, a.K, g.Z, a.alpha, st);

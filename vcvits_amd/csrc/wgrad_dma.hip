@@ -453,7 +453,7 @@ WgPlan plan(const VcvWgradArgs& a) {
   }
   g.Z = (int)Z;
   pl.cost = best;
-  static const bool verbose = getenv("VCVITS_WGRAD_VERBOSE") != nullptr;
+  const bool verbose = vcv_tuning().wgrad_verbose != 0;
   if (verbose)
     fprintf(stderr, "wgrad plan M%d C%d K%d U%lld s%d tile %dx%d: occ %lld tiles %lld total %lld Z %lld cost %.1f us lds %zu\n", a.Mg, a.Cg, a.K,
             U, a.s, BM, BN, occ, tiles, total, Z, best, pl.lds);
@@ -503,7 +503,7 @@ struct PlanEntry { WgPlan pl; int which; };
 
 template <bool STR>
 int launch(const VcvWgradArgs& a, hipStream_t st) {
-  static const int only = getenv("VCVITS_WGRAD_TILE") ? atoi(getenv("VCVITS_WGRAD_TILE")) : -1;  // tuning sweeps
+  const int only = vcv_tuning().wgrad_tile;  // tuning sweeps (the plan cache below is keyed on the shape only: set it before the first launch)
   static thread_local std::unordered_map<PlanKey, PlanEntry, PlanKeyHash> cache;
   const PlanKey key = {{a.B, a.Cg, a.Mg, a.Ta, a.Tb, a.P, a.K, a.s, a.dj, a.off, a.a_tf, a.b_tf, a.dbias != nullptr, a.slab != nullptr},
                        a.slab ? a.slab_floats : 0};

@@ -64,29 +64,29 @@ from collections import OrderedDict
 
 import torch
 
-from .. import _lib, ops
+from .. import _lib, ops, tuning
 from .._lib import lib
 
-ENABLED = [os.environ.get("VCVITS_GRAPHS", "1") == "1"]
+ENABLED = [tuning.flag("VCVITS_GRAPHS", True, "HIP-graph replay of repeated launch sequences at all")]
 # the whole batch (both optimizer passes and their AdamW steps) as one graph: on by default (VCVITS_BATCH_GRAPHS=0 keeps
 # the eager loop with the graphed no-grad generator pass)
-BATCH_ENABLED = [os.environ.get("VCVITS_BATCH_GRAPHS", os.environ.get("VCVITS_STEP_GRAPHS", "1")) == "1"]
+BATCH_ENABLED = [tuning.flag("VCVITS_BATCH_GRAPHS", True, "the whole training batch (both passes + AdamW) as one recorded sequence")]
 # record batches whose gradient all-reduces span real ranks: on by default in the segmented form (optim.DDP_GRAPH_MODE: the
 # collectives stay OUTSIDE the graphs); the one-graph forms ("linear" / "fork": RCCL kernels recorded) only on request
-DDP_GRAPHS = [os.environ.get("VCVITS_DDP_GRAPHS", "1") == "1"]
-MAX_ENTRIES = int(os.environ.get("VCVITS_GRAPH_ENTRIES", "12"))  # graphs kept per object (distinct batch shapes), LRU
+DDP_GRAPHS = [tuning.flag("VCVITS_DDP_GRAPHS", True, "record batches whose gradient all-reduces span real ranks")]
+MAX_ENTRIES = tuning.integer("VCVITS_GRAPH_ENTRIES", 12, "recorded graphs kept per object (distinct batch shapes), LRU")  # graphs kept per object (distinct batch shapes), LRU
 # ... and the memory they may hold together: every recorded batch owns a private pool with the whole activation footprint of
 # its shape (plus a table arena and a weight-gradient arena), next to the eager working set.  Fraction of the device's
 # memory (default 0.4: 115 GB of the MI355X's 288) or VCVITS_GRAPH_BYTES in bytes; least-recently-used graphs go first.
-GRAPH_MEM_FRACTION = float(os.environ.get("VCVITS_GRAPH_MEM_FRACTION", "0.4"))
-GRAPH_BYTES = int(os.environ.get("VCVITS_GRAPH_BYTES", "0"))
+GRAPH_MEM_FRACTION = tuning.number("VCVITS_GRAPH_MEM_FRACTION", 0.4, "share of the device memory the recorded graphs' pools may hold together")
+GRAPH_BYTES = tuning.integer("VCVITS_GRAPH_BYTES", 0, "... as an absolute byte budget (0: the fraction)")
 MAX_OOM_RETRIES = 3  # captures that ran out of memory before the object gives up recording (other failures: at once)
 MAX_COUNTED = 256  # distinct shapes whose repeat counts are remembered
 
 # Capture with the thread-local error mode: under the default ("global") any other thread's event query during the capture is
 # an error that kills the process -- and in a data-parallel run torch's RCCL watchdog thread polls the events of the gradient
 # all-reduces it is still retiring at about that time.  Only the capturing thread's own calls are policed.
-CAPTURE_ERROR_MODE = os.environ.get("VCVITS_CAPTURE_ERROR_MODE", "thread_local")
+CAPTURE_ERROR_MODE = tuning.text("VCVITS_CAPTURE_ERROR_MODE", "thread_local", "stream-capture error mode of the recordings")
 
 
 def set_enabled(on):
@@ -312,14 +312,12 @@ class GraphedBatch(_Recorder):
                 # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step) ...
                 if o._static_set is None:
                     return False
-                # ... and, across REAL ranks, only on request (VCVITS_DDP_GRAPHS=1): the recorded collectives have run here on
-                # a forced one-rank group only (one GPU per box), a graph with forks costs the host 10 - 55 ms per launch on
-                # this ROCm -- about what the eager loop costs -- and a capture that misbehaves on one of eight ranks hangs all
+                # ... and, across REAL ranks, unless switched off (VCVITS_DDP_GRAPHS=0).  The default form records no RCCL kernel
+                # (optim.DDP_GRAPH_MODE "segments": the collectives run eagerly between three replays); the one-graph forms
+                # ("linear" / "fork") have run on a forced one-rank group only
                 if o.world > 1 and not DDP_GRAPHS[0]:
                     return False
-                from .optim import DDP_GRAPH_MODE
-                if o.world > 1 and DDP_GRAPH_MODE[0] != "segments" and os.environ.get("VCVITS_DDP_GRAPHS") != "1":
-                    return False  # (recorded RCCL kernels across real ranks: explicit request only)
+
         return True
 
     def run(self, batch, extra=()):

@@ -13,7 +13,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from .. import ops
+from .. import ops, tuning
 
 # gloo side channels for the host-side "received a gradient" flag exchange, one per set of ranks, shared by every optimizer
 # over that set (optim_g and optim_d of one model; a rebuilt optimizer) and destroyed by shutdown_flag_groups()
@@ -44,9 +44,10 @@ def shutdown_flag_groups():
 #                         graph, the chain stays linear, the host issues three replays and ~20 collectives per batch
 #   "linear"              one graph with the all-reduces recorded in the blocking form (round 5)
 #   "fork"                one graph with the async form on torch's communication stream (forks and joins in the graph)
-DDP_GRAPH_MODE = [os.environ.get("VCVITS_DDP_GRAPH_MODE",
-                                 "segments" if os.environ.get("VCVITS_DDP_GRAPH_LINEAR") is None else
-                                 ("linear" if os.environ.get("VCVITS_DDP_GRAPH_LINEAR") == "1" else "fork"))]
+DDP_GRAPH_MODE = [tuning.text("VCVITS_DDP_GRAPH_MODE", "segments", "how a recorded batch carries its gradient all-reduces: segments | linear | fork")]
+FORCE_DDP = tuning.flag("VCVITS_FORCE_DDP", False, "keep the bucket hooks / collectives in a ONE-rank group (exercises the RCCL path on a 1-GPU box)")
+DDP_STATIC = tuning.flag("VCVITS_DDP_STATIC", True, "freeze the used-parameter set after two steps of cross-rank agreement (no per-step host exchange)")
+GRAD_SINK = tuning.flag("VCVITS_GRAD_SINK", True, "kernels add parameter gradients straight into the optimizer's flat buffer")
 
 class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay 0.01 by default) over a flat buffer.
@@ -100,13 +101,13 @@ class FlatAdamW(torch.optim.Optimizer):
         self._synced = False
         # VCVITS_FORCE_DDP=1 keeps the bucket hooks / collectives active in a 1-rank group (used to exercise
         # the RCCL path on a single-GPU box)
-        self._ddp = self.world > 1 or (os.environ.get("VCVITS_FORCE_DDP") == "1" and dist.is_initialized())
+        self._ddp = self.world > 1 or (tuning.live_flag("VCVITS_FORCE_DDP") and dist.is_initialized())
         self._flag_pg = None
         # Static-graph mode (default; torch DDP's `static_graph` contract): once STATIC_AFTER consecutive steps had every
         # rank report the SAME set of parameters with a gradient, the set is frozen and the per-step flag exchange -- a
         # blocking host collective, i.e. a cross-rank host barrier twice per batch -- is skipped; a later step whose local
         # set differs raises (the other ranks no longer take part in an exchange).  VCVITS_DDP_STATIC=0 exchanges every step.
-        self._static_ok = os.environ.get("VCVITS_DDP_STATIC", "1") == "1"
+        self._static_ok = tuning.live_flag("VCVITS_DDP_STATIC")
         self._static_set = None
         self._static_steps = 0
         self._violation = False
@@ -131,7 +132,7 @@ class FlatAdamW(torch.optim.Optimizer):
         # flat buffer (ops.register_grad_sink) instead of handing autograd a temporary to accumulate.  The
         # backward then returns None for the parameter; autograd still evaluates its AccumulateGrad node (no
         # kernel) and fires the post-accumulate hook above, after the producing kernel was enqueued.
-        if dev.type == "cuda" and os.environ.get("VCVITS_GRAD_SINK", "1") == "1":
+        if dev.type == "cuda" and tuning.live_flag("VCVITS_GRAD_SINK"):
             for p in self.params:
                 ops.register_grad_sink(p, p.grad)
         if dev.type == "cuda":
@@ -394,7 +395,7 @@ class ExponentialLR:
     base rate when that state was dropped -- exactly what the reference does)."""
 
     # VCVITS_LR_REFERENCE_STACK=0 / hparams train.lr_reference_stack=False select the torch >= 2.2 behaviour
-    DEFAULT_REFERENCE_STACK = os.environ.get("VCVITS_LR_REFERENCE_STACK", "1") == "1"
+    DEFAULT_REFERENCE_STACK = tuning.flag("VCVITS_LR_REFERENCE_STACK", True, "ExponentialLR as in the reference's pinned torch 2.0 (first epoch-end step does not decay)")
 
     def __init__(self, optimizer, gamma, last_epoch=-1, reference_stack=None):
         """reference_stack=True (default) follows the scheduler of the stack the reference was written for: its

@@ -9,10 +9,10 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, tuning
 
 MAX_WAV_VALUE = 32768.0
-_CHECK_RANGE = os.environ.get("VCVITS_CHECK_RANGE", "0") == "1"
+_CHECK_RANGE = tuning.flag("VCVITS_CHECK_RANGE", False, "mel_processing: log when a waveform leaves [-1, 1] (the reference prints; a device sync)")
 
 mel_basis = {}
 

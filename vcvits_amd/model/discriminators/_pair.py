@@ -9,6 +9,8 @@ every conv is restricted to the generated half (`ops.grad_batch_start`), so no d
 issued for the real branch."""
 import torch
 
+from ... import tuning
+
 
 def run_pair(disc, y, y_hat):
     if getattr(disc, "use_spectral_norm", False) and disc.training:
@@ -33,6 +35,11 @@ def run_pair(disc, y, y_hat):
 
 
 _STREAMS = []
+_N_STREAMS = tuning.integer("VCVITS_STREAMS", 1, "independent sub-discriminators spread over N HIP streams (eager loop only; 1: one stream)")
+
+
+def streams():
+    return tuning.live_flag("VCVITS_STREAMS")
 
 
 def run_many(discs, inputs):
@@ -40,8 +47,7 @@ def run_many(discs, inputs):
     are spread over N HIP streams so the short, low-occupancy layers (first / last convs, pooled scales)
     of one discriminator overlap the big GEMMs of another; autograd replays each chain's backward on
     the stream it ran on."""
-    import os
-    n = int(os.environ.get("VCVITS_STREAMS", "1"))
+    n = streams()
     if n <= 1 or not inputs[0][0].is_cuda:
         return [run_pair(d, y, y_hat) for d, (y, y_hat) in zip(discs, inputs)]
     while len(_STREAMS) < n:

@@ -1,12 +1,11 @@
 """vits/model/discriminators/multi_period_discriminator.py:9-31 (one DiscriminatorS + one
 DiscriminatorP per period)."""
-import os
 from typing import List
 
 from torch import nn
 
 from ..modules import prepare_weight_norm
-from ._pair import run_many
+from ._pair import run_many, streams
 from .discriminator import DiscriminatorP, DiscriminatorS
 
 
@@ -19,7 +18,7 @@ class MultiPeriodDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList(discs)
 
     def forward(self, y, y_hat, g=None):
-        if int(os.environ.get("VCVITS_STREAMS", "1")) <= 1:
+        if streams() <= 1:
             prepare_weight_norm(self)  # one launch for every layer of every sub-discriminator
             for d in self.discriminators:
                 d._wn_parent_prepared = True

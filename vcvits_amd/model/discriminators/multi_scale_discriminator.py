@@ -1,12 +1,10 @@
 """vits/model/discriminators/multi_scale_discriminator.py:10-42 (5 DiscriminatorS on inputs
 pooled by cascaded AvgPool1d(4, 2, 2))."""
-import os
-
 from torch import nn
 
 from ... import ops
 from ..modules import prepare_weight_norm
-from ._pair import run_many
+from ._pair import run_many, streams
 from .discriminator import DiscriminatorS
 
 
@@ -17,7 +15,7 @@ class MultiScaleDiscriminator(nn.Module):
             [DiscriminatorS(use_spectral_norm=use_spectral_norm)] + [DiscriminatorS() for _ in range(4)])
 
     def forward(self, y, y_hat):
-        if int(os.environ.get("VCVITS_STREAMS", "1")) <= 1:
+        if streams() <= 1:
             prepare_weight_norm(self)  # one launch for every layer of every sub-discriminator
             for d in self.discriminators:
                 d._wn_parent_prepared = True

@@ -1,17 +1,15 @@
 """vits/model/flow.py:7-37"""
-import os
-
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, tuning
 from . import modules
 
 # Mixed-precision policy of the inference path in bf16 mode: the flow is under 1 % of the decode's FLOPs (5.9 of 770 GFLOP per
 # 10 s at 48 kHz) but its output error passes through the whole decoder, so a no-grad pass runs it in the fp32
 # arithmetic (split-operand kernels) and leaves bf16 to the HiFi-GAN decoder, where the time is.  VCVITS_INFER_FLOW_F32=0:
 # the flow in bf16 too.
-_INFER_F32 = [os.environ.get("VCVITS_INFER_FLOW_F32", "1") == "1"]
+_INFER_F32 = [tuning.flag("VCVITS_INFER_FLOW_F32", True, "bf16 mode: the reverse flow of infer() keeps fp32 arithmetic")]
 
 
 class ResidualCouplingBlock(nn.Module):

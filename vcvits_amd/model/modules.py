@@ -3,11 +3,11 @@ forward/backward run on the HIP kernels behind ops/."""
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, tuning
 from .._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH
 
 LRELU_SLOPE = 0.1  # vits/model/modules.py:16
-_WN_LINK = __import__("os").environ.get("VCVITS_WN_LINK", "1") == "1"  # (A/B switch: WN residual-gradient hand-off)
+_WN_LINK = tuning.flag("VCVITS_WN_LINK", True, "WN: the residual gradient handed to the next layer's data-gradient launch (A/B)")
 
 
 def _default_conv_init(weight, bias):

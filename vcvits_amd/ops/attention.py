@@ -4,6 +4,7 @@ Part of `vcvits_amd.ops` (the package re-exports every name: `from vcvits_amd im
 runs on the GPU through libvcvits_hip.so; there is no CPU fallback."""
 import torch
 
+from .. import tuning
 from .._lib import (VcvConvArgs, check, lib, ptr, stream)
 from .core import (LAUNCH_COUNTS, _COMPUTE, _f32c)
 from .conv import (_common, _launch_conv)
@@ -132,7 +133,7 @@ class _RelAttnFusedFn(torch.autograd.Function):
 
 
 # the fused attention kernels (attention.hip) take every shape they support; VCVITS_ATTN_FUSED=0 keeps the unfused path
-_ATTN_FUSED = [__import__("os").environ.get("VCVITS_ATTN_FUSED", "1") == "1"]
+_ATTN_FUSED = [tuning.flag("VCVITS_ATTN_FUSED", True, "relative-position attention as the fused MFMA kernels (0: the three-launch form)")]
 
 
 def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window, pdrop=0.0, training=False, want_attn=True):

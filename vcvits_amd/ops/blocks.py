@@ -5,6 +5,7 @@ Part of `vcvits_amd.ops` (the package re-exports every name: `from vcvits_amd im
 runs on the GPU through libvcvits_hip.so; there is no CPU fallback."""
 import torch
 
+from .. import tuning
 from .._lib import (check, lib, ptr, stream)
 from .core import (_f32c, _sink, _sunk)
 from .elementwise import (mask_mul, scale)
@@ -375,7 +376,7 @@ def interpolate_nearest(x, size, raw_sizes=None):
 # column and COUNTS the position in a per-device int32 word, which check_indices() reads back (a device sync: called at check
 # points -- validation, checkpoint save, epoch end -- or after every batch with VCVITS_CHECK_INDICES=1) and raises on.
 _INDEX_ERR = {}
-CHECK_INDICES_EVERY_BATCH = [__import__("os").environ.get("VCVITS_CHECK_INDICES", "0") == "1"]
+CHECK_INDICES_EVERY_BATCH = [tuning.flag("VCVITS_CHECK_INDICES", False, "read the out-of-range embedding index count back after EVERY batch (a device sync)")]
 
 
 def _index_err_word(dev):

@@ -12,6 +12,7 @@ from .._lib import (ACT_LEAKY, ACT_NONE, ACT_TANH, TF_DLEAKY, TF_LEAKY, TF_NONE,
 from .core import (LAUNCH_COUNTS, _ACT_TO_DTF, _COMPUTE, _DETERMINISTIC, _FAMILIES, _FAMILY_KEY, _GROUPED_BF16,
                    _USE_DMA, _USE_PK, _USE_X3, _USE_X3_WGRAD, _cur_dev, _f32c, _rows, _sink, _sunk, conv_out_len)
 from .weights import (_PACK_JOBS, _stable_entry)
+from .. import tuning
 
 
 def _launch_conv(a, flip_w=None, wt=None):
@@ -187,11 +188,11 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1, out=None, **kw)
         # one OUTPUT channel (conv_post of the discriminators, 1024 -> 1; of the generator, 32 -> 1): the data gradient
         # is a one-input-channel convolution of dy with the flipped taps -- an HBM write stream, not a GEMM (was 35 us
         # on the generic kernel); the derivative of a leaky-ReLU on the conv's input rides in the launch's epilogue
-        wf = w.reshape(C, K).flip(-1).contiguous()
         masked = kw.get("out_tf", TF_NONE) == TF_DLEAKY
-        check(lib().vcv_conv_c1_fwd_masked(ptr(dy), ptr(wf), None, ptr(out), ptr(kw["oaux"]) if masked else None, B, C, Tout,
-                                           Tin, P, K, 1, dil, (K - 1) * dil - pad, ACT_NONE, kw.get("slope", 0.1), stream()),
-              "vcv_conv_c1_fwd_masked")
+        # (the [C, K] rows of w are read backwards by the kernel: no flipped copy, no launch of its own for it)
+        check(lib().vcv_conv_c1_fwd_flip(ptr(dy), ptr(w), None, ptr(out), ptr(kw["oaux"]) if masked else None, B, C, Tout,
+                                         Tin, P, K, 1, dil, (K - 1) * dil - pad, ACT_NONE, kw.get("slope", 0.1), 1, stream()),
+              "vcv_conv_c1_fwd_flip")
         return out
     if stride == 1 and groups == 1 and M >= 32 and C >= 32:
         # stride-1 data gradient == forward conv with the flipped / transposed weights: the forward
@@ -455,7 +456,7 @@ class _TapFn(torch.autograd.Function):
         return g_pass, None, None
 
 
-_TAP_FUSE = [__import__("os").environ.get("VCVITS_TAP_FUSE", "1") == "1"]  # (A/B switch)
+_TAP_FUSE = [tuning.flag("VCVITS_TAP_FUSE", True, "feature-map taps: the second gradient summed inside the producer's activation-derivative pass (A/B)")]
 
 
 def fmap_tap(x):

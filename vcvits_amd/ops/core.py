@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from .. import _lib
+from .. import _lib, tuning
 from .._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, TF_DLEAKY, TF_DRELU, TF_NONE, _GET_DEVICE, check, lib,
                     ptr, stream)
 
@@ -39,21 +39,21 @@ def conv_out_len(tin, k, stride, pad, dil):
     return (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-_USE_DMA = [__import__("os").environ.get("VCVITS_CONV_DMA", "1") == "1"]
+_USE_DMA = [tuning.flag("VCVITS_CONV_DMA", True, "conv launches may go to the packed-weight kernel families (0: register-staged kernel only)")]
 
 
 # fp32 launches try the channel-innermost packed kernel (vcv_conv_pk_*) before the LDS-DMA kernel
-_USE_PK = [__import__("os").environ.get("VCVITS_CONV_PK", "1") == "1"]
+_USE_PK = [tuning.flag("VCVITS_CONV_PK", True, "fp32 launches try the packed fp32-input MFMA kernel before the LDS-DMA kernel")]
 
 
 # fp32 launches try the split-operand kernel first (vcv_conv_x3_*: fp32 operands as three exact bf16 terms each, nine -- or
 # six -- bf16 MFMA products per fp32 product, fp32 accumulate: fp32 results at 1.8-2.7 x the fp32 MFMA peak)
-_USE_X3 = [__import__("os").environ.get("VCVITS_CONV_X3", "1") == "1"]
+_USE_X3 = [tuning.flag("VCVITS_CONV_X3", True, "fp32 launches on the bf16 pipe by exact operand splitting (ops.set_f32_split)")]
 
 
 # the weight gradient in the same arithmetic (vcv_wgrad_x3: wgrad_bf16.hip with three term planes and producer waves);
 # the library takes the shapes where it beats the fp32 kernel (wgrad_dma.hip) and declines the rest
-_USE_X3_WGRAD = [__import__("os").environ.get("VCVITS_WGRAD_X3", "1") == "1"]
+_USE_X3_WGRAD = [tuning.flag("VCVITS_WGRAD_X3", True, "... weight gradients too, where the split kernel is ahead")]
 
 
 def set_f32_split(on, terms=None, all_shapes=None, wgrad=None):
@@ -84,11 +84,11 @@ LAUNCH_COUNTS = {"bf16": 0, "bf16io": 0, "x3": 0, "pk": 0, "dma": 0, "gemm": 0, 
 # bf16 mode stores the conv <-> conv activations of the decoder's inference pass in bf16 in HBM (vcv_conv_bf16io_*: what the
 # reference's fp16 autocast does to every conv output, train.py:104-106); VCVITS_BF16_ACT=0 / set_bf16_activations(False)
 # keeps them fp32 (operands still rounded on their way into the matrix cores)
-_BF16_ACT = [__import__("os").environ.get("VCVITS_BF16_ACT", "1") == "1"]
+_BF16_ACT = [tuning.flag("VCVITS_BF16_ACT", True, "bf16 mode: no-grad decoder passes keep 16-bit activations in HBM (ops.set_bf16_activations)")]
 
 
 # bf16 mode: DiscriminatorS's grouped k = 41 forward on the bf16 matrix pipe (VCVITS_GROUPED_BF16=0: fp32-input MFMA)
-_GROUPED_BF16 = [__import__("os").environ.get("VCVITS_GROUPED_BF16", "1") == "1"]
+_GROUPED_BF16 = [tuning.flag("VCVITS_GROUPED_BF16", True, "bf16 mode: DiscriminatorS's grouped k41 layers on the bf16 matrix pipe")]
 
 
 def set_bf16_activations(on):
@@ -158,7 +158,7 @@ def _cur_dev():
 
 # Combine of the split weight-gradient reductions: True = per-workgroup slabs added in a fixed order (bit-reproducible),
 # False (default: ~2 % faster per step) = fp32 atomics (order varies from run to run).  The bf16 kernel always uses slabs.
-_DETERMINISTIC = [__import__("os").environ.get("VCVITS_DETERMINISTIC", "0") == "1"]
+_DETERMINISTIC = [tuning.flag("VCVITS_DETERMINISTIC", False, "bit-reproducible gradients run to run (ops.set_deterministic; also read by the library)")]
 
 
 def set_deterministic(on):

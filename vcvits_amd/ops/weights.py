@@ -7,6 +7,7 @@ import ctypes
 
 import torch
 
+from .. import tuning
 from .._lib import (VcvConvArgs, check, lib, ptr, stream)
 from .core import (CAPTURING, LAUNCH_COUNTS, _COMPUTE, _USE_PK, _USE_X3, _f32c,
                    _sink, _upload_table)
@@ -95,7 +96,7 @@ _WN_TABLES = {}
 _WN_CACHE = {}
 
 
-_WN_CACHE_ON = [__import__("os").environ.get("VCVITS_WEIGHT_CACHE", "1") == "1"]
+_WN_CACHE_ON = [tuning.flag("VCVITS_WEIGHT_CACHE", True, "weight-normed weights and their packs cached until a parameter changes")]
 
 
 # bumped by every raw write into parameter storage: weights handed to layers before it (modules._w_pre / _w_lazy) are
@@ -130,7 +131,7 @@ GRAPH_EPOCH = [0]
 _PARAM_REGIONS = {}
 
 
-_PARAM_REGIONS_ON = [__import__("os").environ.get("VCVITS_PARAM_REGIONS", "1") == "1"]
+_PARAM_REGIONS_ON = [tuning.flag("VCVITS_PARAM_REGIONS", True, "packs of plain (not weight-normed) conv weights cached per optimizer step")]
 
 
 def register_param_region(flat):
@@ -185,7 +186,7 @@ def _stable_packs(w_ptr):
 _PACK_JOBS = {}
 
 
-_PACK_BATCH = [__import__("os").environ.get("VCVITS_PACK_BATCH", "1") == "1"]
+_PACK_BATCH = [tuning.flag("VCVITS_PACK_BATCH", True, "all packs of a module tree re-made in one launch after its weights changed")]
 
 
 _PACK_FILL = {"vcv_conv_x3_run": "vcv_conv_x3_pack_job", "vcv_conv_pk_run": "vcv_conv_pk_pack_job",

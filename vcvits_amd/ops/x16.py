@@ -7,6 +7,7 @@ import ctypes
 
 import torch
 
+from .. import tuning
 from .._lib import (ACT_NONE, TF_LEAKY, TF_NONE, VcvConvArgs, check, lib, ptr, stream)
 from .core import (LAUNCH_COUNTS, _f32c, _rows, conv_out_len)
 from .conv import (_common, _launch_conv, convT_out_len)
@@ -74,7 +75,7 @@ def conv_forward_x16(x, w, bias=None, stride=1, pad=0, dil=1, in_leaky=False, ou
     return out
 
 
-_CONVT_MERGED = [__import__("os").environ.get("VCVITS_CONVT_MERGED", "1") == "1"]  # (0: one launch phase per output residue)
+_CONVT_MERGED = [tuning.flag("VCVITS_CONVT_MERGED", True, "16-bit transposed convs: all output phases as rows of one launch")]
 
 
 def convT_forward_x16(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.1, out_dtype=torch.bfloat16):
@@ -109,7 +110,7 @@ def convT_forward_x16(x, w, bias=None, stride=1, pad=0, in_leaky=False, slope=0.
 
 
 # ---- one conv pair of a ResBlock1 as ONE launch (resblock_pair.hip) ------------------------------------------------------------
-_PAIR_FUSED = [__import__("os").environ.get("VCVITS_PAIR_FUSED", "1") == "1"]
+_PAIR_FUSED = [tuning.flag("VCVITS_PAIR_FUSED", True, "inference: a ResBlock conv pair as one launch where the fused kernel takes it")]
 
 
 def resblock_pair_supported(x, w1, w2, dil):
