@@ -231,6 +231,9 @@ typedef struct VcvWgradArgs {
 } VcvWgradArgs;
 
 int vcv_conv_wgrad(const VcvWgradArgs* args, void* stream);
+/* 1: vcv_conv_wgrad runs this launch on the LDS-DMA weight-gradient kernel (wgrad_dma.hip); 0: on the register-staged one
+ * (grouped launches, derivative-masked operands, rows under 64 positions, (C, K) blocks under 96 columns). */
+int vcv_conv_wgrad_takes_dma(const VcvWgradArgs* args);
 
 /*
  * bf16-operand weight gradient (same VcvWgradArgs, G == 1, transforms NONE / LEAKY): operands rounded to bf16 on their

@@ -93,7 +93,7 @@ def lib():
 
 # every symbol include/vcvits_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "vcv_version", "vcv_conv_gemm", "vcv_conv_wgrad", "vcv_bias_grad",
+    "vcv_version", "vcv_conv_gemm", "vcv_conv_wgrad", "vcv_conv_wgrad_takes_dma", "vcv_bias_grad",
     "vcv_weight_norm_fwd", "vcv_weight_norm_bwd", "vcv_spectral_norm_fwd", "vcv_spectral_norm_bwd", "vcv_avg3", "vcv_scale", "vcv_mask_mul",
     "vcv_reflect_pad_fwd", "vcv_reflect_pad_bwd", "vcv_avgpool4_fwd", "vcv_avgpool4_bwd",
     "vcv_loss_sum", "vcv_loss_grad", "vcv_adamw", "vcv_stft_mag_fwd", "vcv_stft_mag_bwd",
@@ -114,6 +114,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _ARGTYPES = {
     "vcv_conv_gemm": [ctypes.POINTER(VcvConvArgs), _P],
     "vcv_conv_wgrad": [ctypes.POINTER(VcvWgradArgs), _P],
+    "vcv_conv_wgrad_takes_dma": [ctypes.POINTER(VcvWgradArgs)],
     "vcv_bias_grad": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "vcv_weight_norm_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "vcv_weight_norm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -533,14 +533,25 @@ int launch(const VcvWgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// returns -100 when the launch is not eligible for this kernel (the caller falls back)
-int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st) {
+static bool wgrad_dma_eligible(const VcvWgradArgs& a) {
   const bool tf_ok = (a.a_tf == VCV_TF_NONE || a.a_tf == VCV_TF_LEAKY) && (a.b_tf == VCV_TF_NONE || a.b_tf == VCV_TF_LEAKY) &&
                      a.slope >= 0.f && a.slope < 1.f;
   const int N = a.Cg * a.K;
   const long long U = (long long)a.Ta * a.P;
-  if (a.G != 1 || !tf_ok || a.transpose_out || a.Mg < 32 || N < 96 || U < 64 || a.s < 1 || a.s > 8) return -100;
+  if (a.G != 1 || !tf_ok || a.transpose_out || a.Mg < 32 || N < 96 || U < 64 || a.s < 1 || a.s > 8) return false;
   // 32-bit byte offsets inside one batch item of either operand
-  if ((long long)a.Mg * U * 4 >= (1ll << 31) || (long long)a.Cg * a.Tb * a.P * 4 >= (1ll << 31)) return -100;
+  if ((long long)a.Mg * U * 4 >= (1ll << 31) || (long long)a.Cg * a.Tb * a.P * 4 >= (1ll << 31)) return false;
+  return true;
+}
+
+// returns -100 when the launch is not eligible for this kernel (the caller falls back)
+int vcv_wgrad_dma_try(const VcvWgradArgs& a, hipStream_t st) {
+  if (!wgrad_dma_eligible(a)) return -100;
   return a.s == 1 ? launch<false>(a, st) : launch<true>(a, st);
+}
+
+// 1: vcv_conv_wgrad hands this launch to the LDS-DMA kernel (wgrad_dma_kernel); 0: it runs on the register-staged
+// conv_wgrad_kernel (tools/fallback_census.py lists those shapes)
+extern "C" int vcv_conv_wgrad_takes_dma(const VcvWgradArgs* a) {
+  return a && vcv_tuning().wgrad_dma != 0 && wgrad_dma_eligible(*a) ? 1 : 0;
 }
