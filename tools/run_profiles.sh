@@ -2,9 +2,9 @@
 # Run on the GPU box (gpurun): rocprofv3 kernel trace + the two HBM-traffic PMC passes (each in its own run, per
 # MI355X_MICROARCH.md) of the bench workloads, an MFMA-busy PMC pass of the dominant kernels, raw CSVs under
 # gpurun_out/<tag>_*/..., condensed by tools/profile_summary.py / tools/pmc_busy_summary.py into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r5'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_profiles.sh r6'
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 # every step under its own limit: SIGUSR1 first (bench.py dumps the Python stacks of all threads into the step's log),
 # SIGKILL 20 s later -- one stuck pass must not eat the whole call
 T="timeout -s USR1 -k 20"
@@ -69,6 +69,7 @@ $T 400 python3 bench.py --steps 10 --warmup 3 > profiles/${TAG}_bench_line.json 
 $T 400 python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > profiles/${TAG}_bench_line_bf16.json 2>/dev/null
 $T 400 python3 bench.py --dtype bf16 --workload full --batch 32 --steps 10 --warmup 5 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2.json 2>/dev/null
 $T 400 python3 bench.py --dtype bf16 --config 48k --workload full --steps 10 --warmup 5 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg3_1gpu.json 2>/dev/null
+$T 400 python3 bench.py --dtype bf16 --workload full --batch 32 --varlen 64 --steps 16 --warmup 3 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg2_varlen.json 2>/dev/null
 $T 400 python3 bench.py --dtype bf16 --config 48k --workload infer --steps 5 --warmup 2 > profiles/${TAG}_bench_line_cfg4.json 2>/dev/null
 $T 400 python3 bench.py --config 48k --workload infer --steps 3 --warmup 1 --no-cpu-baseline > profiles/${TAG}_bench_line_cfg4_f32.json 2>/dev/null
 cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
