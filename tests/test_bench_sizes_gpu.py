@@ -184,7 +184,7 @@ def test_config2_batch_rows_equal_single_runs(gpu, config, B, dtype):
 
 
 def test_config2_bf16_step_losses_B32(gpu):
-    """The timed configs[2] step itself (bf16 mode, B = 32): losses within the bf16 bound (2e-3, DESIGN 3.1) of the fp32 CPU oracle
+    """The timed configs[2] step itself (bf16 mode, B = 32): losses within the bf16 bound (2e-3, DESIGN 3.4) of the fp32 CPU oracle
     run on the same 32 utterances."""
     from oracle.cpu_step import CpuTrainer
     from vcvits_amd import configs, ops
@@ -210,7 +210,7 @@ def test_config2_bf16_step_losses_B32(gpu):
 
 def test_config3_bf16_step_losses_B16(gpu):
     """The timed configs[3] step itself on one rank (48k widths, 12 periods, bf16 mode, per-GPU B = 16 x 384 frames): losses
-    within the bf16 bound (2e-3, DESIGN 3.1) of the fp32 CPU oracle run on the same 16 utterances."""
+    within the bf16 bound (2e-3, DESIGN 3.4) of the fp32 CPU oracle run on the same 16 utterances."""
     from oracle.cpu_step import CpuTrainer
     from vcvits_amd import configs, ops
     from vcvits_amd.light.vcvits import VCVITS

@@ -3,7 +3,7 @@ conv activations, fp32 accumulate / master weights / losses / optimizer -- the r
 configs/base.json:18, with bf16 for fp16) at FULL widths of both configs against the fp32 CPU oracle trainer: both
 losses and every parameter gradient of both optimizer passes (vits/light/vcvits.py:54-183).
 
-Bounds (DESIGN.md section 3.1): one bf16 rounding is a relative error of at most 2^-9 per operand (rms 2^-9 / sqrt 3 =
+Bounds (DESIGN.md section 3.4): one bf16 rounding is a relative error of at most 2^-9 per operand (rms 2^-9 / sqrt 3 =
 1.1e-3, two operands per GEMM: 1.6e-3); the gradient of the generator's first layer has passed ~30 generator GEMMs
 forward, 6 + 6 discriminator GEMMs and ~30 back: a random walk of ~70 steps -> 1.4e-2 expected for a well-conditioned
 sum, more where a gradient is a sum of terms of both signs (bias sums) or sits behind (leaky-)ReLU kinks.  Observed on

@@ -9,7 +9,7 @@ Now:
     name, default, one line of meaning -- and nowhere else is `os.environ` consulted for a VCVITS_* name.  The modules keep
     their one-element-list switches (shared by reference across the ops package), initialised from these declarations.
 
-`python -m vcvits_amd.tuning` prints both tables (README / DESIGN section 13 are generated from it)."""
+`python -m vcvits_amd.tuning` prints both tables (DESIGN section 10 points here)."""
 import os
 
 REGISTRY = {}  # name -> (kind, default, doc, value)
