@@ -432,10 +432,20 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
             setup_steps += 1
         sync()
     elif module is not None:
-        while setup_steps < 4:
+        # (data parallel: recording waits until both optimizers have frozen their used-parameter sets -- two steps of
+        # cross-rank agreement -- and then for the third sighting of the shape: up to eight setup steps instead of four,
+        # every rank taking the same number)
+        ddp_opts = [o for o in (module.optim_g, module.optim_d) if getattr(o, "_ddp", False)]
+        max_setup = 8 if ddp_opts else 4
+        while setup_steps < max_setup:
             bg = module.__dict__.get("_batch_graph")
-            if bg is not None and (bg.replays > 0 or not bg.applicable()):
-                break
+            if bg is not None:
+                if bg.replays > 0:
+                    break
+                if not bg.applicable():
+                    waiting = bool(ddp_opts) and not bg.failed and any(o._static_set is None for o in ddp_opts)
+                    if not waiting:
+                        break
             run()
             setup_steps += 1
         sync()
