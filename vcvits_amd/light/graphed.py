@@ -74,7 +74,7 @@ BATCH_ENABLED = [tuning.flag("VCVITS_BATCH_GRAPHS", True, "the whole training ba
 # record batches whose gradient all-reduces span real ranks: on by default in the segmented form (optim.DDP_GRAPH_MODE: the
 # collectives stay OUTSIDE the graphs); the one-graph forms ("linear" / "fork": RCCL kernels recorded) only on request
 DDP_GRAPHS = [tuning.flag("VCVITS_DDP_GRAPHS", True, "record batches whose gradient all-reduces span real ranks")]
-MAX_ENTRIES = tuning.integer("VCVITS_GRAPH_ENTRIES", 12, "recorded graphs kept per object (distinct batch shapes), LRU")  # graphs kept per object (distinct batch shapes), LRU
+MAX_ENTRIES = tuning.integer("VCVITS_GRAPH_ENTRIES", 12, "recorded graphs kept per object (distinct batch shapes), LRU")
 # ... and the memory they may hold together: every recorded batch owns a private pool with the whole activation footprint of
 # its shape (plus a table arena and a weight-gradient arena), next to the eager working set.  Fraction of the device's
 # memory (default 0.4: 115 GB of the MI355X's 288) or VCVITS_GRAPH_BYTES in bytes; least-recently-used graphs go first.
@@ -317,7 +317,6 @@ class GraphedBatch(_Recorder):
                 # ("linear" / "fork") have run on a forced one-rank group only
                 if o.world > 1 and not DDP_GRAPHS[0]:
                     return False
-
         return True
 
     def run(self, batch, extra=()):

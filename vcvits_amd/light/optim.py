@@ -187,6 +187,8 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def allreduce_buckets_now(self):
         """Average every bucket across the group, blocking form on the current stream (segmented replay)."""
+        if not self._ddp:
+            return
         for view in self.bucket_views():
             dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
 
