@@ -449,6 +449,20 @@ def run_leg(config, workload, dtype, batch, frames, steps, warmup, dev, world, r
             run()
             setup_steps += 1
         sync()
+    if module is not None and prof:
+        # still setup: the timed region mixes replayed batches with eager ones (every fourth carries per-launch events), and
+        # recording a batch EMPTIES the caching allocator (torch's capture entry) -- the first eager batch after it would pay
+        # for ~10 GB of fresh hipMallocs inside the timed region (seen once as a 130-300 ms first step on a fresh box).  One
+        # eager batch here gives the eager loop its pools back.
+        from vcvits_amd.light import graphed as _graphed
+        bg = module.__dict__.get("_batch_graph")
+        if bg is not None and bg.replays > 0:
+            was = _graphed.BATCH_ENABLED[0]
+            _graphed.set_batch_enabled(False)
+            run()
+            _graphed.set_batch_enabled(was)
+            setup_steps += 1
+            sync()
     for _ in range(warmup):
         run()
     sync()
