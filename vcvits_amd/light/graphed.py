@@ -47,7 +47,7 @@ the addresses is still there and means the same.  That is enforced by constructi
     calls.  What this form gives up is the overlap of a bucket's all-reduce with the rest of the backward pass (the eager
     loop's side stream): across eight ranks that is the all-reduce time of ~0.5 GB of gradients over xGMI per batch.  The
     round-5 forms stay selectable: one graph with the collectives recorded in the blocking form ("linear") or on torch's
-    communication stream ("fork": a graph with forks costs the host 10 - 70 ms per launch on this ROCm).  Recording starts
+    communication stream ("fork": a graph with forks costs the host 5 - 9 ms per launch on this ROCm against 1 - 2 for a linear chain).  Recording starts
     only after the used-parameter set was frozen (FlatAdamW static mode: no host-side flag exchange left in the step);
   * the key of a graph holds the batch shapes, the arithmetic switches and the parameter-storage epoch
     (ops.GRAPH_EPOCH: a rebuilt optimizer, a replaced layer) -- a graph recorded for other storage is never replayed;

@@ -202,8 +202,8 @@ class FlatAdamW(torch.optim.Optimizer):
         if backend == "nccl" and ops.CAPTURING[0] is not None and DDP_GRAPH_MODE[0] == "linear":
             # recorded into a HIP graph (light/graphed.py): the blocking form, which this torch launches on the CURRENT stream --
             # the graph stays one linear chain (0.5 - 2.7 ms of host time per replay).  The async form runs on the process
-            # group's own stream: a fork and a join per bucket, and a graph with forks costs the host 10 - 70 ms per launch on
-            # this ROCm and ran slower than the eager loop.  Recorded, a bucket's all-reduce does not overlap
+            # group's own stream: a fork and a join per bucket, and a graph with forks costs the host 5 - 9 ms per launch on
+            # this ROCm against 1 - 2 for a linear chain.  Recorded, a bucket's all-reduce does not overlap
             # the backward kernels that follow it; VCVITS_DDP_GRAPH_LINEAR=0 keeps the side stream.
             dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
         elif backend == "nccl":
