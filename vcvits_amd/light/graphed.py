@@ -66,6 +66,7 @@ import torch
 
 from .. import _lib, ops, tuning
 from .._lib import lib
+from ..model.discriminators._pair import join_streams
 
 ENABLED = [tuning.flag("VCVITS_GRAPHS", True, "HIP-graph replay of repeated launch sequences at all")]
 # the whole batch (both optimizer passes and their AdamW steps) as one graph: on by default (VCVITS_BATCH_GRAPHS=0 keeps
@@ -307,6 +308,14 @@ class GraphedBatch(_Recorder):
                 and m.training and og is not None and od is not None and og.grad.is_cuda
                 and not lib().vcv_prof_active() and ops.DROPOUT_TRACE[0] is None and ops.CAPTURING[0] is None):
             return False
+        from ..model.discriminators._pair import streams
+        if streams() > 1:
+            # the sub-discriminators spread over several HIP streams (VCVITS_STREAMS > 1) are for the EAGER loop only: recorded
+            # with the forks, the batch replays 4 - 5 % faster and WRONG -- in deterministic mode the first replay equals the
+            # eager batch and from the second on the discriminator loss runs away, identically for 2 and 3 streams and with
+            # every side stream joined after each backward pass (tools/probes/streams_race_probe.py): not an ordering race
+            # but something a replay leaves behind; not found
+            return False
         for o in (og, od):
             if getattr(o, "_ddp", False):
                 # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step) ...
@@ -402,6 +411,7 @@ class GraphedBatch(_Recorder):
                     opt.zero_grad()
                     loss = m.training_step(static, 0, idx)
                     loss.backward()
+                    join_streams()  # (VCVITS_STREAMS > 1: side-stream gradient kernels before the all-reduces / AdamW)
                     opt.step()  # (finish_grad_sync inside: the all-reduce joins are part of the graph)
                     losses["g" if idx == 0 else "d"] = loss.detach()
                     state["touched_%s" % ("g" if idx == 0 else "d")] = bytes(opt._touched)
@@ -432,6 +442,7 @@ class GraphedBatch(_Recorder):
                 og.zero_grad()
                 loss = m.training_step(static, 0, 0)
                 loss.backward()
+                join_streams()
                 losses["g"] = loss.detach()
 
             def seg_d(cap):
@@ -441,6 +452,7 @@ class GraphedBatch(_Recorder):
                 od.zero_grad()
                 loss = m.training_step(static, 0, 1)
                 loss.backward()
+                join_streams()
                 losses["d"] = loss.detach()
 
             def seg_end(cap):

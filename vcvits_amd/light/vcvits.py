@@ -49,6 +49,8 @@ except Exception:  # noqa: BLE001 -- not installed (this image) or broken: the m
     _Base, HAS_LIGHTNING = nn.Module, False
 
 
+from ..model.discriminators._pair import join_streams  # noqa: E402
+
 class VCVITS(_Base):
     def __init__(self, **kwargs):
         super().__init__()
@@ -378,6 +380,7 @@ class VCVITS(_Base):
             opt.zero_grad()
             loss = self.training_step(batch, batch_idx, idx)
             loss.backward()
+            join_streams()  # (VCVITS_STREAMS > 1: the sub-discriminators' gradient kernels ran on side streams)
             if after_backward is not None:
                 opt.finish_grad_sync()
                 after_backward(idx, opt)

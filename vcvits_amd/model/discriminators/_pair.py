@@ -42,6 +42,22 @@ def streams():
     return tuning.live_flag("VCVITS_STREAMS")
 
 
+def join_streams():
+    """Make the current stream wait for everything queued on the side streams.  Needed after a BACKWARD pass: the weight-,
+    bias- and weight-norm-gradient kernels of a sub-discriminator run on its side stream and add into the optimizer's flat
+    gradient buffer through gradient sinks -- autograd sees `None` for those parameters and therefore puts no stream
+    dependency between the side stream and whatever reads the buffer next (the all-reduce, AdamW).  In the eager loop the
+    omission is a latent race; recorded into a HIP graph it is a missing edge, and the replayed AdamW overtakes the
+    gradients (tools/probes/streams_race_probe.py)."""
+    n = streams()
+    if n <= 1 or not _STREAMS:
+        return
+    cur = torch.cuda.current_stream()
+    for s in _STREAMS[:n]:  # (the streams run_many deals the chains to; under a capture they are part of it since the forward)
+        if s is not cur:
+            cur.wait_stream(s)
+
+
 def run_many(discs, inputs):
     """Run independent discriminators on their (y, y_hat) pairs.  With VCVITS_STREAMS=N > 1 the chains
     are spread over N HIP streams so the short, low-occupancy layers (first / last convs, pooled scales)
