@@ -313,8 +313,9 @@ class GraphedBatch(_Recorder):
             # the sub-discriminators spread over several HIP streams (VCVITS_STREAMS > 1) are for the EAGER loop only: recorded
             # with the forks, the batch replays 4 - 5 % faster and WRONG -- in deterministic mode the first replay equals the
             # eager batch and from the second on the discriminator loss runs away, identically for 2 and 3 streams and with
-            # every side stream joined after each backward pass (tools/probes/streams_race_probe.py): not an ordering race
-            # but something a replay leaves behind; not found
+            # every side stream joined after each backward pass, with or without gradient sinks / the weight cache / batched
+            # packs / tap fusion / parameter regions (tools/probes/streams_race_probe.py): not an ordering race of this code;
+            # either something a replay leaves behind or the re-launch of a forked hipGraph on this ROCm -- not found
             return False
         for o in (og, od):
             if getattr(o, "_ddp", False):
