@@ -41,14 +41,12 @@ the addresses is still there and means the same.  That is enforced by constructi
     the full model raced (wrong losses from the third replay on, a GPU memory fault once eager batches were interleaved);
   * data parallel (round 6): the batch is recorded as THREE graphs sharing one pool -- [G pass] [AdamW(G) + D pass]
     [AdamW(D)] -- and the bucket all-reduces are issued eagerly between their replays, in the blocking form, on the same
-    stream, in the order the eager loop issues them (light/optim.py: DDP_GRAPH_MODE "segments").  No RCCL kernel is inside
-    a graph, the chain stays linear, a rank that replays and a rank that still runs eagerly issue the same collectives in
-    the same order, and the host's work per batch is three replays + ~20 collective calls instead of ~1,500 launcher
-    calls.  What this form gives up is the overlap of a bucket's all-reduce with the rest of the backward pass (the eager
-    loop's side stream): across eight ranks that is the all-reduce time of ~0.5 GB of gradients over xGMI per batch.  The
-    round-5 forms stay selectable: one graph with the collectives recorded in the blocking form ("linear") or on torch's
-    communication stream ("fork": a graph with forks costs the host 5 - 9 ms per launch on this ROCm against 1 - 2 for a linear chain).  Recording starts
-    only after the used-parameter set was frozen (FlatAdamW static mode: no host-side flag exchange left in the step);
+    stream, in the order the eager loop issues them (light/optim.py).  No RCCL kernel is inside a graph, the chain stays
+    linear, a rank that replays and a rank that still runs eagerly issue the same collectives in the same order, and the
+    host's work per batch is three replays + ~20 collective calls instead of ~1,500 launcher calls.  What this form gives up
+    is the overlap of a bucket's all-reduce with the rest of the backward pass (the eager loop's side stream): across eight
+    ranks that is the all-reduce time of ~0.5 GB of gradients over xGMI per batch.  Recording starts only after the
+    used-parameter set was frozen (FlatAdamW static mode: no host-side flag exchange left in the step);
   * the key of a graph holds the batch shapes, the arithmetic switches and the parameter-storage epoch
     (ops.GRAPH_EPOCH: a rebuilt optimizer, a replaced layer) -- a graph recorded for other storage is never replayed;
     entries are LRU-bounded by count (`MAX_ENTRIES`) AND by the memory their pools hold (`GRAPH_MEM_FRACTION` of the
@@ -72,8 +70,7 @@ ENABLED = [tuning.flag("VCVITS_GRAPHS", True, "HIP-graph replay of repeated laun
 # the whole batch (both optimizer passes and their AdamW steps) as one graph: on by default (VCVITS_BATCH_GRAPHS=0 keeps
 # the eager loop with the graphed no-grad generator pass)
 BATCH_ENABLED = [tuning.flag("VCVITS_BATCH_GRAPHS", True, "the whole training batch (both passes + AdamW) as one recorded sequence")]
-# record batches whose gradient all-reduces span real ranks: on by default in the segmented form (optim.DDP_GRAPH_MODE: the
-# collectives stay OUTSIDE the graphs); the one-graph forms ("linear" / "fork": RCCL kernels recorded) only on request
+# record batches whose gradient all-reduces span real ranks (in three segments: the collectives stay OUTSIDE the graphs)
 DDP_GRAPHS = [tuning.flag("VCVITS_DDP_GRAPHS", True, "record batches whose gradient all-reduces span real ranks")]
 MAX_ENTRIES = tuning.integer("VCVITS_GRAPH_ENTRIES", 12, "recorded graphs kept per object (distinct batch shapes), LRU")
 # ... and the memory they may hold together: every recorded batch owns a private pool with the whole activation footprint of
@@ -308,23 +305,13 @@ class GraphedBatch(_Recorder):
                 and m.training and og is not None and od is not None and og.grad.is_cuda
                 and not lib().vcv_prof_active() and ops.DROPOUT_TRACE[0] is None and ops.CAPTURING[0] is None):
             return False
-        from ..model.discriminators._pair import streams
-        if streams() > 1:
-            # the sub-discriminators spread over several HIP streams (VCVITS_STREAMS > 1) are for the EAGER loop only: recorded
-            # with the forks, the batch replays 4 - 5 % faster and WRONG -- in deterministic mode the first replay equals the
-            # eager batch and from the second on the discriminator loss runs away, identically for 2 and 3 streams and with
-            # every side stream joined after each backward pass, with or without gradient sinks / the weight cache / batched
-            # packs / tap fusion / parameter regions (tools/probes/streams_race_probe.py): not an ordering race of this code;
-            # either something a replay leaves behind or the re-launch of a forked hipGraph on this ROCm -- not found
-            return False
         for o in (og, od):
             if getattr(o, "_ddp", False):
                 # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step) ...
                 if o._static_set is None:
                     return False
-                # ... and, across REAL ranks, unless switched off (VCVITS_DDP_GRAPHS=0).  The default form records no RCCL kernel
-                # (optim.DDP_GRAPH_MODE "segments": the collectives run eagerly between three replays); the one-graph forms
-                # ("linear" / "fork") have run on a forced one-rank group only
+                # ... and, across REAL ranks, unless switched off (VCVITS_DDP_GRAPHS=0).  No RCCL kernel is recorded: the
+                # collectives run eagerly between the replays of three segments
                 if o.world > 1 and not DDP_GRAPHS[0]:
                     return False
         return True
@@ -402,6 +389,11 @@ class GraphedBatch(_Recorder):
             if o.hyper is None:
                 o.hyper = torch.zeros(2, device=dev, dtype=torch.int32)
         state = {}
+        # the root gradient of both backward passes: ONE tensor outside the graph's pool.  autograd's own `ones_like(loss)` is
+        # a pool allocation, and with the sub-discriminators on several streams (VCVITS_STREAMS > 1) the replayed branch that
+        # read it last saw the block's previous contents instead (a generator-pass loss term: all of MPD's gradients came out
+        # 5.13 x too large from the first replay on, deterministically -- tools/probes/streams_race_probe.py)
+        root_one = torch.ones((), device=dev, dtype=torch.float32)
 
         def body(cap):
             losses = {}
@@ -411,7 +403,7 @@ class GraphedBatch(_Recorder):
                     m._toggle(idx)
                     opt.zero_grad()
                     loss = m.training_step(static, 0, idx)
-                    loss.backward()
+                    loss.backward(root_one)
                     join_streams()  # (VCVITS_STREAMS > 1: side-stream gradient kernels before the all-reduces / AdamW)
                     opt.step()  # (finish_grad_sync inside: the all-reduce joins are part of the graph)
                     losses["g" if idx == 0 else "d"] = loss.detach()
@@ -428,12 +420,11 @@ class GraphedBatch(_Recorder):
                     p.requires_grad_(True)
             return losses
 
-        from .optim import DDP_GRAPH_MODE
-        segments = bool(getattr(og, "_ddp", False) or getattr(od, "_ddp", False)) and DDP_GRAPH_MODE[0] == "segments"
+        segments = bool(getattr(og, "_ddp", False) or getattr(od, "_ddp", False))
 
         def seg_bodies():
             """The same batch as three recordings: the gradient all-reduces (not recorded: FlatAdamW._launch_bucket returns
-            at once while recording in this mode) run eagerly between their replays."""
+            at once while recording) run eagerly between their replays."""
             losses = {}
             old_arena = [None]
 
@@ -442,7 +433,7 @@ class GraphedBatch(_Recorder):
                 m._toggle(0)
                 og.zero_grad()
                 loss = m.training_step(static, 0, 0)
-                loss.backward()
+                loss.backward(root_one)
                 join_streams()
                 losses["g"] = loss.detach()
 
@@ -452,7 +443,7 @@ class GraphedBatch(_Recorder):
                 m._toggle(1)
                 od.zero_grad()
                 loss = m.training_step(static, 0, 1)
-                loss.backward()
+                loss.backward(root_one)
                 join_streams()
                 losses["d"] = loss.detach()
 
@@ -499,7 +490,7 @@ class GraphedBatch(_Recorder):
             return None
         graph, cap, seed, losses = rec
         cap.append(arena["buf"])
-        ent = {"graph": graph, "inputs": static, "losses": losses, "seed": seed, "cap": cap, "logged": dict(m.logged),
+        ent = {"graph": graph, "inputs": static, "losses": losses, "seed": seed, "cap": cap, "logged": dict(m.logged), "root": root_one,
                "device": dev, "bytes": self.last_pool_bytes + 4 * int(arena["buf"].numel()), "segments": segments,
                "touched_g": state["touched_g"], "touched_d": state["touched_d"],
                "ranges_g": state["ranges_g"], "ranges_d": state["ranges_d"],

@@ -38,13 +38,12 @@ def shutdown_flag_groups():
     _FLAG_GROUPS.clear()
 
 
-# How a RECORDED batch (light/graphed.py) carries its gradient all-reduces:
-#   "segments" (default)  the batch is three graphs -- [G pass] [AdamW(G) + D pass] [AdamW(D)] -- and the bucket all-reduces are
-#                         issued EAGERLY between the replays, blocking form, on the same stream: nothing of RCCL is inside a
-#                         graph, the chain stays linear, the host issues three replays and ~20 collectives per batch
-#   "linear"              one graph with the all-reduces recorded in the blocking form (round 5)
-#   "fork"                one graph with the async form on torch's communication stream (forks and joins in the graph)
-DDP_GRAPH_MODE = [tuning.text("VCVITS_DDP_GRAPH_MODE", "segments", "how a recorded batch carries its gradient all-reduces: segments | linear | fork")]
+# A RECORDED batch (light/graphed.py) is three graphs -- [G pass] [AdamW(G) + D pass] [AdamW(D)] -- and the bucket all-reduces are
+# issued EAGERLY between their replays, blocking form, on the same stream: nothing of RCCL is inside a graph, the chain of
+# replays and collectives is linear, and the host issues three replays and ~20 collectives per batch.  (Round 5's one-graph
+# forms -- the collectives recorded in the blocking form, or on torch's communication stream with forks and joins -- measured
+# level with this one on a forced one-rank group and crash inside RCCL's capture path once the sub-discriminators run on
+# several streams; they are gone.)
 FORCE_DDP = tuning.flag("VCVITS_FORCE_DDP", False, "keep the bucket hooks / collectives in a ONE-rank group (exercises the RCCL path on a 1-GPU box)")
 DDP_STATIC = tuning.flag("VCVITS_DDP_STATIC", True, "freeze the used-parameter set after two steps of cross-rank agreement (no per-step host exchange)")
 GRAD_SINK = tuning.flag("VCVITS_GRAD_SINK", True, "kernels add parameter gradients straight into the optimizer's flat buffer")
@@ -195,18 +194,14 @@ class FlatAdamW(torch.optim.Optimizer):
     def _launch_bucket(self, b):
         view = self.grad[b["lo"]:b["hi"]]
         backend = dist.get_backend(self.pg)
-        if ops.CAPTURING[0] is not None and DDP_GRAPH_MODE[0] == "segments":
-            return  # (recorded in segments: the all-reduces run eagerly between the replays -- GraphedBatch.run)
-        if ops.CAPTURING[0] is None:
-            self._order_now.append(b["i"])
-        if backend == "nccl" and ops.CAPTURING[0] is not None and DDP_GRAPH_MODE[0] == "linear":
-            # recorded into a HIP graph (light/graphed.py): the blocking form, which this torch launches on the CURRENT stream --
-            # the graph stays one linear chain (0.5 - 2.7 ms of host time per replay).  The async form runs on the process
-            # group's own stream: a fork and a join per bucket, and a graph with forks costs the host 5 - 9 ms per launch on
-            # this ROCm against 1 - 2 for a linear chain.  Recorded, a bucket's all-reduce does not overlap
-            # the backward kernels that follow it; VCVITS_DDP_GRAPH_LINEAR=0 keeps the side stream.
-            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
-        elif backend == "nccl":
+        if ops.CAPTURING[0] is not None:
+            return  # (recording: the all-reduces run eagerly between the replays of the three segments -- GraphedBatch.run)
+        self._order_now.append(b["i"])
+        # a bucket may hold gradients of sub-discriminators that ran on DIFFERENT side streams (VCVITS_STREAMS > 1), and the
+        # collective orders itself after the CURRENT stream only: make that one wait for the others first
+        from ..model.discriminators._pair import join_streams
+        join_streams()
+        if backend == "nccl":
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._works.append((work, None))
         else:
@@ -228,7 +223,7 @@ class FlatAdamW(torch.optim.Optimizer):
             if view is not None:
                 view.div_(self.world)
         self._works = []
-        if ops.CAPTURING[0] is None:
+        if ops.CAPTURING[0] is None:  # (a recording pass issues no collectives: it must not erase the eager order)
             self._bucket_order, self._order_now = self._order_now, []
         # A parameter one rank used and another did not (a batch-dependent conditioning path) still received the
         # averaged gradient everywhere: every rank must apply the same update, so the "received a gradient" flags are
