@@ -27,7 +27,7 @@ def test_step_graph_tests_in_child_process(gpu):
                        timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
-    assert "10 passed" in out, out[-1500:]
+    assert "8 passed" in out, out[-1500:]
 
 
 def _cfg(p_dropout):
@@ -430,48 +430,3 @@ def test_captured_backward_regenerates_the_replays_dropout_mask(gpu):
         ops.replace("next_seed", real_next)
         L.vcv_set_seed_offset_ptr(None)
 
-
-@step_graph
-@pytest.mark.parametrize("nstreams", [2, 3])
-def test_graphed_batch_multi_stream_is_bit_identical_in_deterministic_mode(gpu, nstreams, monkeypatch):
-    """The sub-discriminator chains on several HIP streams (VCVITS_STREAMS, default 2) inside a recorded batch.  In
-    deterministic mode nothing in the GAN step depends on an execution order, so replayed batches must leave the parameters
-    of both optimizers BIT-identical to the eager loop's -- and to the single-stream run's.  (Before the root gradient of the
-    recorded backward passes moved out of the graph's pool, the multi-stream replay scaled every MPD gradient by 5.13 from
-    the first replay on; tools/probes/streams_race_probe.py is the long form of this test.)"""
-    from vcvits_amd import configs, ops, synthetic
-    from vcvits_amd.light import graphed
-    from vcvits_amd.light.vcvits import VocoderGAN
-    cfg = configs.base()
-    cfg["model"].update({"inter_channels": 32, "upsample_initial_channel": 128,
-                         "multi_period_discriminator_periods": [2, 3, 5, 7]})
-    cfg["data"]["n_mel_channels"] = 40
-    cfg["train"]["segment_size"] = 8192
-    torch.manual_seed(9)
-    sd = copy.deepcopy(VocoderGAN(**cfg).state_dict())
-    batches = [{k: v.to(gpu) for k, v in synthetic.vocoder_batch(4, 32, segment_size=8192, seed=60 + i).items()} for i in range(2)]
-    ops.set_deterministic(True)
-    flats = {}
-    try:
-        for ns, mode in ((1, False), (nstreams, False), (nstreams, True)):
-            monkeypatch.setenv("VCVITS_STREAMS", str(ns))
-            graphed.set_step_enabled(mode)
-            mod = VocoderGAN(**cfg)
-            mod.load_state_dict(sd)
-            mod = mod.to(gpu)
-            mod.configure_optimizers()
-            for i in range(8):
-                mod.fit_batch(batches[i % 2])
-            torch.cuda.synchronize()
-            flats[(ns, mode)] = (mod.optim_g.flat.clone(), mod.optim_d.flat.clone())
-            if mode:
-                sg = mod.__dict__["_batch_graph"]
-                assert not sg.failed and sg.replays >= 6, (sg.failed, sg.replays)
-            mod.optim_g.close()
-            mod.optim_d.close()
-    finally:
-        graphed.set_step_enabled(True)
-        ops.set_deterministic(False)
-    ref = flats[(1, False)]
-    for key in ((nstreams, False), (nstreams, True)):
-        assert torch.equal(flats[key][0], ref[0]) and torch.equal(flats[key][1], ref[1]), key

@@ -305,6 +305,16 @@ class GraphedBatch(_Recorder):
                 and m.training and og is not None and od is not None and og.grad.is_cuda
                 and not lib().vcv_prof_active() and ops.DROPOUT_TRACE[0] is None and ops.CAPTURING[0] is None):
             return False
+        from ..model.discriminators._pair import streams
+        if streams() > 1:
+            # the sub-discriminators spread over several HIP streams are for the EAGER loop only.  Recorded with the forks the
+            # batch replays 4 - 5 % faster and not reliably right: autograd's root gradient (a pool allocation) was read
+            # stale by the branch that consumed it last -- every MPD gradient 5.13 x too large from the first replay on;
+            # fixed by `root_one` below, after which the vocoder workload replays bit-identically in deterministic mode on
+            # 2 and 3 streams -- but the bf16 / reduced-width / forced-DDP cases of tests/test_graphed_gpu.py still replay
+            # wrong losses (9 % off), so there is at least one more victim of the same kind.  Until the mechanism is
+            # understood (tools/probes/streams_race_probe.py), such a batch is not recorded.
+            return False
         for o in (og, od):
             if getattr(o, "_ddp", False):
                 # data parallel: only once the used-parameter set is frozen (no host-side flag exchange left in the step) ...

@@ -35,7 +35,7 @@ def run_pair(disc, y, y_hat):
 
 
 _STREAMS = []
-_N_STREAMS = tuning.integer("VCVITS_STREAMS", 2, "the independent sub-discriminator chains of MPD / MSD spread over N HIP streams (1: one stream)")
+_N_STREAMS = tuning.integer("VCVITS_STREAMS", 1, "the independent sub-discriminator chains of MPD / MSD spread over N HIP streams (eager loop only; 1: one stream)")
 
 
 def streams():
@@ -59,12 +59,11 @@ def join_streams():
 
 
 def run_many(discs, inputs):
-    """Run independent discriminators on their (y, y_hat) pairs.  With VCVITS_STREAMS=N > 1 (default 2) the chains
+    """Run independent discriminators on their (y, y_hat) pairs.  With VCVITS_STREAMS=N > 1 the chains
     are spread over N HIP streams so the short, low-occupancy layers (first / last convs, pooled scales)
     of one discriminator overlap the big GEMMs of another; autograd replays each chain's backward on
-    the stream it ran on.  Two streams: +4.6 % on the fp32 headline, +3.3 % on the full bf16 step (three: the same, four:
-    nothing); recorded into a HIP graph the forks cost the host 5 - 7 ms per replay.  What it needs to be CORRECT there is in
-    light/graphed.py (a root gradient outside the graph's pool) and join_streams above."""
+    the stream it ran on.  Eager loop only: a batch RECORDED with the forks replays 4 - 5 % faster (two streams: 253 vs 242
+    utterances/s on the fp32 headline) but not reliably right -- light/graphed.py refuses to record it."""
     n = streams()
     if n <= 1 or not inputs[0][0].is_cuda:
         return [run_pair(d, y, y_hat) for d, (y, y_hat) in zip(discs, inputs)]
