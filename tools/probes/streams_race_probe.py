@@ -31,19 +31,241 @@ def _force_recording():
     graphed.GraphedBatch.applicable = applicable
 
 
+def _variant_run_many():
+    """PROBE_MAP=011: chain i of a multi-discriminator goes to the side stream digit i names (instead of round robin)."""
+    from vcvits_amd.model.discriminators import _pair
+    pmap = os.environ.get("PROBE_MAP")
+    if pmap:
+        _pair._stream_of = lambda i, n: int(pmap[i % len(pmap)])
+
+
+TRACE = {"bufs": {}, "call": 0}
+
+
+def _trace_mpd1(mod):
+    """--trace-mpd1: every stage of net_period_d.discriminators[1] (input, effective weights, each layer's output) copied
+    into buffers allocated BEFORE any recording (first eager batch), per call of the batch (0: generator pass, 1: discriminator
+    pass) -- so the first replayed batch's intermediates can be laid beside the eager batch's."""
+    from vcvits_amd.model.modules import prepare_weight_norm
+    from vcvits_amd.model.discriminators.discriminator import ACT_LEAKY, LRELU_SLOPE
+    d = mod.net_period_d.discriminators[1]
+
+    def put(name, t):
+        key = (TRACE["call"], name)
+        buf = TRACE["bufs"].get(key)
+        if buf is None:
+            buf = TRACE["bufs"][key] = torch.zeros_like(t.detach(), memory_format=torch.contiguous_format)
+        buf.copy_(t.detach())
+        if ops.CAPTURING[0] is not None:
+            TRACE.setdefault("ptr", {})[key] = (t.data_ptr(), t.numel() * t.element_size())
+
+    def hook(name, t):
+        if t.requires_grad:
+            call = TRACE["call"]
+
+            def h(g):
+                old = TRACE["call"]
+                TRACE["call"] = call
+                put("d_" + name, g)
+                TRACE["call"] = old
+            t.register_hook(h)
+
+    def forward(x):
+        prepare_weight_norm(d)
+        lazy = d.convs[0].__dict__.get("_w_lazy")
+        if lazy is not None:
+            put("wbuf", lazy[0].wbuf)
+        put("in", x)
+        fmap = []
+        b, c, t = x.shape
+        x = x.view(b, c, t // d.period, d.period)
+        for i, l in enumerate(d.convs):
+            x, rec = ops.fmap_tap(l(x, out_act=ACT_LEAKY, slope=LRELU_SLOPE))
+            put("conv%d" % i, x)
+            hook("conv%d" % i, x)
+            fmap.append(rec)
+        x, rec = ops.fmap_tap(d.conv_post(x))
+        put("post", x)
+        hook("post", x)
+        fmap.append(rec)
+        TRACE["call"] += 1
+        return torch.flatten(x, 1, -1), fmap
+    d.forward = forward
+    from vcvits_amd.light import vcvits as V
+    orig = V.discriminator_loss.__wrapped__ if hasattr(V.discriminator_loss, "__wrapped__") else V.discriminator_loss
+    n = [0]
+
+    def discriminator_loss(rs, gs):
+        which = "mpd" if len(TRACE.get("seen", [])) % 2 == 0 else "msd"
+        TRACE.setdefault("seen", []).append(1)
+        TRACE["call"] = 9
+        for i, (r, g) in enumerate(zip(rs, gs)):
+            put("%s.main_sees_r%d" % (which, i), r)
+            put("%s.main_sees_g%d" % (which, i), g)
+        out = orig(rs, gs)
+        put(which + ".r_terms", torch.stack(out[1]))
+        put(which + ".g_terms", torch.stack(out[2]))
+        put(which + ".loss", out[0])
+        call = TRACE["call"]
+        for nm, t in ((which + ".loss", out[0]),) + tuple(("%s.r%d" % (which, i), r) for i, r in enumerate(rs)):
+            if t.requires_grad:
+                def h(g, nm=nm):
+                    old = TRACE["call"]
+                    TRACE["call"] = 9
+                    put("d_" + nm, g)
+                    TRACE["call"] = old
+                t.register_hook(h)
+        for i, (r, g) in enumerate(zip(rs, gs)):
+            put("%s.after_r%d" % (which, i), r)
+        return out
+    discriminator_loss.__wrapped__ = orig
+    from vcvits_amd.ops import elementwise as E
+    if not hasattr(E._LossTermsFn, "_orig_backward"):
+        E._LossTermsFn._orig_backward = E._LossTermsFn.backward
+        cnt = [0]
+
+        def backward(ctx, gout):
+            if ctx.mode == 1 and ctx.n_a == 3 and TRACE["call"] >= 2:  # the discriminator pass's MPD terms
+                tag = "bw%d." % (len(TRACE.setdefault("bw", [])) % 2)
+                TRACE["bw"].append(1)
+                old = TRACE["call"]
+                TRACE["call"] = 8
+                put(tag + "gout", gout.contiguous())
+                for i in range(3):
+                    put(tag + "a%d_before" % i, ctx.saved_tensors[1 + i])
+                res = E._LossTermsFn._orig_backward(ctx, gout)
+                for i in range(3):
+                    put(tag + "da%d" % i, res[4 + i])
+                    put(tag + "a%d_after" % i, ctx.saved_tensors[1 + i])
+                TRACE["call"] = old
+                return res
+            return E._LossTermsFn._orig_backward(ctx, gout)
+        E._LossTermsFn.backward = staticmethod(backward)
+    V.discriminator_loss = discriminator_loss
+
+
+def _dump_graphs(path):
+    """--dot PATH: every recorded graph written as a DOT file (hipGraphDebugDotPrint on the kept hipGraph_t) right after its
+    capture ends."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+    G = torch.cuda.CUDAGraph
+    n = [0]
+
+    class Kept(G):
+        def __new__(cls, *a, **k):
+            return super().__new__(cls, True)
+
+        def __init__(self, *a, **k):
+            super().__init__(True)
+
+        def capture_end(self):
+            super().capture_end()
+            rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(self.raw_cuda_graph()), ("%s.%d.dot" % (path, n[0])).encode(), 1)
+            print("hipGraphDebugDotPrint ->", rc)
+            n[0] += 1
+            self.instantiate()
+    torch.cuda.CUDAGraph = Kept
+
+
+def _trace_handoffs():
+    """--trace-hand: every gradient that passes a stream hand-off node copied out (in forward-call order per batch)."""
+    from vcvits_amd.model.discriminators import _pair
+    H = _pair._Handoff
+    of, ob = H.forward, H.backward
+
+    def forward(ctx, x, other):
+        ctx.tag = TRACE.setdefault("hand", [0])[0]
+        TRACE["hand"][0] += 1
+        ctx.fstream = torch.cuda.current_stream() == other
+        return of(ctx, x, other)
+
+    def backward(ctx, g):
+        key = (7, "hand%03d.%s.%s" % (ctx.tag, "main" if ctx.fstream else "side", "x".join(map(str, g.shape))))
+        buf = TRACE["bufs"].get(key)
+        if buf is None:
+            buf = TRACE["bufs"][key] = torch.zeros_like(g, memory_format=torch.contiguous_format)
+        buf.copy_(g)
+        return ob(ctx, g)
+    H.forward, H.backward = staticmethod(forward), staticmethod(backward)
+    from vcvits_amd.model.discriminators.multi_period_discriminator import MultiPeriodDiscriminator as MPD
+    mf = MPD.forward
+
+    def mpd_forward(self, y, y_hat, g=None):
+        if y_hat.requires_grad:
+            def h(gr):
+                key = (7, "y_hat_total")
+                buf = TRACE["bufs"].get(key)
+                if buf is None:
+                    buf = TRACE["bufs"][key] = torch.zeros_like(gr, memory_format=torch.contiguous_format)
+                buf.copy_(gr)
+            y_hat.register_hook(h)
+        return mf(self, y, y_hat, g)
+    MPD.forward = mpd_forward
+
+
+def _trace_generator(mod):
+    """--trace-gen: per generator block, its input at forward time, the same tensor again when the block's backward starts,
+    and the gradient arriving at its output."""
+    def put(name, t):
+        key = (6, name)
+        buf = TRACE["bufs"].get(key)
+        if buf is None:
+            buf = TRACE["bufs"][key] = torch.zeros_like(t.detach(), memory_format=torch.contiguous_format)
+        buf.copy_(t.detach())
+
+    def attach(name, m):
+        def fh(mod_, inp, out):
+            if not (torch.is_grad_enabled() and out.requires_grad):
+                return
+            x = inp[0]
+            put(name + ".in_fwd", x)
+
+            def h(g):
+                put(name + ".gout", g)
+                put(name + ".in_bwd", x)
+            out.register_hook(h)
+        m.register_forward_hook(fh)
+    g = mod.net_g if not hasattr(mod.net_g, "dec") else mod.net_g.dec
+    attach("conv_post", g.conv_post)
+    for i, m in enumerate(g.resblocks):
+        attach("rb%02d" % i, m)
+    for i, m in enumerate(g.ups):
+        attach("ups%d" % i, m)
+    attach("conv_pre", g.conv_pre)
+
+
 def main():
     _force_recording()
+    if "--trace-hand" in sys.argv:
+        _trace_handoffs()
+    _variant_run_many()
+    if "--dot" in sys.argv:
+        _dump_graphs(sys.argv[sys.argv.index("--dot") + 1])
     nb = 1 if "--one-batch" in sys.argv else 2
     full = "--full" in sys.argv
     dev = torch.device("cuda:0")
-    ops.set_deterministic(True)
+    ops.set_deterministic("--nondet" not in sys.argv)
     cfg = configs.base_48k() if "--48k" in sys.argv else configs.base()
+    small = "--small" in sys.argv  # the reduced-width vocoder of tests/test_graphed_gpu.py::test_graphed_step_vocoder_workload
+    if small:
+        cfg["model"].update({"inter_channels": 16, "upsample_initial_channel": 32, "multi_period_discriminator_periods": [2, 3]})
+        cfg["data"]["n_mel_channels"] = 40
+        cfg["train"]["segment_size"] = 4096
+    if "--periods23" in sys.argv:
+        cfg["model"]["multi_period_discriminator_periods"] = [2, 3]
+    if "--seg4096" in sys.argv:
+        cfg["train"]["segment_size"] = 4096
+    if "--bf16" in sys.argv:
+        ops.set_compute_dtype("bf16")
     if full:
         cfg["model"]["p_dropout"] = 0.0
     torch.manual_seed(3)
     cls = VCVITS if full else VocoderGAN
     sd = copy.deepcopy(cls(**cfg).state_dict())
-    B = 16 if "--b16" in sys.argv else 4
+    B = 16 if "--b16" in sys.argv else (2 if small or "--b2" in sys.argv else 4)
+    seg = {"segment_size": 4096} if small or "--seg4096" in sys.argv else {}
     m = cfg["model"]
     if full:
         batches = []
@@ -54,8 +276,11 @@ def main():
             b["ids_slice"] = torch.tensor(([5, 100, 17, 200] * 4)[:B], device=dev)
             batches.append(b)
     else:
-        batches = [synthetic.vocoder_batch(B, m["inter_channels"], seed=40 + i, device=dev) for i in range(2)]
+        batches = [synthetic.vocoder_batch(B, m["inter_channels"], seed=40 + i, device=dev, **seg)
+                   for i in range(2)]
     res = {}
+    if "--memhist" in sys.argv:
+        torch.cuda.memory._record_memory_history(max_entries=2000000, stacks="python")
     for mode in (False, True):
         graphed.set_batch_enabled(mode)
         mod = cls(**cfg)
@@ -64,8 +289,18 @@ def main():
         mod.configure_optimizers()
         ls = []
         snap = None
+        if "--trace-mpd1" in sys.argv:
+            _trace_mpd1(mod)
+        if "--trace-gen" in sys.argv:
+            _trace_generator(mod)
         for i in range(10):
+            TRACE["call"] = 0
+            TRACE["seen"] = []
+            TRACE["hand"] = [0]
             o = mod.fit_batch(batches[i % nb])
+            if i == 2 and TRACE["bufs"]:
+                torch.cuda.synchronize()
+                TRACE[mode] = {k: v.clone() for k, v in TRACE["bufs"].items()}
             ls.append((o["g"].item(), o["d"].item()))
             if i == 2:  # the first replayed batch: the gradients it left in the flat buffers
                 names = {id(p): n for n, p in mod.named_parameters()}
@@ -73,12 +308,32 @@ def main():
                 for tag, opt in (("G", mod.optim_g), ("D", mod.optim_d)):
                     for p, off in zip(opt.params, opt.offsets):
                         snap[tag + ":" + names[id(p)]] = opt.grad[off:off + p.numel()].clone()
+        if mode and "--memhist" in sys.argv and "ptr" in TRACE:
+            snap = torch.cuda.memory._snapshot()
+            lo, n = TRACE["ptr"][(1, "post")]
+            print("discriminator-pass output of MPD.1 while recording: 0x%x + %d" % (lo, n))
+            for ev in snap["device_traces"][0]:
+                a, sz = ev.get("addr", 0), ev.get("size", 0)
+                if a < lo + n and lo < a + sz:
+                    fr = [f for f in ev.get("frames", []) if "torch/" not in f["filename"] and "probe" not in f["filename"]][:4]
+                    print("  %-16s 0x%x + %-8d stream %-14s %s" % (ev["action"], a, sz, ev.get("stream"), " <- ".join(
+                        "%s:%d" % (os.path.basename(f["filename"]), f["line"]) for f in fr)))
         bg = mod.__dict__.get("_batch_graph")
         res[mode] = (ls, mod.optim_g.flat.clone(), mod.optim_d.flat.clone(), bg.replays if bg is not None else 0, snap)
         mod.optim_g.close()
         mod.optim_d.close()
     (l0, g0, d0, r0, s0), (l1, g1, d1, r1, s1) = res[False], res[True]
-    bad = [(k, float((s0[k] - s1[k]).abs().max()), float(s0[k].abs().max())) for k in s0 if not torch.equal(s0[k], s1[k])]
+    if False in TRACE and True in TRACE:
+        for k in sorted(TRACE[False]):
+            a, b = TRACE[False][k], TRACE[True][k]
+            if k[0] in (6, 7) and torch.equal(a, b):
+                continue
+            print("trace call %d %-6s eager |x| %.6e  replay |x| %.6e  max |diff| %.3e" % (k[0], k[1], float(a.norm()), float(b.norm()), float((a - b).abs().max())))
+    if "--nondet" in sys.argv:  # atomics: compare to a tolerance
+        bad = [(k, float((s0[k] - s1[k]).abs().max()), float(s0[k].abs().max())) for k in s0
+               if float((s0[k] - s1[k]).norm()) > 1e-3 * float(s0[k].norm()) + 1e-12]
+    else:
+        bad = [(k, float((s0[k] - s1[k]).abs().max()), float(s0[k].abs().max())) for k in s0 if k in s1 and not torch.equal(s0[k], s1[k])]
     print("gradient tensors of the first replayed batch that differ from the eager batch's: %d of %d" % (len(bad), len(s0)))
     for k, e, sc in bad[:40]:
         print("   %-60s max |diff| %.3e  (scale %.3e)" % (k, e, sc))

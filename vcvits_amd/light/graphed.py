@@ -308,12 +308,15 @@ class GraphedBatch(_Recorder):
         from ..model.discriminators._pair import streams
         if streams() > 1:
             # the sub-discriminators spread over several HIP streams are for the EAGER loop only.  Recorded with the forks the
-            # batch replays 4 - 5 % faster and not reliably right: autograd's root gradient (a pool allocation) was read
-            # stale by the branch that consumed it last -- every MPD gradient 5.13 x too large from the first replay on;
-            # fixed by `root_one` below, after which the vocoder workload replays bit-identically in deterministic mode on
-            # 2 and 3 streams -- but the bf16 / reduced-width / forced-DDP cases of tests/test_graphed_gpu.py still replay
-            # wrong losses (9 % off), so there is at least one more victim of the same kind.  Until the mechanism is
-            # understood (tools/probes/streams_race_probe.py), such a batch is not recorded.
+            # batch replays 4 - 5 % faster -- and, for some deals of the chains to the streams, wrong (3 of the 8 deals of three
+            # chains to two streams; round robin is not one of them).  Three causes were found and removed: autograd's root
+            # gradient read stale (`root_one` below), gradient blocks recycled by the stream that allocated them before the
+            # other stream had read them (_pair._Handoff), device-to-device copy nodes (_pair._Halves).  What is left is not
+            # in the recording: the dumped graph of a failing deal has every edge it needs (reachability over all node
+            # pairs: nothing is unordered against the generator's backward pass, where the first wrong value appears), the
+            # allocator history shows no overlap, and the SAME graph replays bit-exactly on one graph queue
+            # (DEBUG_HIP_FORCE_GRAPH_QUEUES=1) or two hardware queues (GPU_MAX_HW_QUEUES=2) -- which also removes the gain.
+            # profiles/r6_multistream_replay_probe.txt; tools/probes/streams_race_probe.py reproduces every step.
             return False
         for o in (og, od):
             if getattr(o, "_ddp", False):
