@@ -188,8 +188,11 @@ class FlatAdamW(torch.optim.Optimizer):
         """Average every bucket across the group, blocking form on the current stream (segmented replay)."""
         if not self._ddp:
             return
+        avg = dist.get_backend(self.pg) == "nccl"  # (gloo has no AVG: sum, then scale -- as _launch_bucket does)
         for view in self.bucket_views():
-            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
+            dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg)
+            if not avg:
+                view.div_(self.world)
 
     def _launch_bucket(self, b):
         view = self.grad[b["lo"]:b["hi"]]
