@@ -73,6 +73,37 @@ def test_fused_pair_equals_two_launches_and_the_cpu_arithmetic(gpu, C, K, dil, T
     assert (ys.float().cpu() - ref / 3).abs().max().item() <= 6e-3 * scale
 
 
+@pytest.mark.parametrize("C,K,dil,T,B,grid", [(64, 11, 3, 2504, 2, 3), (64, 7, 5, 2000, 3, 2), (64, 11, 1, 1520, 2, 1),
+                                              (32, 11, 5, 2504, 2, 3), (64, 3, 3, 2000, 2, 2)])
+def test_persistent_workgroups_walk_many_tiles(gpu, C, K, dil, T, B, grid):
+    """A grid of 1 - 3 workgroups walks 12 - 30 tiles each: the weight ring of the streamed variants (64 channels, K >= 7)
+    runs on across tiles -- its slab positions shift by 2 K mod 4 per tile and the first slabs of the NEXT tile are copied
+    under the epilogue of the current one -- and the next tile's input prefetch rides over both convs.  Bit-identical to the
+    same launch on the default grid (one tile per workgroup at these sizes)."""
+    from vcvits_amd import ops
+    from vcvits_amd._lib import lib
+    x, w1, b1, w2, b2 = _inputs(B, C, K, T, seed=C + K + dil)
+    xg, w1g, b1g, w2g, b2g = (t.to(gpu) for t in (x, w1, b1, w2, b2))
+    ops.set_compute_dtype("bf16")
+    try:
+        y0 = ops.resblock_pair_x16(xg, w1g, b1g, w2g, b2g, dil, slope=SLOPE)
+        assert lib().vcv_tuning_set(b"pair_grid", grid) == 0
+        try:
+            y1 = ops.resblock_pair_x16(xg, w1g, b1g, w2g, b2g, dil, slope=SLOPE)
+            acc0 = (torch.randn(B, C, T, generator=torch.Generator().manual_seed(7)) * 0.3).half().to(gpu)
+            ya = ops.resblock_pair_x16(xg, w1g, b1g, w2g, b2g, dil, slope=SLOPE, out=acc0.clone(), accumulate=True, post_scale=0.5)
+        finally:
+            lib().vcv_tuning_set(b"pair_grid", 0)
+        yb = ops.resblock_pair_x16(xg, w1g, b1g, w2g, b2g, dil, slope=SLOPE, out=acc0.clone(), accumulate=True, post_scale=0.5)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype("f32")
+    assert torch.equal(y0, y1), float((y0.float() - y1.float()).abs().max())
+    assert torch.equal(ya, yb)
+    ref = _cpu_reference(x, w1, b1, w2, b2, dil)
+    assert (y1.float().cpu() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
+
+
 def test_fused_pair_declines_what_does_not_fit(gpu):
     from vcvits_amd import ops
     x = torch.zeros(1, 64, 512, dtype=torch.float16, device=gpu)

@@ -70,7 +70,7 @@ struct Geo {
   static constexpr bool BOTHW = (size_t)2 * WSLOTS * 16 <= 56 * 1024;  // both convs' weights resident at once
   // otherwise (64 channels, K >= 7: 57 - 90 KB per conv) the weights are STREAMED: one slab = one tap of one conv
   // ([cg][h][m]: CG * 2 * C slots = 8 KB at C = 64 -- exactly one 16-byte slot per thread of the workgroup) through a ring of
-  // NRING slabs, loaded two taps ahead into a register and written to the ring before the tap's barrier
+  // NRING slabs, copied three taps ahead by LDS-DMA (conv_mma)
   static constexpr int SLAB = CG * 2 * C;
   static constexpr int NRING = 4;
   static constexpr int W_LDS_SLOTS = BOTHW ? 2 * WSLOTS : NRING * SLAB;
@@ -90,7 +90,7 @@ __host__ __device__ constexpr int xs_slots(int dil) {
 template <int C, int K, int WHICH, int TM, int TNW>
 __device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* W, const bf16x8* __restrict__ wpg,
                                          const bf16x8* __restrict__ img, int pitch, int dstep, int shift, int wave, int l31,
-                                         int h) {
+                                         int h, int gbase) {
   constexpr int CG = C / 16;
   if constexpr (C == 32) {
     bf16x8 a[K][CG];
@@ -110,17 +110,31 @@ __device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* W
       }
     }
   } else if constexpr (!Geo<C, K>::BOTHW) {
-    // streamed weights: W = the ring, wpg = the packed weights in global memory, WHICH * K = this conv's first slab
+    // streamed weights: W = the ring of four slabs, wpg = the packed weights in global memory, WHICH * K = this conv's first
+    // slab.  The ring runs on ACROSS tiles (the 2 K slabs repeat; gbase = ring position of the pair's slab 0).  Tap `sidx`
+    // reads ring slot (gbase + sidx) & 3 and starts the LDS-DMA of slab sidx + 3 into the slot the PREVIOUS tap read (free
+    // since that tap's barrier); the tap's barrier waits for all but the two youngest DMAs (vmcnt(2)), i.e. for slab
+    // sidx + 1.  A copy has two taps of MFMAs to land, takes no registers, and the next tile's first slabs arrive under the
+    // epilogue.  The first form loaded slab sidx + 2 into a register and wrote it to the ring in the same tap: the compiler
+    // sank the load down to the write -- `global_load; s_waitcnt vmcnt(0); ds_write` at the end of every tap, the whole L2
+    // latency exposed 2 K times per tile under a workgroup barrier (MFMA pipe 23 - 27 % busy, 54 % of the wave-cycles in
+    // s_waitcnt: profiles/r6_infer_stall_counters.txt) -- plus two exposed loads and a barrier at the head of every tile.
     constexpr int SLAB = Geo<C, K>::SLAB, NR = Geo<C, K>::NRING;
     static_assert(SLAB == 64 * NWAVE, "one 16-byte slot of a slab per thread");
+    static_assert(NR == 4, "ring positions are taken & 3; the DMA runs three slabs ahead");
     const int tid = wave * 64 + l31 + 32 * h;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // (Double-buffering the fragments by hand -- the reads of step (j, cg + 1) issued before the MFMAs of step (j, cg) --
+    // measured the same 3.85 ms at K = 11: with A fragments re-read by all eight waves the tap moves 96 KB through an LDS
+    // that passes 128 B / clock, 768 clocks against 512 of MFMA work per SIMD; the read LATENCY is not the bound.)
 #pragma unroll 1
     for (int j = 0; j < K; ++j) {
       const int sidx = WHICH * K + j;
-      bf16x8 wnext;
-      const bool pre = sidx + 2 < 2 * K;
-      if (pre) wnext = wpg[(sidx + 2) * SLAB + tid];
-      const bf16x8* Wj = W + (sidx & (NR - 1)) * SLAB;
+      const int cur = gbase + sidx;
+      const int nid = sidx + 3 < 2 * K ? sidx + 3 : sidx + 3 - 2 * K;
+      __builtin_amdgcn_global_load_lds((const void*)(wpg + nid * SLAB + tid),
+                                       (lds_ptr)(const_cast<bf16x8*>(W) + ((cur + 3) & (NR - 1)) * SLAB + wave * 64), 16, 0, 0);
+      const bf16x8* Wj = W + (cur & (NR - 1)) * SLAB;
 #pragma unroll
       for (int cg = 0; cg < CG; ++cg) {
         bf16x8 a[TM], bb[TNW];
@@ -133,8 +147,9 @@ __device__ __forceinline__ void conv_mma(f32x16 (&acc)[TM][TNW], const bf16x8* W
 #pragma unroll
           for (int tn = 0; tn < TNW; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
       }
-      if (pre) const_cast<bf16x8*>(W)[((sidx + 2) & (NR - 1)) * SLAB + tid] = wnext;
-      __syncthreads();  // slab sidx + 2 is in place, slab sidx is free (all waves are past this tap)
+      // all but the two youngest DMAs have landed: slab sidx + 1 (this wave's part; the barrier makes it everybody's), and
+      // every wave is past its reads of slab sidx
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   } else {
 #pragma unroll 1
@@ -234,8 +249,14 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
   int tile = blockIdx.x;
   if (tile >= total_tiles) return;
   issue(tile);
-  if (G::BOTHW)
+  int gbase = 0;  // streamed weights: ring position of the pair's slab 0 (conv_mma)
+  if (G::BOTHW) {
     for (int i = tid; i < 2 * G::WSLOTS; i += 64 * NWAVE) Ws[i] = p.wp[i];
+  } else {  // the first three slabs; from here on the ring feeds itself, across tiles
+    Ws[tid] = p.wp[tid];
+    Ws[G::SLAB + tid] = p.wp[G::SLAB + tid];
+    Ws[2 * G::SLAB + tid] = p.wp[2 * G::SLAB + tid];
+  }
   stage(tile);
   __syncthreads();
 
@@ -245,11 +266,6 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
     const int next = tile + (int)gridDim.x;
     const bool more = next < total_tiles;
     if (more) issue(next);  // in flight under this tile's two convs
-    if (!G::BOTHW) {        // streamed weights: the first two slabs of conv1 (the ring is free: the tile before ended with a barrier)
-      Ws[tid] = p.wp[tid];
-      Ws[G::SLAB + tid] = p.wp[G::SLAB + tid];
-      __syncthreads();
-    }
 
     // ---- conv1: xt[m][n], n in [0, N1): wave w owns n-tiles w * TNW .. ----
     f32x16 acc[TM][TNW];
@@ -259,7 +275,7 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
       for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
-    conv_mma<C, K, 0>(acc, Ws, p.wp, Xs, xs_n, dil, sh, wave, l31, h);
+    conv_mma<C, K, 0>(acc, Ws, p.wp, Xs, xs_n, dil, sh, wave, l31, h, gbase);
     // epilogue 1: + b1, leaky, bf16 -> XTs; columns outside [0, T) are the zero padding of conv2's input
 #pragma unroll
     for (int tn = 0; tn < TNW; ++tn) {
@@ -312,7 +328,8 @@ resblock_pair_kernel(const PairArgs p, const int xs_n, const int total_tiles) {
       for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
-    conv_mma<C, K, 1>(acc, Ws + (G::BOTHW ? G::WSLOTS : 0), p.wp, XTs, G::XT_SLOTS, 1, 0, wave, l31, h);
+    conv_mma<C, K, 1>(acc, Ws + (G::BOTHW ? G::WSLOTS : 0), p.wp, XTs, G::XT_SLOTS, 1, 0, wave, l31, h, gbase);
+    gbase = (gbase + 2 * K) & 3;
     // epilogue 2 through the wave's LDS tile (the Xs region: nobody reads it after conv1's barrier): rows of eight consecutive
     // positions per lane, + b2 + x (fp16, re-read: L2), [y += post_scale * out], one rounding to fp16, 16-byte stores
     {
