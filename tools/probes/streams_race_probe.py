@@ -1,6 +1,14 @@
 """Race detector for the multi-stream discriminators inside a recorded batch: in deterministic mode (no atomics anywhere in
-the GAN step) the replayed batches must equal the eager loop BIT FOR BIT, whatever the stream count.
-  VCVITS_STREAMS=2 python tools/probes/streams_race_probe.py [--full] [--one-batch]"""
+the GAN step) the replayed batches must equal the eager loop BIT FOR BIT, whatever the stream count.  GraphedBatch does not
+record with VCVITS_STREAMS > 1; this probe makes it (profiles/r6_multistream_replay_probe.txt).
+  VCVITS_STREAMS=2 [PROBE_MAP=001] python tools/probes/streams_race_probe.py [options]
+    --full / --small / --periods23 / --seg4096 / --b2 / --b16 / --48k / --bf16 / --nondet / --one-batch   the workload
+    PROBE_MAP=abc        chain i of a multi-discriminator on side stream digit i (default: round robin)
+    PROBE_NOHAND=1       without the gradient hand-off nodes (model/discriminators/_pair.py: _Handoff)
+    --trace-mpd1         every stage of one DiscriminatorP, forward and backward, eager batch beside first replayed batch
+    --trace-hand         the gradient at every stream hand-off; --trace-gen: inputs / output gradients of every generator block
+    --memhist            allocator history of the block one wrong value was read from (with --trace-mpd1)
+    --dot PATH           hipGraphDebugDotPrint of every recorded graph (tools/probes/graph_dot_check.py reads them)"""
 import copy
 import os
 import sys
@@ -32,11 +40,14 @@ def _force_recording():
 
 
 def _variant_run_many():
-    """PROBE_MAP=011: chain i of a multi-discriminator goes to the side stream digit i names (instead of round robin)."""
+    """PROBE_MAP=011: chain i of a multi-discriminator goes to the side stream digit i names (instead of round robin);
+    PROBE_NOHAND=1: no gradient hand-off nodes at the stream boundaries."""
     from vcvits_amd.model.discriminators import _pair
     pmap = os.environ.get("PROBE_MAP")
     if pmap:
         _pair._stream_of = lambda i, n: int(pmap[i % len(pmap)])
+    if os.environ.get("PROBE_NOHAND") == "1":
+        _pair._hand = lambda t, other: t
 
 
 TRACE = {"bufs": {}, "call": 0}
